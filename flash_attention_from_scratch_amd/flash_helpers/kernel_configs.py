@@ -1,0 +1,439 @@
+"""Kernel-config surface of the MI355X build (torch-free, like the reference's).
+
+Mirrors the public names of the reference's ``py/flash_helpers/kernel_configs.py``
+(reference file:line cited per item) so tests, autotune and bench scripts written
+against the reference keep working.  The 13-field key is unchanged; what the
+fields *select* on CDNA4 is documented in DESIGN.md ("config -> device variant"):
+
+* ``B_r`` / ``B_c``      Q rows per workgroup / keys per LDS tile.
+* ``n_warps``            wave64 wavefronts per workgroup (64 lanes, not 32).
+* ``async_copy``         K/V tiles by direct global->LDS DMA (vs register staged).
+* ``eager_load_blocks``  next K/V tile prefetched into the second LDS buffer.
+* ``swizzled``           XOR-swizzled K image (conflict-free ds_read_b128).
+* ``*_mma_load_K_tiles`` / ``mma_double_buffer_loads``  operand-fetch schedule
+  hints; validated exactly like the reference, but the CDNA4 compiler schedules
+  LDS->MFMA operand reads itself, so they map onto the same device code.
+* ``optimized_softmax``  first K/V block skips the rescale of (l, O).
+"""
+
+import itertools
+import os
+import re
+from dataclasses import dataclass, fields, replace
+from enum import IntEnum
+
+ELEM_SIZE = 2  # bytes per fp16/bf16 element
+
+
+class DType(IntEnum):
+    """torch ScalarType codes without importing torch (ref kernel_configs.py:9-13)."""
+
+    FP16 = 5
+    BF16 = 15
+
+    def to_cpp_str(self) -> str:
+        # ref kernel_configs.py:15-21 (kept for name-parsing round trips)
+        return {DType.FP16: "torch::kFloat16", DType.BF16: "torch::kBFloat16"}[self]
+
+    def to_torch_dtype(self):
+        import torch
+
+        return {DType.FP16: torch.float16, DType.BF16: torch.bfloat16}[self]
+
+    def to_c_abi(self) -> int:
+        """Value of ``fa_dtype`` in include/fa_hip.h (same integers)."""
+        return int(self)
+
+    @classmethod
+    def from_string(cls, dtype_str: str) -> "DType":
+        """'fp16' / 'BF16' / '5' / '15' -> DType (ref kernel_configs.py:34-55)."""
+        text = dtype_str.strip()
+        if re.fullmatch(r"[+-]?\d+", text):
+            return cls(int(text))
+        try:
+            return cls[text.upper()]
+        except KeyError:
+            options = [f"{m.name} ({m.value})" for m in cls]
+            raise ValueError(
+                f"Invalid dtype string '{text.upper()}'. Valid options: {options}"
+            ) from None
+
+
+# ---------------------------------------------------------------------------
+# FLOP / byte model (ref kernel_configs.py:61-103).  calc_self_attn_flop is the
+# reference's headline convention; 4*B*H*S^2*d is the roofline figure.
+# ---------------------------------------------------------------------------
+def tile_softmax_flop(B_r, B_c, d_head) -> int:
+    return B_r * (4 * B_c + d_head + 4)
+
+
+def kv_tile_flop(B_r, B_c, d_head) -> int:
+    matmuls = 2 * (2 * B_r * B_c * d_head)  # S = Q K^T and O += P V
+    return matmuls + tile_softmax_flop(B_r, B_c, d_head)
+
+
+def gmem_transfer_size(B_r, B_c, d_head) -> int:
+    return 2 * d_head * (B_r + B_c) * ELEM_SIZE
+
+
+def arithmetic_intensity(B_r, B_c, kv_seq_len, d_head) -> float:
+    flop = kv_tile_flop(B_r, B_c, d_head) * (kv_seq_len // B_c)
+    return flop / gmem_transfer_size(B_r, kv_seq_len, d_head)
+
+
+def calc_total_flop(n_samples, n_heads, seq_len, B_r, B_c, d_head):
+    if seq_len % B_r or seq_len % B_c:
+        raise AssertionError("seq_len must be a multiple of B_r and B_c")
+    q_blocks, kv_blocks = seq_len // B_r, seq_len // B_c
+    per_q_block = kv_blocks * kv_tile_flop(B_r, B_c, d_head) + B_r * d_head
+    return n_samples * n_heads * q_blocks * per_q_block
+
+
+def calc_self_attn_flop(n_samples, n_heads, seq_len, d_head):
+    return n_samples * n_heads * (4 * seq_len**2 * d_head + 6 * seq_len**2)
+
+
+def calc_mfma_flop(n_samples, n_heads, seq_len, d_head):
+    """Algorithmic matmul FLOPs 4*B*H*S^2*d -- the roofline numerator."""
+    return 4 * n_samples * n_heads * seq_len**2 * d_head
+
+
+_FLAG_WORDS = (
+    ("async_copy", "async"),
+    ("eager_load_blocks", "eager"),
+    ("swizzled", "swizzled"),
+)
+_TAIL_WORDS = (
+    ("mma_double_buffer_loads", "buffer"),
+    ("optimized_softmax", "opt_softmax"),
+)
+
+
+@dataclass(frozen=True, order=True)
+class FlashForwardKernelConfig:
+    """13-field kernel key (ref kernel_configs.py:106-120, flash_attention.cuh:34-52)."""
+
+    dtype: DType
+    d_head: int
+    B_r: int
+    B_c: int
+    n_warps: int
+    async_copy: bool
+    eager_load_blocks: bool
+    swizzled: bool
+    Q_mma_load_K_tiles: int
+    K_mma_load_K_tiles: int
+    V_mma_load_K_tiles: int
+    mma_double_buffer_loads: bool
+    optimized_softmax: bool
+
+    def __str__(self):
+        return self.short_form()
+
+    def short_form(self, include_d_head=True, include_tup=True):
+        """'(FP16, 128, 64, 64, 4): async+eager+...' (ref kernel_configs.py:125-147)."""
+        words = [word for attr, word in _FLAG_WORDS if getattr(self, attr)]
+        words.append(
+            "load_%d_%d_%d_tiles"
+            % (self.Q_mma_load_K_tiles, self.K_mma_load_K_tiles, self.V_mma_load_K_tiles)
+        )
+        words += [word for attr, word in _TAIL_WORDS if getattr(self, attr)]
+        features = "+".join(words)
+        if not include_tup:
+            return features
+        dims = [self.dtype.name]
+        if include_d_head:
+            dims.append(str(self.d_head))
+        dims += [str(self.B_r), str(self.B_c), str(self.n_warps)]
+        return f"({', '.join(dims)}): {features}"
+
+    def to_cpp_struct(self) -> str:
+        """Brace initialiser as the reference's generator writes it (ref :149-165)."""
+
+        def lit(value):
+            if isinstance(value, DType):
+                return value.to_cpp_str()
+            if isinstance(value, bool):
+                return "true" if value else "false"
+            return str(int(value))
+
+        return "FlashForwardKernelConfig{%s}" % ", ".join(
+            lit(getattr(self, f.name)) for f in fields(self)
+        )
+
+    def to_c_abi_tuple(self):
+        """The 13 ints of ``fa_fwd_config`` (include/fa_hip.h), in field order."""
+        return tuple(int(getattr(self, f.name)) for f in fields(self))
+
+    def kernel_name(self) -> str:
+        return "flash_forward_kernel"
+
+    def smem_bytes(self, elem_size=ELEM_SIZE) -> int:
+        """Reference formula (flash_attention.cuh:54-56); LDS use of the HIP kernel
+        is reported by fa_fwd_lds_bytes() and differs (double-buffered K/V, Q in VGPRs)."""
+        return (self.B_r + 2 * self.B_c) * self.d_head * elem_size
+
+    def total_flop(self, n_samples: int, n_heads: int, seq_len: int) -> int:
+        return calc_total_flop(n_samples, n_heads, seq_len, self.B_r, self.B_c, self.d_head)
+
+    def attn_flop(self, n_samples: int, n_heads: int, seq_len: int) -> int:
+        return calc_self_attn_flop(n_samples, n_heads, seq_len, self.d_head)
+
+    def mfma_flop(self, n_samples: int, n_heads: int, seq_len: int) -> int:
+        return calc_mfma_flop(n_samples, n_heads, seq_len, self.d_head)
+
+
+# ---------------------------------------------------------------------------
+# Name parsers (ref kernel_configs.py:178-330): three spellings of a config.
+# ---------------------------------------------------------------------------
+_BRACES = re.compile(r"FlashForwardKernelConfig\{([^}]*)\}")
+_N_FIELDS = len(fields(FlashForwardKernelConfig))
+
+
+def _build(values):
+    if len(values) != _N_FIELDS:
+        raise ValueError("Incorrect number of parameters parsed")
+    kw = {}
+    for f, v in zip(fields(FlashForwardKernelConfig), values):
+        if f.name == "dtype":
+            kw[f.name] = v if isinstance(v, DType) else DType(int(v))
+        elif f.type is bool or f.type == "bool":
+            kw[f.name] = bool(int(v))
+        else:
+            kw[f.name] = int(v)
+    return FlashForwardKernelConfig(**kw)
+
+
+def _parse_flash_forward_demanged_name(line) -> FlashForwardKernelConfig:
+    """'...FlashForwardKernelConfig{5, 128, 64, 64, 4, 1, 1, 1, 0, 2, 0, 1, 1}...'"""
+    found = _BRACES.search(line)
+    if not found:
+        raise ValueError("Invalid line format: FlashForwardKernelConfig not found")
+    words = {"true": 1, "false": 0}
+    values = []
+    for token in found.group(1).split(","):
+        token = token.strip()
+        values.append(words[token] if token in words else int(token))
+    return _build(values)
+
+
+def _parse_flash_forward_demanged_name_with_types(line: str) -> FlashForwardKernelConfig:
+    """'...{(c10::ScalarType)5, (int)128, ..., (bool)1}...' (typed demangling)."""
+    found = _BRACES.search(line)
+    if not found:
+        raise ValueError("Invalid line format: FlashForwardKernelConfig block not found")
+    values = []
+    for token in found.group(1).split(","):
+        cast = re.fullmatch(r"\s*\((c10::ScalarType|int|bool)\)\s*(\S+)\s*", token)
+        if not cast:
+            raise ValueError(f"Unexpected parameter format: {token.strip()}")
+        kind, text = cast.groups()
+        values.append(DType.from_string(text) if kind == "c10::ScalarType" else int(text))
+    return _build(values)
+
+
+_SHORT = re.compile(r"\(([^)]*)\):\s*([^|\s]+)")
+
+
+def _parse_short_form_flash_forward_kernel_config(line: str) -> FlashForwardKernelConfig:
+    """'(FP16, 128, 64, 64, 4): async+eager+swizzled+load_0_2_2_tiles+opt_softmax'
+    optionally embedded in a '|'-separated table row."""
+    cells = [c.strip() for c in line.split("|") if c.strip()]
+    if not cells:
+        raise ValueError(f"Cannot parse line (empty after splitting): {line}")
+    found = _SHORT.match(cells[0])
+    if not found:
+        raise ValueError(f"Cannot parse config string (no matching pattern): {cells[0]}")
+    dims = [d.strip() for d in found.group(1).split(",")]
+    if len(dims) != 5:
+        raise ValueError(f"Cannot parse config tuple: {found.group(1)}")
+    words = found.group(2).split("+")
+    loads = [w for w in words if w.startswith("load_") and w.endswith("_tiles")]
+    if not loads:
+        raise ValueError(f"Cannot find load segment in features: {found.group(2)}")
+    q_t, k_t, v_t = (int(x) for x in loads[0][len("load_"):-len("_tiles")].split("_"))
+    flags = {attr: (word in words) for attr, word in _FLAG_WORDS + _TAIL_WORDS}
+    return FlashForwardKernelConfig(
+        dtype=DType.from_string(dims[0]),
+        d_head=int(dims[1]),
+        B_r=int(dims[2]),
+        B_c=int(dims[3]),
+        n_warps=int(dims[4]),
+        Q_mma_load_K_tiles=q_t,
+        K_mma_load_K_tiles=k_t,
+        V_mma_load_K_tiles=v_t,
+        **flags,
+    )
+
+
+def parse_kernel_name_into_config(kernel_name: str) -> FlashForwardKernelConfig:
+    for parser in (
+        _parse_flash_forward_demanged_name,
+        _parse_flash_forward_demanged_name_with_types,
+        _parse_short_form_flash_forward_kernel_config,
+    ):
+        try:
+            return parser(kernel_name)
+        except (ValueError, KeyError):
+            continue
+    raise ValueError(f"Invalid kernel name: {kernel_name}")
+
+
+# Names a rocprofv3 kernel trace shows for the comparators this build benches
+# against (the reference maps Dao-AILab FA2/FA3 CUDA symbols here, :333-341;
+# those wheels do not exist on ROCm -- torch SDPA is the comparator).
+REF_KERNEL_NAME_MAP = {
+    "torch.sdpa": "Reference",
+}
+
+
+def transform_kernel_name_to_short_form(kernel_name: str) -> str:
+    if kernel_name in REF_KERNEL_NAME_MAP:
+        return REF_KERNEL_NAME_MAP[kernel_name]
+    return parse_kernel_name_into_config(kernel_name).short_form()
+
+
+def transform_kernel_name(kernel_name: str) -> str:
+    try:
+        return parse_kernel_name_into_config(kernel_name).short_form()
+    except ValueError:
+        return kernel_name
+
+
+# ---------------------------------------------------------------------------
+# Enumerations (ref kernel_configs.py:364-485)
+# ---------------------------------------------------------------------------
+def should_autotune_config(cfg: FlashForwardKernelConfig) -> bool:
+    """Same pruning rule as the reference (:364-386) so the drop-in list is identical."""
+    if cfg.eager_load_blocks and not cfg.async_copy:
+        return False
+    q_t, k_t = cfg.Q_mma_load_K_tiles, cfg.K_mma_load_K_tiles
+    if q_t not in (0, k_t):
+        return False
+    if cfg.B_r == 64:
+        if cfg.n_warps == 8:
+            return False
+        if cfg.B_c == 32 and q_t == 0:
+            return False
+        if cfg.B_c == 64 and q_t != 0:
+            return False
+    elif cfg.B_r == 128 and q_t == 0:
+        return False
+    return True
+
+
+def get_autotuning_kernel_configs(dtypes=(DType.BF16, DType.FP16)):
+    """The reference's 80-config sweep (40 per dtype), same order (:389-423)."""
+    axes = [
+        list(dtypes),
+        [128],  # d_head
+        [64, 128],  # B_r
+        [32, 64],  # B_c
+        [4],  # n_warps
+        [True],  # async_copy
+        [True],  # eager_load_blocks
+        [True],  # swizzled
+        [0, 2],  # Q_mma_load_K_tiles
+        [0, 2],  # K_mma_load_K_tiles
+        [0, 2],  # V_mma_load_K_tiles
+        [False, True],  # mma_double_buffer_loads
+        [False, True],  # optimized_softmax
+    ]
+    candidates = (FlashForwardKernelConfig(*point) for point in itertools.product(*axes))
+    return [cfg for cfg in candidates if should_autotune_config(cfg)]
+
+
+_PROGRESSION = (
+    "async+load_0_0_0_tiles",
+    "async+swizzled+load_0_0_0_tiles",
+    "async+eager+swizzled+load_0_0_0_tiles",
+    "async+eager+swizzled+load_2_2_2_tiles",
+    "async+eager+swizzled+load_2_2_2_tiles+buffer",
+    "async+eager+swizzled+load_2_2_2_tiles+buffer+opt_softmax",
+    "async+eager+swizzled+load_0_2_2_tiles+opt_softmax",
+)
+
+
+def get_kernel_progression_configs(all_block_sizes=False):
+    """The reference's 7-step story at (FP16, 128, 64, 64, 4) (:426-455)."""
+    steps = [
+        _parse_short_form_flash_forward_kernel_config(f"(FP16, 128, 64, 64, 4): {s}")
+        for s in _PROGRESSION
+    ]
+    if not all_block_sizes:
+        return steps
+    out = []
+    for step in steps:
+        for B_r, B_c, n_warps in itertools.product([128, 64], [128, 64, 32], [4, 8]):
+            if (B_r < 128 and n_warps == 8) or B_r < B_c:
+                continue
+            out.append(replace(step, B_r=B_r, B_c=B_c, n_warps=n_warps))
+    return out
+
+
+def get_native_kernel_configs(dtypes=(DType.BF16, DType.FP16)):
+    """CDNA4-native tile shapes beyond the reference's list: wave64 workgroups of
+    4 or 8 waves, 32 or 64 Q rows per wave, 64/128-key LDS tiles.  These are the
+    shapes the MI355X autotune sweeps (KERNELS=native / KERNELS=tune)."""
+    shapes = [
+        # (B_r, B_c, n_waves)
+        (128, 64, 4),
+        (128, 128, 4),
+        (256, 64, 8),
+        (256, 128, 8),
+        (256, 32, 8),
+        (256, 64, 4),
+        (256, 128, 4),
+    ]
+    out = []
+    for dtype in dtypes:
+        for B_r, B_c, n_waves in shapes:
+            for opt in (False, True):
+                out.append(
+                    FlashForwardKernelConfig(
+                        dtype, 128, B_r, B_c, n_waves, True, True, True, 0, 0, 0, False, opt
+                    )
+                )
+    return out
+
+
+def get_kernels_to_build():
+    """The drop-in list: exactly the reference's built set (:458-463)."""
+    return sorted(set(get_autotuning_kernel_configs()))
+
+
+def get_all_supported_configs():
+    """Everything libfa_hip.so accepts that these helpers can enumerate."""
+    cfgs = set(get_autotuning_kernel_configs())
+    cfgs.update(get_native_kernel_configs())
+    cfgs.update(get_kernel_progression_configs())
+    return sorted(cfgs)
+
+
+def get_kernel_configs(kernels_key=""):
+    """KERNELS env selector (ref :466-485) plus 'native' for the CDNA4 shapes."""
+    if kernels_key == "":
+        kernels_key = os.environ.get("KERNELS", "")
+    if kernels_key.startswith("prog"):
+        return get_kernel_progression_configs(all_block_sizes="all" in kernels_key)
+    if kernels_key == "all":
+        return get_kernels_to_build()
+    if kernels_key == "tune":
+        return get_autotuning_kernel_configs()
+    if kernels_key == "native":
+        return get_native_kernel_configs()
+    if kernels_key == "best":
+        return [best_config(DType.BF16), best_config(DType.FP16)]
+    if "," in kernels_key:
+        B_r, B_c = (int(x) for x in kernels_key.split(","))
+        pool = get_autotuning_kernel_configs() + get_native_kernel_configs()
+        return [cfg for cfg in pool if (cfg.B_r, cfg.B_c) == (B_r, B_c)]
+    raise ValueError(f"Invalid kernels env key: {kernels_key}")
+
+
+def best_config(dtype=DType.BF16) -> FlashForwardKernelConfig:
+    """Config bench.py uses for the headline number (updated from autotune runs;
+    see profiles/ and DESIGN.md)."""
+    return FlashForwardKernelConfig(
+        DType(dtype), 128, 256, 64, 8, True, True, True, 0, 0, 0, False, True
+    )

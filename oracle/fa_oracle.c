@@ -1,0 +1,326 @@
+/*
+ * fa_oracle.c -- CPU restatement of the reference's Flash-Attention-2 forward.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in the product path (the package
+ * flash_attention_from_scratch_amd/, libfa_hip.so) links, loads or calls this
+ * file; only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg do.
+ *
+ * Parity status: PINNED.  The reference holds no golden vectors of its own
+ * (SURVEY.md 8c); the restatement is checked against fixtures generated in the
+ * build container by importing the reference's Python oracles
+ * (py/flash_helpers/test/utils.py:137-162 py_flash_attention and
+ * tools/debug/debug.py:40-153 block_flash_attention) -- see oracle/gen_golden.py
+ * and tests/golden/.
+ *
+ * What is restated (all /root/reference paths):
+ *   src/include/forward_kernel.cuh:19-83   process_kv_block   -> kv_block_step()
+ *   src/include/forward_kernel.cuh:85-204  flash_forward_kernel -> q_block_forward()
+ *   src/include/softmax.cuh:13-34          calc_row_max (raw-logit running max)
+ *   src/include/softmax.cuh:36-49          scale_l_O    (exp2((m_prev-m)*c))
+ *   src/include/softmax.cuh:51-64          exponentiate_tensor (exp2(s*c - m*c))
+ *   src/include/softmax.cuh:66-83          update_row_exp_sum  (fp32 P, pre-rounding)
+ *   src/include/softmax.cuh:107-128        final_softmax_normalization (O *= 1/l)
+ *   src/include/load_store.cuh:314-353     convert_to_16_bit_dtype (RNE; P and O)
+ *   src/flash_attention.cu:100-112         grid = (S/B_r, H, B), reverse KV order
+ *
+ * Invariants reproduced: KV blocks visited last-to-first; the running max is of
+ * the UNSCALED logits and the scale c = rsqrt(d)*log2(e) is applied inside the
+ * base-2 exponent; P is rounded to the 16-bit type before P.V while l sums the
+ * fp32 P; O is multiplied by 1/l and rounded RNE to the 16-bit type.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define FA_ORACLE_FP16 5  /* torch ScalarType codes, kernel_configs.py:12-13 */
+#define FA_ORACLE_BF16 15
+
+/* ---------- 16-bit <-> fp32, round-to-nearest-even ---------- */
+static inline float u32_as_f32(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+static inline uint32_t f32_as_u32(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+
+static inline float bf16_to_f32(uint16_t h) { return u32_as_f32((uint32_t)h << 16); }
+static inline uint16_t f32_to_bf16(float f) {
+    uint32_t u = f32_as_u32(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40); /* NaN */
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+
+static inline float fp16_to_f32(uint16_t h) {
+    uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
+    uint32_t exp = (h >> 10) & 0x1fu;
+    uint32_t man = h & 0x3ffu;
+    if (exp == 0) {
+        if (man == 0) return u32_as_f32(sign);
+        float v = (float)man * 5.9604644775390625e-8f; /* 2^-24 */
+        return sign ? -v : v;
+    }
+    if (exp == 31) return u32_as_f32(sign | 0x7f800000u | (man << 13));
+    return u32_as_f32(sign | ((exp + 112u) << 23) | (man << 13));
+}
+static inline uint16_t f32_to_fp16(float f) {
+    uint32_t u = f32_as_u32(f);
+    uint16_t sign = (uint16_t)((u >> 16) & 0x8000u);
+    uint32_t a = u & 0x7fffffffu;
+    if (a > 0x7f800000u) return (uint16_t)(sign | 0x7e00u);          /* NaN */
+    if (a >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u);          /* >= 65520 -> inf */
+    if (a < 0x33000001u) return sign;                                 /* <= 2^-25 -> 0 */
+    if (a < 0x38800000u) {                                            /* subnormal half */
+        float v = u32_as_f32(a) * 16777216.0f;                        /* * 2^24, exact */
+        float r = nearbyintf(v);                                      /* RNE (default mode) */
+        return (uint16_t)(sign | (uint16_t)r);
+    }
+    uint32_t e = a - 0x38000000u;                                     /* rebias 127 -> 15 */
+    e += 0xfffu + ((e >> 13) & 1u);
+    return (uint16_t)(sign | (uint16_t)(e >> 13));
+}
+
+static inline float b16_to_f32(uint16_t h, int dtype) {
+    return dtype == FA_ORACLE_BF16 ? bf16_to_f32(h) : fp16_to_f32(h);
+}
+static inline uint16_t f32_to_b16(float f, int dtype) {
+    return dtype == FA_ORACLE_BF16 ? f32_to_bf16(f) : f32_to_fp16(f);
+}
+static inline float round_b16(float f, int dtype) { return b16_to_f32(f32_to_b16(f, dtype), dtype); }
+
+/* exported so tests can pin the conversions against torch */
+float fa_oracle_b16_to_f32(uint16_t h, int dtype) { return b16_to_f32(h, dtype); }
+uint16_t fa_oracle_f32_to_b16(float f, int dtype) { return f32_to_b16(f, dtype); }
+
+typedef struct {
+    const uint16_t *q, *k, *v;
+    uint16_t *o;
+    int dtype;
+    int64_t batch, seq, heads, d;
+    int64_t bs, ss, hs; /* strides in elements, flash_attention.cu:84-86 */
+} tensors_t;
+
+/*
+ * One (batch, head, Q block): forward_kernel.cuh:85-204.  qf/kf/vf are this
+ * head's rows upcast to fp32 (exact).  Scratch: S[B_r*B_c], O[B_r*d], m, l [B_r].
+ * round_p = 1 reproduces the device (P -> 16 bit before PV); 0 keeps fp32 P
+ * (the tools/debug/debug.py:block_flash_attention arithmetic).
+ * If m_trace/l_trace are non-NULL they receive the final m (raw logits) and l.
+ */
+static void q_block_forward(const tensors_t *t, int64_t b, int64_t h, int64_t qb, int B_r,
+                            int B_c, int round_p, int optimized_softmax, const float *kf,
+                            const float *vf, float *S, float *O, float *m, float *l,
+                            float *qrow, float *m_trace, float *l_trace) {
+    const int64_t d = t->d;
+    const int64_t n_kv = t->seq / B_c;
+    /* forward_kernel.cuh:150-151: rsqrt(d) * M_LOG2E evaluated in fp32 */
+    const float c = (float)((double)(1.0f / sqrtf((float)d)) * M_LOG2E);
+    for (int r = 0; r < B_r; ++r) { m[r] = -INFINITY; l[r] = 0.0f; }
+    memset(O, 0, sizeof(float) * B_r * d);
+
+    for (int64_t blk = n_kv - 1; blk >= 0; --blk) { /* forward_kernel.cuh:142,179-184 */
+        const int is_first = (blk == n_kv - 1);
+        /* S = Q K^T, fp32 accumulate (gemm.cuh:45-87, mma f32 accum) */
+        for (int r = 0; r < B_r; ++r) {
+            const int64_t qi = qb * B_r + r;
+            const uint16_t *qp = t->q + b * t->bs + qi * t->ss + h * t->hs;
+            for (int64_t x = 0; x < d; ++x) qrow[x] = b16_to_f32(qp[x], t->dtype);
+            for (int cidx = 0; cidx < B_c; ++cidx) {
+                const float *kp = kf + (blk * B_c + cidx) * d;
+                float acc = 0.0f;
+                for (int64_t x = 0; x < d; ++x) acc = fmaf(qrow[x], kp[x], acc);
+                S[r * B_c + cidx] = acc;
+            }
+        }
+        /* local_softmax, softmax.cuh:85-105 */
+        for (int r = 0; r < B_r; ++r) {
+            float *s = S + r * B_c;
+            const float m_prev = m[r];
+            float mx = is_first ? s[0] : fmaxf(m_prev, s[0]);
+            for (int cidx = 1; cidx < B_c; ++cidx) mx = fmaxf(mx, s[cidx]);
+            m[r] = mx;
+            if (!(is_first && optimized_softmax)) {
+                /* scale_l_O: exp2f((m_prev - m_cur) * softmax_scale), softmax.cuh:42 */
+                const float scale = exp2f((m_prev - mx) * c);
+                l[r] *= scale;
+                float *orow = O + r * d;
+                for (int64_t x = 0; x < d; ++x) orow[x] *= scale;
+            }
+            const float max_scaled = mx * c; /* softmax.cuh:58 */
+            float rowsum = 0.0f;
+            for (int cidx = 0; cidx < B_c; ++cidx) {
+                const float p = exp2f(fmaf(s[cidx], c, -max_scaled)); /* softmax.cuh:61 */
+                rowsum += p;                                          /* fp32 P, :71-82 */
+                s[cidx] = round_p ? round_b16(p, t->dtype) : p;       /* load_store.cuh:345 */
+            }
+            l[r] = (is_first && optimized_softmax) ? rowsum : l[r] + rowsum;
+        }
+        /* O += P V, fp32 accumulate */
+        for (int r = 0; r < B_r; ++r) {
+            float *orow = O + r * d;
+            for (int cidx = 0; cidx < B_c; ++cidx) {
+                const float p = S[r * B_c + cidx];
+                const float *vp = vf + (blk * B_c + cidx) * d;
+                for (int64_t x = 0; x < d; ++x) orow[x] = fmaf(p, vp[x], orow[x]);
+            }
+        }
+    }
+    /* final_softmax_normalization + convert + store, forward_kernel.cuh:186-203 */
+    for (int r = 0; r < B_r; ++r) {
+        const int64_t qi = qb * B_r + r;
+        const float inv = 1.0f / l[r];
+        uint16_t *op = t->o + b * t->bs + qi * t->ss + h * t->hs;
+        for (int64_t x = 0; x < d; ++x) op[x] = f32_to_b16(O[r * d + x] * inv, t->dtype);
+        if (m_trace) m_trace[((b * t->heads + h) * t->seq) + qi] = m[r];
+        if (l_trace) l_trace[((b * t->heads + h) * t->seq) + qi] = l[r];
+    }
+}
+
+/*
+ * Blockwise forward over the whole tensor.  Returns 0, or a negative code:
+ * -1 bad dtype, -2 seq not a multiple of B_r/B_c (flash_attention.cu:79-82),
+ * -3 allocation failure.
+ */
+int fa_oracle_forward_blockwise(const uint16_t *q, const uint16_t *k, const uint16_t *v,
+                                uint16_t *o, int dtype, int64_t batch, int64_t seq,
+                                int64_t heads, int64_t d_head, int64_t batch_stride,
+                                int64_t seq_stride, int64_t head_stride, int B_r, int B_c,
+                                int round_p, int optimized_softmax, float *m_trace,
+                                float *l_trace, int n_threads) {
+    if (dtype != FA_ORACLE_FP16 && dtype != FA_ORACLE_BF16) return -1;
+    if (B_r <= 0 || B_c <= 0 || seq % B_r != 0 || seq % B_c != 0) return -2;
+    tensors_t t = {q, k, v, o, dtype, batch, seq, heads, d_head,
+                   batch_stride, seq_stride, head_stride};
+    const int64_t n_heads_total = batch * heads;
+    const int64_t n_q = seq / B_r;
+    int failed = 0;
+#ifdef _OPENMP
+    if (n_threads > 0) omp_set_num_threads(n_threads);
+#else
+    (void)n_threads;
+#endif
+#pragma omp parallel
+    {
+        float *kf = (float *)malloc(sizeof(float) * seq * d_head);
+        float *vf = (float *)malloc(sizeof(float) * seq * d_head);
+        float *S = (float *)malloc(sizeof(float) * B_r * B_c);
+        float *O = (float *)malloc(sizeof(float) * B_r * d_head);
+        float *ml = (float *)malloc(sizeof(float) * (2 * B_r + d_head));
+        if (!kf || !vf || !S || !O || !ml) {
+#pragma omp atomic write
+            failed = 1;
+        } else {
+#pragma omp for schedule(dynamic, 1)
+            for (int64_t bh = 0; bh < n_heads_total; ++bh) {
+                const int64_t b = bh / heads, h = bh % heads;
+                for (int64_t s = 0; s < seq; ++s) {
+                    const uint16_t *kp = k + b * batch_stride + s * seq_stride + h * head_stride;
+                    const uint16_t *vp = v + b * batch_stride + s * seq_stride + h * head_stride;
+                    for (int64_t x = 0; x < d_head; ++x) {
+                        kf[s * d_head + x] = b16_to_f32(kp[x], dtype);
+                        vf[s * d_head + x] = b16_to_f32(vp[x], dtype);
+                    }
+                }
+                for (int64_t qb = 0; qb < n_q; ++qb)
+                    q_block_forward(&t, b, h, qb, B_r, B_c, round_p, optimized_softmax, kf, vf,
+                                    S, O, ml, ml + B_r, ml + 2 * B_r, m_trace, l_trace);
+            }
+        }
+        free(kf); free(vf); free(S); free(O); free(ml);
+    }
+    return failed ? -3 : 0;
+}
+
+/*
+ * Eager attention, the arithmetic of py_flash_attention (utils.py:137-162):
+ *   S = einsum(q,k) / sqrt(d);  P = softmax(S);  O = einsum(P, v)
+ * upcast = 1: fp32 everywhere, result rounded once to the 16-bit type.
+ * upcast = 0: every intermediate tensor (S, S/sqrt(d), P, O) is rounded to the
+ *             16-bit type, as eager torch does when the inputs stay 16-bit
+ *             (dot products accumulate in fp32 inside the matmul).
+ * out_f32 (optional, B*S*H*d fp32, contiguous (B,S,H,d)) receives the unrounded
+ * fp32 result when upcast = 1.
+ */
+int fa_oracle_forward_eager(const uint16_t *q, const uint16_t *k, const uint16_t *v,
+                            uint16_t *o, float *out_f32, int dtype, int64_t batch, int64_t seq,
+                            int64_t heads, int64_t d_head, int64_t batch_stride,
+                            int64_t seq_stride, int64_t head_stride, int upcast,
+                            int n_threads) {
+    if (dtype != FA_ORACLE_FP16 && dtype != FA_ORACLE_BF16) return -1;
+    const int64_t n_heads_total = batch * heads;
+    int failed = 0;
+#ifdef _OPENMP
+    if (n_threads > 0) omp_set_num_threads(n_threads);
+#else
+    (void)n_threads;
+#endif
+#pragma omp parallel
+    {
+        float *kf = (float *)malloc(sizeof(float) * seq * d_head);
+        float *vf = (float *)malloc(sizeof(float) * seq * d_head);
+        float *s = (float *)malloc(sizeof(float) * seq);
+        float *qrow = (float *)malloc(sizeof(float) * d_head);
+        double *acc = (double *)malloc(sizeof(double) * d_head);
+        if (!kf || !vf || !s || !qrow || !acc) {
+#pragma omp atomic write
+            failed = 1;
+        } else {
+            const float sqrt_d = upcast ? sqrtf((float)d_head)
+                                        : round_b16(sqrtf((float)d_head), dtype);
+#pragma omp for schedule(dynamic, 1)
+            for (int64_t bh = 0; bh < n_heads_total; ++bh) {
+                const int64_t b = bh / heads, h = bh % heads;
+                const int64_t base = b * batch_stride + h * head_stride;
+                for (int64_t r = 0; r < seq; ++r)
+                    for (int64_t x = 0; x < d_head; ++x) {
+                        kf[r * d_head + x] = b16_to_f32(k[base + r * seq_stride + x], dtype);
+                        vf[r * d_head + x] = b16_to_f32(v[base + r * seq_stride + x], dtype);
+                    }
+                for (int64_t qi = 0; qi < seq; ++qi) {
+                    for (int64_t x = 0; x < d_head; ++x)
+                        qrow[x] = b16_to_f32(q[base + qi * seq_stride + x], dtype);
+                    float mx = -INFINITY;
+                    for (int64_t j = 0; j < seq; ++j) {
+                        double a = 0.0;
+                        for (int64_t x = 0; x < d_head; ++x)
+                            a += (double)qrow[x] * (double)kf[j * d_head + x];
+                        float val = (float)a;
+                        if (!upcast) val = round_b16(val, dtype);
+                        val = val / sqrt_d;
+                        if (!upcast) val = round_b16(val, dtype);
+                        s[j] = val;
+                        mx = fmaxf(mx, val);
+                    }
+                    double denom = 0.0;
+                    for (int64_t j = 0; j < seq; ++j) {
+                        s[j] = expf(s[j] - mx);
+                        denom += (double)s[j];
+                    }
+                    const float inv = (float)(1.0 / denom);
+                    for (int64_t x = 0; x < d_head; ++x) acc[x] = 0.0;
+                    for (int64_t j = 0; j < seq; ++j) {
+                        float p = s[j] * inv;
+                        if (!upcast) p = round_b16(p, dtype);
+                        for (int64_t x = 0; x < d_head; ++x)
+                            acc[x] += (double)p * (double)vf[j * d_head + x];
+                    }
+                    for (int64_t x = 0; x < d_head; ++x) {
+                        o[base + qi * seq_stride + x] = f32_to_b16((float)acc[x], dtype);
+                        if (out_f32 && upcast)
+                            out_f32[((b * seq + qi) * heads + h) * d_head + x] = (float)acc[x];
+                    }
+                }
+            }
+        }
+        free(kf); free(vf); free(s); free(qrow); free(acc);
+    }
+    return failed ? -3 : 0;
+}
+
+int fa_oracle_max_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
