@@ -1,0 +1,141 @@
+"""ctypes binding of libfa_hip.so (include/fa_hip.h).  No torch imports here.
+
+This is the stub INTEGRATION.md shows for the reference side: the reference's
+pybind entry (src/flash_attention.cu:137-140) reduces to filling ``fa_fwd_args``
+and calling ``fa_fwd_launch``.
+"""
+
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libfa_hip.so")
+
+FA_FP16, FA_BF16 = 5, 15
+
+CONFIG_FIELDS = (
+    "dtype", "d_head", "B_r", "B_c", "n_warps", "async_copy", "eager_load_blocks",
+    "swizzled", "Q_mma_load_K_tiles", "K_mma_load_K_tiles", "V_mma_load_K_tiles",
+    "mma_double_buffer_loads", "optimized_softmax",
+)
+
+# every symbol include/fa_hip.h declares (tests check the library exports them all)
+EXPORTED_SYMBOLS = (
+    "fa_init", "fa_fwd_supported", "fa_fwd_lds_bytes", "fa_fwd_launch",
+    "fa_fwd_launch_timed", "fa_num_kernels", "fa_get_kernel", "fa_last_error", "fa_version",
+)
+
+
+class FaFwdConfig(ctypes.Structure):
+    _fields_ = [(name, ctypes.c_int32) for name in CONFIG_FIELDS]
+
+
+class FaFwdArgs(ctypes.Structure):
+    _fields_ = [
+        ("q", ctypes.c_void_p), ("k", ctypes.c_void_p), ("v", ctypes.c_void_p),
+        ("o", ctypes.c_void_p),
+        ("batch", ctypes.c_int64), ("seq_len", ctypes.c_int64), ("n_heads", ctypes.c_int64),
+        ("d_head", ctypes.c_int64),
+        ("batch_stride", ctypes.c_int64), ("seq_stride", ctypes.c_int64),
+        ("head_stride", ctypes.c_int64),
+        ("cfg", FaFwdConfig),
+    ]
+
+
+class FaKernelInfo(ctypes.Structure):
+    _fields_ = [
+        ("cfg", FaFwdConfig), ("threads", ctypes.c_int32), ("lds_bytes", ctypes.c_int32),
+        ("num_regs", ctypes.c_int32), ("scratch_bytes", ctypes.c_int32),
+        ("rows_per_wave", ctypes.c_int32),
+    ]
+
+
+class FaError(RuntimeError):
+    """Non-zero fa_status; message from fa_last_error() (RuntimeError like TORCH_CHECK)."""
+
+    def __init__(self, status, message):
+        super().__init__(message)
+        self.status = status
+
+
+_lib = None
+
+
+def load():
+    """Load libfa_hip.so or fail loudly -- there is no CPU / eager fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: the HIP extension is not built. Run "
+            "`python -c 'import __graft_entry__ as g; g.build()'` or "
+            "`make -C flash_attention_from_scratch_amd/csrc`. "
+            "flash_attention has no fallback path."
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    cfg_p, args_p = ctypes.POINTER(FaFwdConfig), ctypes.POINTER(FaFwdArgs)
+    lib.fa_init.restype = ctypes.c_int
+    lib.fa_init.argtypes = []
+    lib.fa_fwd_supported.restype = ctypes.c_int
+    lib.fa_fwd_supported.argtypes = [cfg_p]
+    lib.fa_fwd_lds_bytes.restype = ctypes.c_int
+    lib.fa_fwd_lds_bytes.argtypes = [cfg_p]
+    lib.fa_fwd_launch.restype = ctypes.c_int
+    lib.fa_fwd_launch.argtypes = [args_p, ctypes.c_void_p]
+    lib.fa_fwd_launch_timed.restype = ctypes.c_int
+    lib.fa_fwd_launch_timed.argtypes = [args_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_float)]
+    lib.fa_num_kernels.restype = ctypes.c_int
+    lib.fa_num_kernels.argtypes = []
+    lib.fa_get_kernel.restype = ctypes.c_int
+    lib.fa_get_kernel.argtypes = [ctypes.c_int, ctypes.POINTER(FaKernelInfo)]
+    lib.fa_last_error.restype = ctypes.c_char_p
+    lib.fa_last_error.argtypes = []
+    lib.fa_version.restype = ctypes.c_char_p
+    lib.fa_version.argtypes = []
+    _lib = lib
+    return lib
+
+
+def last_error():
+    return load().fa_last_error().decode("utf-8", "replace")
+
+
+def check(status):
+    if status < 0:
+        raise FaError(status, last_error())
+    return status
+
+
+def make_config(kernel_cfg) -> FaFwdConfig:
+    """Read the 13 attributes by name, as the reference does (flash_attention.cu:16-32).
+    `dtype` may be a DType (IntEnum) or anything int() accepts."""
+    values = {}
+    for name in CONFIG_FIELDS:
+        values[name] = int(getattr(kernel_cfg, name))
+    return FaFwdConfig(**values)
+
+
+def supported(kernel_cfg) -> bool:
+    cfg = make_config(kernel_cfg)
+    return bool(load().fa_fwd_supported(ctypes.byref(cfg)))
+
+
+def lds_bytes(kernel_cfg) -> int:
+    cfg = make_config(kernel_cfg)
+    return check(load().fa_fwd_lds_bytes(ctypes.byref(cfg)))
+
+
+def kernels():
+    """List of FaKernelInfo for every device variant in the library."""
+    lib = load()
+    out = []
+    for i in range(lib.fa_num_kernels()):
+        info = FaKernelInfo()
+        check(lib.fa_get_kernel(i, ctypes.byref(info)))
+        out.append(info)
+    return out
+
+
+def version() -> str:
+    return load().fa_version().decode()

@@ -1,0 +1,264 @@
+// fa_capi.hip -- C ABI of libfa_hip.so (declared in include/fa_hip.h).
+//
+// Host-side launcher for the gfx950 forward kernel: the work
+// /root/reference/src/flash_attention.cu:58-134 does after its torch checks
+// (config -> kernel lookup, shape checks, grid/block/LDS, optional event timing),
+// with no torch types.  Tensor-level checks (device, contiguity, dtype equality,
+// output allocation, current stream) stay in the Python shim
+// flash_attention_from_scratch_amd/flash_attention_kernels.py.
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <mutex>
+#include <vector>
+
+#include "../../include/fa_hip.h"
+#include "fa_registry.hpp"
+
+extern "C" {
+fa::KernelTable fa_inst_table_dt15_qt1();
+fa::KernelTable fa_inst_table_dt15_qt2();
+fa::KernelTable fa_inst_table_dt5_qt1();
+fa::KernelTable fa_inst_table_dt5_qt2();
+fa::KernelTable fa_inst16_table_dt15();
+fa::KernelTable fa_inst16_table_dt5();
+}
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+std::vector<fa::KernelEntry> &registry() {
+    static std::vector<fa::KernelEntry> all = [] {
+        std::vector<fa::KernelEntry> v;
+        const fa::KernelTable tables[] = {
+            fa_inst_table_dt15_qt1(), fa_inst_table_dt15_qt2(), fa_inst_table_dt5_qt1(),
+            fa_inst_table_dt5_qt2(),  fa_inst16_table_dt15(),   fa_inst16_table_dt5(),
+        };
+        for (const auto &t : tables)
+            for (int i = 0; i < t.count; ++i) v.push_back(t.entries[i]);
+        return v;
+    }();
+    return all;
+}
+
+bool valid_load_tiles(int v) { return v == 0 || v == 2 || v == 4 || v == 8; }
+
+// Config -> device variant.  The operand-fetch hints (load_K_tiles, double
+// buffer) are validated with the reference's rules
+// (static_kernel_configuration.cuh:13-35) and then ignored: on CDNA4 the
+// compiler schedules LDS->MFMA operand reads and all hint values share one variant.
+const fa::KernelEntry *find_kernel(const fa_fwd_config *c, const char **why) {
+    static const char *kNotFound = "Kernel configuration was not found in the libfa_hip.so registry";
+    *why = kNotFound;
+    if (c->d_head != 128) { *why = "Only d_head = 128 is supported"; return nullptr; }
+    if (c->n_warps <= 0 || c->B_r <= 0 || c->B_r % c->n_warps != 0) return nullptr;
+    if (!valid_load_tiles(c->Q_mma_load_K_tiles) || !valid_load_tiles(c->K_mma_load_K_tiles) ||
+        !valid_load_tiles(c->V_mma_load_K_tiles))
+        return nullptr;
+    if (c->Q_mma_load_K_tiles != 0 && c->Q_mma_load_K_tiles != c->K_mma_load_K_tiles)
+        return nullptr;
+    const int rows_per_wave = c->B_r / c->n_warps;
+    for (const auto &e : registry()) {
+        if (e.dtype == c->dtype && e.rows_per_wave == rows_per_wave && e.n_waves == c->n_warps &&
+            e.B_c == c->B_c && e.swizzled == (c->swizzled != 0) &&
+            e.eager == (c->eager_load_blocks != 0) && e.opt_softmax == (c->optimized_softmax != 0) &&
+            e.async_copy == (c->async_copy != 0))
+            return &e;
+    }
+    return nullptr;
+}
+
+std::once_flag g_init_once;
+int g_init_status = FA_OK;
+char g_init_err[256] = "";
+
+void do_init() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) {
+        g_init_status = FA_ERR_DEVICE;
+        snprintf(g_init_err, sizeof(g_init_err), "no HIP device available");
+        return;
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+        g_init_status = FA_ERR_DEVICE;
+        snprintf(g_init_err, sizeof(g_init_err), "hipGetDeviceProperties failed");
+        return;
+    }
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        g_init_status = FA_ERR_DEVICE;
+        snprintf(g_init_err, sizeof(g_init_err),
+                 "Flash Attention (HIP) requires gfx950 / MI355X (current: %s)", prop.gcnArchName);
+        return;
+    }
+    // flash_attention.cu:142-149: opt in to large dynamic shared memory per kernel.
+    for (const auto &e : registry()) {
+        if (e.lds_bytes > 48 * 1024) {
+            hipError_t rc = hipFuncSetAttribute((const void *)e.fn,
+                                                hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                e.lds_bytes);
+            if (rc != hipSuccess) {
+                g_init_status = FA_ERR_LAUNCH;
+                snprintf(g_init_err, sizeof(g_init_err), "hipFuncSetAttribute(%d B LDS): %s",
+                         e.lds_bytes, hipGetErrorString(rc));
+                return;
+            }
+        }
+    }
+}
+
+int validate(const fa_fwd_args *a, const fa::KernelEntry **out) {
+    if (!a || !a->q || !a->k || !a->v || !a->o) return fail(FA_ERR_NULL, "null pointer argument");
+    if (a->cfg.dtype != FA_FP16 && a->cfg.dtype != FA_BF16)
+        return fail(FA_ERR_DTYPE, "Only fp16 and bf16 are supported");
+    const char *why = "";
+    const fa::KernelEntry *e = find_kernel(&a->cfg, &why);
+    if (!e) return fail(FA_ERR_NO_KERNEL, "%s", why);
+    if (a->d_head != a->cfg.d_head)
+        return fail(FA_ERR_SHAPE, "Tensor d_head (%lld) does not match kernel configuration d_head (%d)",
+                    (long long)a->d_head, a->cfg.d_head);
+    if (a->batch <= 0 || a->seq_len <= 0 || a->n_heads <= 0)
+        return fail(FA_ERR_SHAPE, "batch, seq_len and n_heads must be positive");
+    if (a->seq_len % a->cfg.B_r != 0)
+        return fail(FA_ERR_SHAPE, "Only multiples of B_r are supported for seq_len Q currently");
+    if (a->seq_len % a->cfg.B_c != 0)
+        return fail(FA_ERR_SHAPE, "Only multiples of B_c are supported for seq_len K currently");
+    if (a->seq_len > INT32_MAX || a->batch * a->n_heads > INT32_MAX ||
+        a->batch * a->n_heads * (a->seq_len / a->cfg.B_r) > INT32_MAX)
+        return fail(FA_ERR_SHAPE, "problem too large for a 1-D grid");
+    // 16-byte vector accesses: element strides must be multiples of 8, pointers 16-B aligned.
+    if ((a->batch_stride | a->seq_stride | a->head_stride) & 7)
+        return fail(FA_ERR_ALIGN, "strides must be multiples of 8 elements (16 bytes)");
+    if (((uintptr_t)a->q | (uintptr_t)a->k | (uintptr_t)a->v | (uintptr_t)a->o) & 15)
+        return fail(FA_ERR_ALIGN, "q, k, v, o must be 16-byte aligned");
+    *out = e;
+    return FA_OK;
+}
+
+int launch(const fa_fwd_args *a, const fa::KernelEntry *e, hipStream_t stream) {
+    fa::KernelArgs ka;
+    ka.q = a->q;
+    ka.k = a->k;
+    ka.v = a->v;
+    ka.o = a->o;
+    ka.batch_stride = a->batch_stride;
+    ka.seq_stride = a->seq_stride;
+    ka.head_stride = a->head_stride;
+    ka.seq_len = (int32_t)a->seq_len;
+    ka.n_heads = (int32_t)a->n_heads;
+    ka.n_bh = (int32_t)(a->batch * a->n_heads);
+    ka.n_q_blocks = (int32_t)(a->seq_len / a->cfg.B_r);
+    ka.n_kv_blocks = (int32_t)(a->seq_len / a->cfg.B_c);
+    // 1-D grid over (batch*head, Q block); the kernel un-maps it XCD-aware.
+    // (reference: dim3(n_Q_blocks, n_heads, batch), flash_attention.cu:110-112)
+    const dim3 grid((unsigned)(ka.n_bh * ka.n_q_blocks));
+    const dim3 block((unsigned)e->threads);
+    void *params[] = {&ka};
+    hipError_t rc = hipLaunchKernel((const void *)e->fn, grid, block, params, (size_t)e->lds_bytes, stream);
+    if (rc != hipSuccess) return fail(FA_ERR_LAUNCH, "hipLaunchKernel: %s", hipGetErrorString(rc));
+    return FA_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int fa_init(void) {
+    std::call_once(g_init_once, do_init);
+    if (g_init_status != FA_OK) return fail(g_init_status, "%s", g_init_err);
+    return FA_OK;
+}
+
+int fa_fwd_supported(const fa_fwd_config *cfg) {
+    if (!cfg) return 0;
+    const char *why;
+    return find_kernel(cfg, &why) != nullptr;
+}
+
+int fa_fwd_lds_bytes(const fa_fwd_config *cfg) {
+    if (!cfg) return fail(FA_ERR_NULL, "null config");
+    const char *why = "";
+    const fa::KernelEntry *e = find_kernel(cfg, &why);
+    if (!e) return fail(FA_ERR_NO_KERNEL, "%s", why);
+    return e->lds_bytes;
+}
+
+int fa_fwd_launch(const fa_fwd_args *args, void *stream) {
+    const fa::KernelEntry *e = nullptr;
+    int rc = validate(args, &e);
+    if (rc != FA_OK) return rc;
+    if ((rc = fa_init()) != FA_OK) return rc;
+    return launch(args, e, (hipStream_t)stream);
+}
+
+int fa_fwd_launch_timed(const fa_fwd_args *args, void *stream, float *ms) {
+    if (!ms) return fail(FA_ERR_NULL, "null ms pointer");
+    const fa::KernelEntry *e = nullptr;
+    int rc = validate(args, &e);
+    if (rc != FA_OK) return rc;
+    if ((rc = fa_init()) != FA_OK) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    hipEvent_t start, stop;
+    if (hipEventCreate(&start) != hipSuccess || hipEventCreate(&stop) != hipSuccess)
+        return fail(FA_ERR_LAUNCH, "hipEventCreate failed");
+    (void)hipEventRecord(start, s);
+    rc = launch(args, e, s);
+    (void)hipEventRecord(stop, s);
+    hipError_t hrc = hipEventSynchronize(stop);
+    float elapsed = 0.0f;
+    if (hrc == hipSuccess) hrc = hipEventElapsedTime(&elapsed, start, stop);
+    (void)hipEventDestroy(start);
+    (void)hipEventDestroy(stop);
+    if (rc != FA_OK) return rc;
+    if (hrc != hipSuccess) return fail(FA_ERR_LAUNCH, "kernel execution: %s", hipGetErrorString(hrc));
+    *ms = elapsed;
+    return FA_OK;
+}
+
+int fa_num_kernels(void) { return (int)registry().size(); }
+
+int fa_get_kernel(int index, fa_kernel_info *out) {
+    if (!out) return fail(FA_ERR_NULL, "null output");
+    if (index < 0 || index >= (int)registry().size()) return fail(FA_ERR_SHAPE, "index out of range");
+    const fa::KernelEntry &e = registry()[index];
+    memset(out, 0, sizeof(*out));
+    out->cfg.dtype = e.dtype;
+    out->cfg.d_head = 128;
+    out->cfg.B_r = e.rows_per_wave * e.n_waves;
+    out->cfg.B_c = e.B_c;
+    out->cfg.n_warps = e.n_waves;
+    out->cfg.async_copy = e.async_copy;
+    out->cfg.eager_load_blocks = e.eager;
+    out->cfg.swizzled = e.swizzled;
+    out->cfg.optimized_softmax = e.opt_softmax;
+    out->threads = e.threads;
+    out->lds_bytes = e.lds_bytes;
+    out->rows_per_wave = e.rows_per_wave;
+    out->num_regs = -1;
+    out->scratch_bytes = -1;
+    hipFuncAttributes attr;
+    if (hipFuncGetAttributes(&attr, (const void *)e.fn) == hipSuccess) {
+        out->num_regs = attr.numRegs;
+        out->scratch_bytes = (int32_t)attr.localSizeBytes;
+    } else {
+        (void)hipGetLastError();  // no device: resource fields stay -1
+    }
+    return FA_OK;
+}
+
+const char *fa_last_error(void) { return g_err; }
+
+const char *fa_version(void) { return "fa_hip 0.1 gfx950"; }
+
+}  // extern "C"

@@ -1,0 +1,404 @@
+// fa_fwd_kernel.hpp -- Flash-Attention-2 forward for CDNA4 / gfx950 (MI355X).
+//
+// Hand-written HIP; not a translation of the reference's CUDA.  It computes what
+// /root/reference/src/include/forward_kernel.cuh:85-204 (flash_forward_kernel) and
+// :19-83 (process_kv_block) compute -- O = softmax(Q K^T / sqrt(d)) V for one
+// (batch, head, Q block) per workgroup, KV blocks visited last-to-first, raw-logit
+// running max, base-2 exponent with c = rsqrt(d)*log2(e), P rounded RNE to the
+// 16-bit type before P.V, l summed from fp32 P with the cross-lane reduction
+// deferred to the epilogue (softmax.cuh:13-128) -- but is organised for wave64 MFMA:
+//
+//  * Both products are computed TRANSPOSED so every softmax statistic is lane-local:
+//      S^T = K  Q^T   v_mfma_f32_32x32x16 (A = K tile rows from LDS, B = Q^T in VGPRs)
+//      O^T = V^T P^T  v_mfma_f32_32x32x16 (A = V^T via ds_read_b64_tr_b16, B = P^T)
+//    In the 32x32 C layout (col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5))
+//    lane L then owns ONE query (column L&31) and 16 keys per 32-key tile; the other
+//    16 keys sit in lane L^32.  Row max = in-register max + one v_permlane32_swap;
+//    the rescale factor, m and l are per-lane scalars.
+//  * The P^T B-operand needs, per lane, keys {8*(lane>>5) + j}; the C layout hands
+//    the lane keys {4*(lane>>5) + (j&3) + 8*(j>>2)}.  Since a contraction index may
+//    be permuted freely if both operands agree, V^T's A-operand is fetched with the
+//    SAME key permutation (two transpose-reads per operand pick keys 4hi+0..3 and
+//    8+4hi+0..3).  P therefore goes from the softmax registers straight into the
+//    MFMA with just a v_cvt_pk -- no LDS round trip, no cross-lane shuffle.
+//  * Q lives in VGPRs for the whole kernel (it IS the B operand layout: 16 B per
+//    lane per 16-wide k step), loaded once straight from global memory.
+//  * K and V tiles are DMA'd global->LDS (global_load_lds_dwordx4, 1 KiB per
+//    wave-instruction), double-buffered, one barrier per KV tile.  The DMA writes
+//    LDS lane-linearly, so both LDS images are produced by permuting the per-lane
+//    SOURCE address:
+//      K image  [key][128 d], 256 B rows, 16-B chunk index XOR (key & 15)  ->
+//               conflict-free ds_read_b128 for the A operand (16-lane groups hit 16
+//               distinct slots of the 256-B bank row);
+//      V image  [key/8][d/32][8 keys][32 d] 512-B subtiles -> every
+//               ds_read_b64_tr_b16 wave-instruction reads 512 contiguous bytes, all
+//               32 reads of a tile are one base VGPR + immediate offsets.
+//  * Workgroup ids are remapped so all Q blocks of one (batch, head) run on the
+//    same XCD (block id mod 8) and share that XCD's L2 copy of the head's K/V.
+//
+// Template parameters select the device variant behind the reference's 13-field
+// config (see fa_capi.cpp for the mapping):
+//   DT      5 = fp16, 15 = bf16 (torch ScalarType codes)
+//   QT      32-row Q tiles per wave (rows per wave = 32*QT)
+//   NWAVES  wave64 wavefronts per workgroup  (B_r = 32*QT*NWAVES)
+//   BC      keys per LDS tile (B_c)
+//   SWZ     XOR-swizzled K image             (cfg.swizzled)
+//   EAGER   prefetch next tile, 2 LDS buffers (cfg.eager_load_blocks)
+//   OPT     first KV block skips the rescale  (cfg.optimized_softmax)
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace fa {
+
+struct KernelArgs {
+    const void *q;
+    const void *k;
+    const void *v;
+    void *o;
+    int64_t batch_stride;  // elements
+    int64_t seq_stride;
+    int64_t head_stride;
+    int32_t seq_len;
+    int32_t n_heads;
+    int32_t n_bh;          // batch * heads
+    int32_t n_q_blocks;
+    int32_t n_kv_blocks;
+};
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+#define FA_LDS(type) __attribute__((address_space(3))) type
+#define FA_DEV __device__ __forceinline__
+
+template <bool B> struct BoolTag { static constexpr bool value = B; };
+
+template <int DT> struct Elem;
+
+template <> struct Elem<15> {  // bf16
+    typedef bf16x8 vec8;
+    static FA_DEV f32x16 mfma(vec8 a, vec8 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    }
+    static FA_DEV f32x4 mfma16(vec8 a, vec8 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    }
+    // RNE fp32 -> bf16 (v_cvt_pk_bf16_f32), load_store.cuh:345-349 semantics
+    static FA_DEV vec8 pack8(const float *p) {
+        vec8 r;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] = (__bf16)p[j];
+        return r;
+    }
+};
+
+template <> struct Elem<5> {  // fp16
+    typedef f16x8 vec8;
+    static FA_DEV f32x16 mfma(vec8 a, vec8 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    }
+    static FA_DEV f32x4 mfma16(vec8 a, vec8 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+    }
+    static FA_DEV vec8 pack8(const float *p) {
+        vec8 r;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] = (_Float16)p[j];
+        return r;
+    }
+};
+
+// max over the two lanes that share a query column (lane, lane^32).
+static FA_DEV float pair_max(float x) {
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+static FA_DEV float pair_sum(float x) {
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+static FA_DEV void glds16(const void *gsrc, char *lds_dst_wave_uniform) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc,
+                                     (FA_LDS(void) *)lds_dst_wave_uniform, 16, 0, 0);
+}
+
+template <int DT, int QT, int NWAVES, int BC, bool SWZ, bool EAGER, bool OPT>
+struct FwdTraits {
+    static constexpr int kRowsPerWave = 32 * QT;
+    static constexpr int kBr = kRowsPerWave * NWAVES;
+    static constexpr int kBc = BC;
+    static constexpr int kThreads = NWAVES * 64;
+    static constexpr int kTileBytes = BC * 256;                 // one K or V tile (d = 128)
+    static constexpr int kStages = EAGER ? 2 : 1;
+    static constexpr int kLdsBytes = 2 * kStages * kTileBytes;  // K + V, all stages
+    static constexpr int kMinWavesPerSimd = (QT == 1) ? 2 : 1;
+};
+
+// ---------------------------------------------------------------------------------
+// The kernel.  d_head is fixed at 128 (reference: README.md:7-15).
+// ---------------------------------------------------------------------------------
+template <int DT, int QT, int NWAVES, int BC, bool SWZ, bool EAGER, bool OPT>
+__global__ void
+__launch_bounds__(NWAVES * 64, (QT == 1) ? 2 : 1)
+fa_fwd_kernel(const KernelArgs args) {
+    using E = Elem<DT>;
+    using vec8 = typename E::vec8;
+    using TR = FwdTraits<DT, QT, NWAVES, BC, SWZ, EAGER, OPT>;
+    constexpr int D = 128;
+    constexpr int NT = BC / 32;              // 32-key tiles per LDS tile
+    constexpr int KS = D / 16;               // k steps of the QK^T contraction
+    constexpr int DTILES = D / 32;           // 32-wide d tiles of O^T
+    constexpr int TILE = TR::kTileBytes;
+    constexpr int N_DMA = BC / 4;            // 1-KiB DMA pieces per K (or V) tile
+    static_assert(N_DMA % NWAVES == 0 || NWAVES % N_DMA == 0, "tile/wave split");
+    constexpr int DMA_PER_WAVE = (N_DMA >= NWAVES) ? N_DMA / NWAVES : 1;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // LDS carve: K stage 0 | K stage 1 | V stage 0 | V stage 1
+    constexpr int V_BASE = TR::kStages * TILE;
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r31 = lane & 31;
+    const int hi = lane >> 5;
+
+    // ---- workgroup -> (batch*head, Q block); XCD-aware when n_bh % 8 == 0 --------
+    const int nq = args.n_q_blocks;
+    int bh, qb;
+    {
+        const int bid = blockIdx.x;
+        if ((args.n_bh & 7) == 0) {
+            const int xcd = bid & 7, local = bid >> 3;
+            bh = (local / nq) * 8 + xcd;
+            qb = local % nq;
+        } else {
+            bh = bid / nq;
+            qb = bid % nq;
+        }
+    }
+    const int b = bh / args.n_heads, h = bh % args.n_heads;
+    const int64_t ss = args.seq_stride;
+    const int64_t head_off = (int64_t)b * args.batch_stride + (int64_t)h * args.head_stride;
+    const uint16_t *Qg = (const uint16_t *)args.q + head_off;
+    const uint16_t *Kg = (const uint16_t *)args.k + head_off;
+    const uint16_t *Vg = (const uint16_t *)args.v + head_off;
+    uint16_t *Og = (uint16_t *)args.o + head_off;
+
+    // ---- per-lane DMA source offsets (elements), invariant over tiles ------------
+    // piece i (wave-uniform) covers LDS chunks [64 i, 64 i + 64) of a tile.
+    //   K: chunk p -> key p>>4, 16-B chunk (p&15) ^ (key&15)
+    //   V: chunk p -> subtile p>>5 = (key>>3)*4 + (d>>5); inside: key&7 = (p&31)>>2,
+    //      d&31 = (p&3)*8
+    const int k_row_in_piece = lane >> 4;                                  // 0..3
+    const int k_swz = SWZ ? (((wave & 3) * 4 + k_row_in_piece) & 15) : 0;  // (key & 15)
+    const int64_t k_lane_off = (int64_t)k_row_in_piece * ss + (((lane & 15) ^ k_swz) << 3);
+    const int v_sub_in_piece = lane >> 5;                                  // 0..1
+    const int v_w = lane & 31;
+    const int64_t v_lane_row = (v_w >> 2);                                 // key & 7
+    const int v_lane_d = (v_w & 3) * 8;
+
+    auto issue_tile = [&](int kv_block, int stage) {
+        const int64_t kv0 = (int64_t)kv_block * BC;
+        char *kdst = smem + stage * TILE;
+        char *vdst = smem + V_BASE + stage * TILE;
+#pragma unroll
+        for (int j = 0; j < DMA_PER_WAVE; ++j) {
+            const int i = wave + NWAVES * j;  // piece index, wave-uniform
+            if (N_DMA >= NWAVES || i < N_DMA) {
+                // K piece: keys 4i .. 4i+3
+                const uint16_t *ksrc = Kg + (kv0 + 4 * i) * ss + k_lane_off;
+                glds16(ksrc, kdst + i * 1024);
+                // V piece: subtiles 2i, 2i+1 -> keys 8*(sub>>2) + (w>>2), d (sub&3)*32 + ...
+                const int sub = 2 * i + v_sub_in_piece;
+                const uint16_t *vsrc =
+                    Vg + (kv0 + 8 * (sub >> 2) + v_lane_row) * ss + (sub & 3) * 32 + v_lane_d;
+                glds16(vsrc, vdst + i * 1024);
+            }
+        }
+    };
+
+    // ---- prologue: first (= last in sequence) KV tile in flight, then Q -> VGPRs --
+    int kv_block = args.n_kv_blocks - 1;
+    if (EAGER) issue_tile(kv_block, 0);
+
+    vec8 Qr[QT][KS];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        const int64_t row = (int64_t)qb * TR::kBr + wave * TR::kRowsPerWave + qt * 32 + r31;
+        const uint16_t *qp = Qg + row * ss + hi * 8;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) Qr[qt][ks] = *(const vec8 *)(qp + ks * 16);
+    }
+
+    // forward_kernel.cuh:150-151 (fp32 product of rsqrt(d) and log2 e)
+    const float c = (float)((double)(1.0f / __builtin_sqrtf((float)D)) * 1.4426950408889634074);
+
+    f32x16 O[QT][DTILES];
+    float m[QT], l[QT];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        m[qt] = -__builtin_inff();
+        l[qt] = 0.0f;
+#pragma unroll
+        for (int t = 0; t < DTILES; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) O[qt][t][r] = 0.0f;
+    }
+
+    // per-lane LDS read offsets
+    //   K A-operand: row 32*nt + r31, chunk (2*ks + hi) ^ (r31 & 15)
+    const int ka_swz = SWZ ? (r31 & 15) : 0;
+    const int ka_base = r31 * 256;
+    //   V^T A-operand (transpose read): see header comment
+    const int li = lane & 15, lg = lane >> 4;
+    const int va_base = (4 * (lg >> 1) + (li >> 2)) * 64 + (lg & 1) * 32 + (li & 3) * 8;
+
+    auto compute_tile = [&](int stage, auto first_tag) {
+        constexpr bool FIRST = decltype(first_tag)::value;
+        const char *kt = smem + stage * TILE;
+        const char *vt = smem + V_BASE + stage * TILE;
+
+        // ---- S^T = K Q^T -------------------------------------------------------
+        f32x16 S[QT][NT];
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) S[qt][nt][r] = 0.0f;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const int off = nt * 32 * 256 + ka_base + (((2 * ks + hi) ^ ka_swz) << 4);
+                const vec8 a = *(const vec8 *)(kt + off);
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt) S[qt][nt] = E::mfma(a, Qr[qt][ks], S[qt][nt]);
+            }
+        }
+
+        // ---- online softmax, lane-local (softmax.cuh:85-105) ---------------------
+        vec8 Pb[QT][NT][2];
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+            float mx = S[qt][0][0];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, S[qt][nt][r]);
+            mx = pair_max(mx);
+            float m_new;
+            if (FIRST && OPT) {
+                m_new = mx;
+            } else {
+                m_new = fmaxf(m[qt], mx);
+                // scale_l_O, softmax.cuh:36-49
+                const float alpha = __builtin_amdgcn_exp2f((m[qt] - m_new) * c);
+                l[qt] *= alpha;
+#pragma unroll
+                for (int t = 0; t < DTILES; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) O[qt][t][r] *= alpha;
+            }
+            m[qt] = m_new;
+            const float neg_msc = -(m_new * c);
+            float rowsum = 0.0f;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                float p[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    // exponentiate_tensor, softmax.cuh:51-64: exp2(s*c - m*c)
+                    p[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(S[qt][nt][r], c, neg_msc));
+                    rowsum += p[r];  // fp32 P, before rounding (softmax.cuh:66-83)
+                }
+                Pb[qt][nt][0] = E::pack8(p);
+                Pb[qt][nt][1] = E::pack8(p + 8);
+            }
+            l[qt] = (FIRST && OPT) ? rowsum : l[qt] + rowsum;
+        }
+
+        // ---- O^T += V^T P^T ------------------------------------------------------
+#pragma unroll
+        for (int t = 0; t < DTILES; ++t) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    const int s16 = 2 * nt + half;
+                    const char *vp = vt + va_base + s16 * 4096 + t * 512;
+                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((FA_LDS(s16x4) *)(vp));
+                    const s16x4 up =
+                        __builtin_amdgcn_ds_read_tr16_b64_v4i16((FA_LDS(s16x4) *)(vp + 2048));
+                    s16x8 av;
+                    av.lo = lo;
+                    av.hi = up;
+                    const vec8 a = __builtin_bit_cast(vec8, av);
+#pragma unroll
+                    for (int qt = 0; qt < QT; ++qt)
+                        O[qt][t] = E::mfma(a, Pb[qt][nt][half], O[qt][t]);
+                }
+            }
+        }
+    };
+
+    using TrueTag = BoolTag<true>;
+    using FalseTag = BoolTag<false>;
+
+    // ---- main loop over KV tiles, last to first (forward_kernel.cuh:142,175-184) --
+    const int n_kv = args.n_kv_blocks;
+    if (EAGER) {
+        // tile `it` lives in stage it&1; its DMA was issued one iteration earlier.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (n_kv > 1) issue_tile(kv_block - 1, 1);
+        if (OPT) compute_tile(0, TrueTag{}); else compute_tile(0, FalseTag{});
+        for (int it = 1; it < n_kv; ++it) {
+            const int stage = it & 1;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();  // tile `it` landed for every wave; stage^1 free again
+            if (it + 1 < n_kv) issue_tile(kv_block - it - 1, stage ^ 1);
+            compute_tile(stage, FalseTag{});
+        }
+    } else {
+        for (int it = 0; it < n_kv; ++it) {
+            if (it > 0) __syncthreads();  // everyone done reading the single stage
+            issue_tile(kv_block - it, 0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (OPT && it == 0) compute_tile(0, TrueTag{}); else compute_tile(0, FalseTag{});
+        }
+    }
+
+    // ---- epilogue: finish l, normalise, RNE to 16 bit, store ----------------------
+    // (final_softmax_normalization softmax.cuh:107-128; forward_kernel.cuh:186-203)
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        const float inv = 1.0f / pair_sum(l[qt]);
+        const int64_t row = (int64_t)qb * TR::kBr + wave * TR::kRowsPerWave + qt * 32 + r31;
+        uint16_t *op = Og + row * ss + hi * 4;
+#pragma unroll
+        for (int t = 0; t < DTILES; ++t) {
+            float o[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[r] = O[qt][t][r] * inv;
+            const vec8 lo = E::pack8(o);      // regs 0..7 : d = 32t + {0..3} + 4hi, 32t + 8 + ...
+            const vec8 up = E::pack8(o + 8);  // regs 8..15: d = 32t + 16 + ..., 32t + 24 + ...
+            const s16x8 lo_s = __builtin_bit_cast(s16x8, lo);
+            const s16x8 up_s = __builtin_bit_cast(s16x8, up);
+            *(s16x4 *)(op + t * 32 + 0) = lo_s.lo;
+            *(s16x4 *)(op + t * 32 + 8) = lo_s.hi;
+            *(s16x4 *)(op + t * 32 + 16) = up_s.lo;
+            *(s16x4 *)(op + t * 32 + 24) = up_s.hi;
+        }
+    }
+}
+
+}  // namespace fa

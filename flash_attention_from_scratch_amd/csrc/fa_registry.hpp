@@ -1,0 +1,40 @@
+// fa_registry.hpp -- table of device variants built into libfa_hip.so.
+// The role of /root/reference/src/include/flash_kernels.cuh:14-186 (a generated
+// std::map<config, fn>) is played by per-translation-unit tables of KernelEntry
+// that fa_capi.cpp concatenates; which variants exist is decided by the
+// FA_INSTANTIATE lines in fa_inst_*.hip.
+#pragma once
+#include <stdint.h>
+#include "fa_fwd_kernel.hpp"
+
+namespace fa {
+
+typedef void (*kernel_fn)(const KernelArgs);
+
+struct KernelEntry {
+    int dtype;          // 5 / 15
+    int rows_per_wave;  // 16, 32 or 64
+    int n_waves;
+    int B_c;
+    int swizzled;
+    int eager;
+    int opt_softmax;
+    int async_copy;
+    int threads;
+    int lds_bytes;
+    kernel_fn fn;
+};
+
+template <int DT, int QT, int NWAVES, int BC, bool SWZ, bool EAGER, bool OPT>
+constexpr KernelEntry make_entry() {
+    using TR = FwdTraits<DT, QT, NWAVES, BC, SWZ, EAGER, OPT>;
+    return KernelEntry{DT, 32 * QT, NWAVES, BC, SWZ, EAGER, OPT, 1, TR::kThreads, TR::kLdsBytes,
+                       (kernel_fn)&fa_fwd_kernel<DT, QT, NWAVES, BC, SWZ, EAGER, OPT>};
+}
+
+struct KernelTable {
+    const KernelEntry *entries;
+    int count;
+};
+
+}  // namespace fa

@@ -1,0 +1,17 @@
+"""`flash_attention` -- the reference's public API, unchanged
+(/root/reference/flash_attention/__init__.py:7-17):
+
+    forward(kernel_cfg, q, k, v, o=None) -> Tensor
+    forward_timed(kernel_cfg, q, k, v, o=None) -> (Tensor, milliseconds)
+"""
+
+from .. import flash_attention_kernels
+
+
+def forward(kernel_cfg, q, k, v, o=None):
+    return flash_attention_kernels.forward(kernel_cfg, q, k, v, o, benchmark=False)[0]
+
+
+def forward_timed(kernel_cfg, q, k, v, o=None):
+    out, runtime_ms = flash_attention_kernels.forward(kernel_cfg, q, k, v, o, benchmark=True)
+    return out, runtime_ms

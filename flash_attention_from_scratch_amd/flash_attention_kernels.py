@@ -1,0 +1,84 @@
+"""`flash_attention_kernels` -- Python mirror of the reference's pybind module
+(/root/reference/src/flash_attention.cu:34-140) over the C ABI of libfa_hip.so.
+
+    forward(kernel_cfg, q, k, v, o, benchmark=False) -> (Tensor, float)
+
+Same argument meaning, same checks in the same order with the same messages
+(RuntimeError, as TORCH_CHECK raises), same ownership rule for `o`, launch on
+torch's current stream, blocking only when benchmark=True.  PyTorch-ROCm is
+plumbing here (device memory, current stream); the computation is the HIP kernel
+behind fa_fwd_launch.  There is no eager/CPU fallback: a missing library or a
+non-gfx950 device raises.
+"""
+
+import ctypes
+
+import torch
+
+from . import _capi
+
+
+def _check_input(t, name):
+    # CHECK_INPUT, src/include/cuda_utils.cuh:5-11
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must be a CUDA tensor")
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name} must be contiguous")
+
+
+def forward(kernel_cfg, q, k, v, o=None, benchmark=False):
+    _check_input(q, "q")
+    _check_input(k, "k")
+    _check_input(v, "v")
+
+    q_dtype = q.dtype
+    if q_dtype not in (torch.float16, torch.bfloat16):
+        raise RuntimeError("Only fp16 and bf16 are supported")
+    if k.dtype != q_dtype or v.dtype != q_dtype:
+        raise RuntimeError("Input tensors must have the same data type")
+    if q.dim() != 4:
+        raise RuntimeError("q must have shape (batch, seq_len, n_heads, d_head)")
+
+    cfg = _capi.make_config(kernel_cfg)
+    lib = _capi.load()
+    if not lib.fa_fwd_supported(ctypes.byref(cfg)):
+        raise RuntimeError("Kernel configuration was not found in flash_kernels (libfa_hip.so registry)")
+    cfg_dtype = kernel_cfg.dtype.to_torch_dtype() if hasattr(kernel_cfg.dtype, "to_torch_dtype") else None
+    if cfg_dtype is None:
+        cfg_dtype = {5: torch.float16, 15: torch.bfloat16}[int(kernel_cfg.dtype)]
+    if cfg_dtype != q_dtype:
+        raise RuntimeError("Kernel configuration dtype does not match input dtype")
+
+    if q.shape != k.shape:
+        raise RuntimeError("Query and key tensors have same shape")
+    if q.shape != v.shape:
+        raise RuntimeError("Query and value tensors have same shape")
+    batch, seq_len, n_heads, d_head = q.shape
+    if seq_len % cfg.B_r != 0:
+        raise RuntimeError("Only multiples of B_r are supported for seq_len Q currently")
+    if seq_len % cfg.B_c != 0:
+        raise RuntimeError("Only multiples of B_c are supported for seq_len K currently")
+
+    if o is not None:
+        if o.dtype != q_dtype:
+            raise RuntimeError("Output tensor must have the same dtype as inputs")
+        if o.shape != q.shape:
+            raise RuntimeError("Query and output tensors have same shape")
+        _check_input(o, "o")
+    else:
+        o = torch.empty_like(q)
+
+    args = _capi.FaFwdArgs(
+        q=q.data_ptr(), k=k.data_ptr(), v=v.data_ptr(), o=o.data_ptr(),
+        batch=batch, seq_len=seq_len, n_heads=n_heads, d_head=d_head,
+        batch_stride=q.stride(0), seq_stride=q.stride(1), head_stride=q.stride(2),
+        cfg=cfg,
+    )
+    with torch.cuda.device(q.device):
+        stream = ctypes.c_void_p(torch.cuda.current_stream(q.device).cuda_stream)
+        if benchmark:
+            ms = ctypes.c_float(0.0)
+            _capi.check(lib.fa_fwd_launch_timed(ctypes.byref(args), stream, ctypes.byref(ms)))
+            return o, float(ms.value)
+        _capi.check(lib.fa_fwd_launch(ctypes.byref(args), stream))
+    return o, 0.0

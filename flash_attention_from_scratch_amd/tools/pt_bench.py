@@ -1,0 +1,162 @@
+#!/usr/bin/env python3
+"""Event-timed kernel comparison -- the MI355X counterpart of the reference's
+tools/benchmark/pt_bench.py (benchmark_kernel :145-174, stats table :224-411).
+
+Protocol kept from the reference: N warm-ups, then per repeat a cache flush (write a
+buffer larger than L2 + Infinity Cache: 512 MiB here vs the reference's 100 MB for
+A100's 40 MB L2, :36,98-99), an idle spin, and the in-extension event time of
+flash_attention.forward_timed (preferred over outer events, :169-172).  Output is
+the same CSV table (mean/median/min/max/stddev ms, % of the comparator, attention
+TFLOP/s by calc_self_attn_flop) plus the roofline figure 4*B*H*S^2*d.  Clock
+pinning (nvidia-smi -lgc, :111-134) has no unprivileged ROCm equivalent on the GPU
+box; `--perf-determinism` tries `rocm-smi --setperfdeterminism` and carries on.
+
+Kernels are selected with the KERNELS env var exactly as in the reference
+(kernel_configs.get_kernel_configs): all | tune | prog[all] | "B_r,B_c" | native | best.
+"""
+import argparse
+import csv
+import statistics
+import subprocess
+import sys
+from dataclasses import dataclass
+
+import torch
+
+import flash_attention
+from flash_helpers.kernel_configs import calc_mfma_flop, calc_self_attn_flop, get_kernel_configs
+from flash_helpers.test.utils import (
+    BATCH_SIZE_FOR_SEQ_LEN,
+    BENCHMARK_N_HEADS,
+    QKVConfig,
+    generate_qkvo,
+    reference_forward_kernel_v2_timed,
+)
+
+_flush_buf = None
+
+
+def flush_cache():
+    global _flush_buf
+    if _flush_buf is None:
+        _flush_buf = torch.empty(512 * 1024 * 1024, dtype=torch.int8, device="cuda:0")
+    _flush_buf.zero_()
+
+
+@dataclass
+class BenchmarkStats:
+    mean: float
+    median: float
+    min: float
+    max: float
+    stddev: float
+    attn_tflops: float
+    mfma_tflops: float
+
+    def relative_performance(self, baseline_mean: float) -> float:
+        return 100 * baseline_mean / self.mean
+
+
+def calculate_benchmark_stats(samples, attn_flops, mfma_flops) -> BenchmarkStats:
+    mean = statistics.mean(samples)
+    return BenchmarkStats(
+        mean=mean,
+        median=statistics.median(samples),
+        min=min(samples),
+        max=max(samples),
+        stddev=statistics.stdev(samples) if len(samples) > 1 else 0.0,
+        attn_tflops=attn_flops / (mean * 1e-3) / 1e12,
+        mfma_tflops=mfma_flops / (mean * 1e-3) / 1e12,
+    )
+
+
+@torch.inference_mode()
+def benchmark_kernel(kernel, n_warmups=10, n_repeats=50, hermetic=True):
+    """-> list of ms. `kernel()` returns (out, ms) (in-extension events) or out."""
+    for _ in range(n_warmups):
+        kernel()
+    runtimes = []
+    for _ in range(n_repeats):
+        if hermetic:
+            flush_cache()
+            torch.cuda._sleep(1_000_000)
+        torch.cuda.synchronize()
+        start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        start.record()
+        out = kernel()
+        end.record()
+        torch.cuda.synchronize()
+        runtimes.append(out[1] if isinstance(out, tuple) else start.elapsed_time(end))
+    return runtimes
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description=__doc__.split("\n")[0])
+    ap.add_argument("--d_heads", type=str, default="128")
+    ap.add_argument("--seq_lens", type=str, default="512,1024,2048,4096")
+    ap.add_argument("--num_warmups", type=int, default=10)
+    ap.add_argument("--num_repeats", type=int, default=64)
+    ap.add_argument("--noncu", action="store_true", help="no cache flush / idle spin between repeats")
+    ap.add_argument("--batch", type=int, default=0, help="override BATCH_SIZE_FOR_SEQ_LEN")
+    ap.add_argument("--heads", type=int, default=BENCHMARK_N_HEADS)
+    ap.add_argument("--no-ref", action="store_true", help="skip the torch SDPA comparator")
+    ap.add_argument("--perf-determinism", action="store_true")
+    args = ap.parse_args(argv)
+
+    if args.perf_determinism:
+        subprocess.run("rocm-smi --setperfdeterminism 1900", shell=True,
+                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    device = torch.device("cuda:0")
+    writer = csv.writer(sys.stdout)
+    writer.writerow(["Kernel Name", "d_head", "seq_len", "batch", "Mean (ms)", "Median (ms)", "Min (ms)",
+                     "Max (ms)", "StdDev (ms)", "Relative Performance", "Attn TFLOP/s",
+                     "MFMA TFLOP/s (4BHS^2d)", "% of 2.5 PF peak"])
+    harmonic = {}
+    for d_head in map(int, args.d_heads.split(",")):
+        for seq_len in map(int, args.seq_lens.split(",")):
+            batch = args.batch or BATCH_SIZE_FOR_SEQ_LEN[seq_len]
+            data = {}
+            for dtype in (torch.float16, torch.bfloat16):
+                data[dtype] = generate_qkvo(QKVConfig(n_heads=args.heads, d_head=d_head, batch_size=batch,
+                                                      seq_len=seq_len, dtype=dtype, device=device), seed=0)
+            attn_flops = calc_self_attn_flop(batch, args.heads, seq_len, d_head)
+            mfma_flops = calc_mfma_flop(batch, args.heads, seq_len, d_head)
+            rows = []
+            ref_mean = None
+            if not args.no_ref:
+                q, k, v, o = data[torch.float16]
+                ref = calculate_benchmark_stats(
+                    benchmark_kernel(lambda: reference_forward_kernel_v2_timed(q, k, v, o),
+                                     args.num_warmups, max(4, args.num_repeats // 4), not args.noncu),
+                    attn_flops, mfma_flops)
+                ref_mean = ref.mean
+                rows.append(("Reference (torch SDPA fp16)", ref))
+            for cfg in get_kernel_configs():
+                if cfg.d_head != d_head or seq_len % cfg.B_r or seq_len % cfg.B_c:
+                    continue
+                q, k, v, o = data[cfg.dtype.to_torch_dtype()]
+                samples = benchmark_kernel(
+                    lambda: flash_attention.forward_timed(kernel_cfg=cfg, q=q, k=k, v=v, o=o),
+                    args.num_warmups, args.num_repeats, not args.noncu)
+                st = calculate_benchmark_stats(samples, attn_flops, mfma_flops)
+                rows.append((cfg.short_form(), st))
+                harmonic.setdefault(cfg.short_form(), []).append(st.mfma_tflops)
+            rows[1 if ref_mean else 0:] = sorted(rows[1 if ref_mean else 0:], key=lambda r: r[1].mean)
+            for name, st in rows:
+                rel = f"{st.relative_performance(ref_mean):.2f}%" if ref_mean else ""
+                writer.writerow([name, d_head, seq_len, batch, f"{st.mean:.4f}", f"{st.median:.4f}",
+                                 f"{st.min:.4f}", f"{st.max:.4f}", f"{st.stddev:.4f}", rel,
+                                 f"{st.attn_tflops:.2f}", f"{st.mfma_tflops:.2f}",
+                                 f"{100 * st.mfma_tflops / 2500:.1f}"])
+            sys.stdout.flush()
+    n_seq = len(args.seq_lens.split(",")) * len(args.d_heads.split(","))
+    if n_seq > 1:
+        writer.writerow([])
+        writer.writerow(["Kernel Name", "harmonic-mean MFMA TFLOP/s over seq_lens"])
+        for name, vals in sorted(harmonic.items(), key=lambda kv: -statistics.harmonic_mean(kv[1])):
+            if len(vals) == n_seq:
+                writer.writerow([name, f"{statistics.harmonic_mean(vals):.2f}"])
+
+
+if __name__ == "__main__":
+    main()

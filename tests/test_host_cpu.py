@@ -1,0 +1,157 @@
+"""CPU tier: host logic, config surface and the C-ABI library's exports (no compute)."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+import torch
+
+from flash_attention_from_scratch_amd import _capi
+from flash_helpers import kernel_configs as kc
+from tests.conftest import ROOT
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "fa_hip.h")).read()
+    body = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(fa_[a-z_0-9]+)\s*\(", body))
+    assert declared == set(_capi.EXPORTED_SYMBOLS), declared ^ set(_capi.EXPORTED_SYMBOLS)
+    lib = _capi.load()
+    for name in declared:
+        assert hasattr(lib, name), name
+    nm = subprocess.run(["nm", "-D", "--defined-only", _capi.LIB_PATH], capture_output=True, text=True)
+    if nm.returncode == 0:
+        exported = set(re.findall(r" T (fa_[a-z_0-9]+)", nm.stdout))
+        assert declared <= exported
+    assert "gfx950" in _capi.version()
+
+
+def test_struct_layout_matches_header():
+    assert ctypes.sizeof(_capi.FaFwdConfig) == 13 * 4
+    assert ctypes.sizeof(_capi.FaFwdArgs) == 4 * 8 + 7 * 8 + 13 * 4 + 4  # tail padding to 8
+    assert ctypes.sizeof(_capi.FaKernelInfo) == 13 * 4 + 5 * 4
+
+
+def test_every_enumerated_config_has_a_device_kernel():
+    for cfg in kc.get_all_supported_configs():
+        assert _capi.supported(cfg), cfg
+        lds = _capi.lds_bytes(cfg)
+        stages = 2 if cfg.eager_load_blocks else 1
+        assert lds == 2 * stages * cfg.B_c * 128 * 2
+        assert lds <= 160 * 1024
+
+
+def test_registry_enumeration_is_consistent():
+    infos = _capi.kernels()
+    assert len(infos) >= 40
+    seen = set()
+    for info in infos:
+        key = tuple(getattr(info.cfg, f) for f in _capi.CONFIG_FIELDS)
+        assert key not in seen
+        seen.add(key)
+        assert info.threads == 64 * info.cfg.n_warps
+        assert info.rows_per_wave * info.cfg.n_warps == info.cfg.B_r
+        assert info.rows_per_wave in (16, 32, 64)
+        cfg = kc.FlashForwardKernelConfig(kc.DType(info.cfg.dtype), *key[1:5], *map(bool, key[5:8]),
+                                          *key[8:11], *map(bool, key[11:13]))
+        assert _capi.supported(cfg)
+
+
+def test_unsupported_configs_are_rejected():
+    base = kc.get_kernels_to_build()[0]
+    from dataclasses import replace
+
+    assert not _capi.supported(replace(base, d_head=64))
+    assert not _capi.supported(replace(base, B_c=48))
+    assert not _capi.supported(replace(base, n_warps=3))
+    assert not _capi.supported(replace(base, Q_mma_load_K_tiles=2, K_mma_load_K_tiles=0))
+    assert not _capi.supported(replace(base, K_mma_load_K_tiles=3))
+    with pytest.raises(_capi.FaError) as e:
+        _capi.lds_bytes(replace(base, d_head=64))
+    assert "d_head" in str(e.value)
+
+
+def _args(cfg, seq=256, **over):
+    a = dict(q=4096, k=8192, v=12288, o=16384, batch=1, seq_len=seq, n_heads=1, d_head=128,
+             batch_stride=seq * 128, seq_stride=128, head_stride=128, cfg=_capi.make_config(cfg))
+    a.update(over)
+    return _capi.FaFwdArgs(**a)
+
+
+def test_launch_argument_validation_needs_no_gpu():
+    """Validation runs before any HIP call: status codes + the reference's messages."""
+    lib = _capi.load()
+    cfg = kc.FlashForwardKernelConfig(kc.DType.BF16, 128, 128, 64, 4, True, True, True, 2, 2, 0, False, False)
+
+    def status(args):
+        return lib.fa_fwd_launch(ctypes.byref(args), None), _capi.last_error()
+
+    rc, msg = status(_args(cfg, q=0))
+    assert rc == -1 and "null" in msg
+    rc, msg = status(_args(cfg, seq=192, batch_stride=192 * 128))
+    assert rc == -4 and msg == "Only multiples of B_r are supported for seq_len Q currently"
+    rc, msg = status(_args(kc.FlashForwardKernelConfig(kc.DType.BF16, 128, 64, 64, 4, True, True, True, 0, 0, 0, False, False), seq=96))
+    assert rc == -4 and "B_r" in msg
+    rc, msg = status(_args(cfg, d_head=64))
+    assert rc == -4 and "d_head" in msg
+    rc, msg = status(_args(cfg, seq_stride=132))
+    assert rc == -5
+    rc, msg = status(_args(cfg, q=4100))
+    assert rc == -5
+    bad = _args(cfg)
+    bad.cfg.dtype = 6
+    rc, msg = status(bad)
+    assert rc == -2 and msg == "Only fp16 and bf16 are supported"
+    bad = _args(cfg)
+    bad.cfg.B_c = 48
+    rc, msg = status(bad)
+    assert rc == -3 and "not found" in msg
+    if not torch.cuda.is_available():
+        # a valid call on a box without a gfx950 device fails loudly, never falls back
+        rc, msg = status(_args(cfg))
+        assert rc in (-7, -6) and msg
+
+
+def test_python_shim_checks_follow_the_reference():
+    import flash_attention
+
+    cfg = kc.get_kernels_to_build()[0]
+    q = torch.zeros((1, 256, 2, 128), dtype=cfg.dtype.to_torch_dtype())
+    with pytest.raises(RuntimeError, match="must be a CUDA tensor"):
+        flash_attention.forward(cfg, q, q, q)
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setattr(_capi, "_lib", None)
+    monkeypatch.setattr(_capi, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(ImportError, match="no fallback"):
+        _capi.load()
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "flash_attention_from_scratch_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in text and "from oracle" not in text, f
+                assert "fa_oracle" not in text, f
+
+
+def test_short_form_round_trips_and_env_selector(monkeypatch):
+    for cfg in kc.get_all_supported_configs():
+        assert kc.parse_kernel_name_into_config(cfg.short_form()) == cfg
+        assert kc.parse_kernel_name_into_config(f"| {cfg.short_form()} | 1.0 |") == cfg
+    monkeypatch.setenv("KERNELS", "128,64")
+    sel = kc.get_kernel_configs()
+    assert sel and all((c.B_r, c.B_c) == (128, 64) for c in sel)
+    monkeypatch.setenv("KERNELS", "tune")
+    assert len(kc.get_kernel_configs()) == 80
+    monkeypatch.setenv("KERNELS", "prog")
+    assert len(kc.get_kernel_configs()) == 7
+    monkeypatch.setenv("KERNELS", "bogus")
+    with pytest.raises(ValueError):
+        kc.get_kernel_configs()
+    assert kc.DType.from_string("bf16") is kc.DType.BF16 and kc.DType.from_string("5") is kc.DType.FP16
+    assert kc.transform_kernel_name("not a kernel") == "not a kernel"

@@ -1,0 +1,124 @@
+"""CPU tier: the oracle (oracle/) against the fixtures generated from the
+reference's own Python oracles (oracle/gen_golden.py).  This is what pins parity."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import fa_oracle as fo
+from tests.conftest import GOLDEN, load_eager_golden
+
+CASES = [(tag, case) for tag in ("bf16", "fp16") for case in "abc"]
+# one 16-bit ulp at |o| < 0.5 (outputs of N(0,1) attention are O(0.1))
+ULP = {"bf16": 2.0 ** -9, "fp16": 2.0 ** -12}
+
+
+@pytest.mark.parametrize("tag,case", CASES)
+def test_torch_restatement_is_bit_identical_to_reference_eager(tag, case):
+    g = load_eager_golden(tag, case)
+    assert torch.equal(fo.eager_attention(g["q"], g["k"], g["v"], upcast=True), g["o_f32"])
+    assert torch.equal(fo.eager_attention(g["q"], g["k"], g["v"], upcast=False), g["o_b16"])
+
+
+@pytest.mark.parametrize("tag,case", CASES)
+@pytest.mark.parametrize("tiles", [(128, 64), (64, 32), (256, 128)])
+def test_c_blockwise_matches_reference_fp32_eager_within_one_ulp(tag, case, tiles):
+    g = load_eager_golden(tag, case)
+    B_r, B_c = tiles
+    out = fo.blockwise_forward(g["q"], g["k"], g["v"], B_r, B_c)
+    err = (out.float() - g["o_f32"].float()).abs().max().item()
+    assert err <= 2 * ULP[tag], err
+    # and the reference's own accuracy bar (test.py:57-61)
+    lhs, rhs = fo.tolerance_rule(out, g["o_b16"], g["o_f32"])
+    assert lhs <= rhs
+
+
+@pytest.mark.parametrize("tag,case", CASES)
+def test_c_blockwise_optimized_softmax_is_same_arithmetic(tag, case):
+    g = load_eager_golden(tag, case)
+    a = fo.blockwise_forward(g["q"], g["k"], g["v"], 64, 64, optimized_softmax=False)
+    b = fo.blockwise_forward(g["q"], g["k"], g["v"], 64, 64, optimized_softmax=True)
+    # first block: exp2(-inf)=0 rescale of zeros vs skipping it -> identical bits
+    assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("tag,case", CASES)
+def test_c_eager_matches_reference_eager(tag, case):
+    g = load_eager_golden(tag, case)
+    e32 = fo.eager_forward_c(g["q"], g["k"], g["v"], upcast=True)
+    assert (e32.float() - g["o_f32"].float()).abs().max().item() <= ULP[tag]
+    e16 = fo.eager_forward_c(g["q"], g["k"], g["v"], upcast=False)
+    # 16-bit eager accumulates rounding differently inside torch's matmul: a few ulp
+    assert (e16.float() - g["o_b16"].float()).abs().max().item() <= 8 * ULP[tag]
+
+
+@pytest.mark.parametrize("case,tiles", [("a", (128, 64)), ("c", (64, 32))])
+def test_blockwise_trace_matches_reference_block_flash_attention(case, tiles):
+    """tools/debug/debug.py:block_flash_attention output (rows of 'warp 2')."""
+    z = np.load(os.path.join(GOLDEN, f"block_{case}.npz"))
+    g = load_eager_golden("bf16", case)
+    B_r, B_c = tiles
+    assert (int(z["B_r"]), int(z["B_c"])) == tiles
+    rows = slice(int(z["row_start"]), int(z["row_stop"]))
+    q2, k2, v2 = (g[n][0, :, 0].float() for n in ("q", "k", "v"))
+    mine = fo.blockwise_attention_torch(q2, k2, v2, B_c, rows)
+    assert np.abs(mine.numpy() - z["o_final"]).max() < 5e-7
+    # C restatement with fp32 P (round_p=False) reproduces it up to the final bf16 rounding
+    oc, m, l = fo.blockwise_forward(g["q"], g["k"], g["v"], B_r, B_c, round_p=False, return_stats=True)
+    assert np.abs(oc[0, rows, 0].float().numpy() - z["o_final"]).max() <= 2.0 ** -9
+    # statistics: m is the raw-logit row max, l the base-2 row sum
+    S = q2 @ k2.T
+    assert torch.allclose(m[0, 0], S.max(dim=-1).values, rtol=0, atol=1e-4)
+    scale = (128 ** -0.5) * 1.4426950408889634
+    l_ref = (2 ** ((S - S.max(dim=-1, keepdim=True).values) * scale)).sum(-1)
+    assert torch.allclose(l[0, 0], l_ref, rtol=1e-5)
+
+
+def test_16bit_conversions_match_torch_rne():
+    L = fo.lib()
+    gen = torch.Generator().manual_seed(3)
+    xs = torch.cat([
+        torch.randn(4000, generator=gen) * 3,
+        torch.randn(500, generator=gen) * 1e-6,
+        torch.tensor([0.0, -0.0, 65504.0, 65519.0, 65520.0, 1e-8, 6e-8, 2.0 ** -24, 2.0 ** -25,
+                      3 * 2.0 ** -25, 1.0009765625, 1.00048828125, float("inf"), -float("inf")]),
+    ])
+    for code, dt in ((fo.BF16, torch.bfloat16), (fo.FP16, torch.float16)):
+        want = xs.to(dt)
+        want_bits = want.view(torch.int16).numpy().view(np.uint16)
+        for x, wb, w in zip(xs.tolist(), want_bits.tolist(), want.float().tolist()):
+            got = L.fa_oracle_f32_to_b16(x, code)
+            assert got == wb, (x, got, wb, dt)
+            back = L.fa_oracle_b16_to_f32(wb, code)
+            assert back == w or (back != back and w != w)
+
+
+def test_oracle_rejects_bad_tiling():
+    q = torch.zeros((1, 96, 1, 128), dtype=torch.bfloat16)
+    with pytest.raises(RuntimeError):
+        fo.blockwise_forward(q, q, q, 64, 64)
+
+
+def test_reference_enumerations_pinned():
+    """kernel_configs.py enumerations / FLOP model, as captured from the reference."""
+    from flash_helpers import kernel_configs as kc
+
+    with open(os.path.join(GOLDEN, "configs.json")) as f:
+        ref = json.load(f)
+    assert [c.short_form() for c in kc.get_kernels_to_build()] == ref["kernels_to_build"]
+    assert [c.to_cpp_struct() for c in kc.get_kernels_to_build()] == ref["kernels_to_build_cpp"]
+    assert [c.short_form() for c in kc.get_autotuning_kernel_configs()] == ref["autotune"]
+    assert [c.short_form() for c in kc.get_kernel_progression_configs()] == ref["progression"]
+    assert [c.short_form() for c in kc.get_kernel_progression_configs(True)] == ref["progression_all"]
+    assert kc.calc_self_attn_flop(4, 16, 4096, 128) == ref["self_attn_flop_4_16_4096_128"]
+    assert kc.calc_total_flop(4, 16, 4096, 128, 64, 128) == ref["total_flop_4_16_4096_128_64_128"]
+    assert kc.arithmetic_intensity(128, 64, 4096, 128) == ref["arithmetic_intensity_128_64_4096_128"]
+    assert kc.get_kernels_to_build()[0].__class__(*kc.get_kernels_to_build()[0].__dict__.values()).smem_bytes() > 0
+    cfg = kc.parse_kernel_name_into_config(ref["typed_name_example"]["name"])
+    assert cfg.short_form() == ref["typed_name_example"]["short"]
+    from flash_helpers.test import utils as ut
+
+    assert {str(k): v for k, v in ut.BATCH_SIZE_FOR_SEQ_LEN.items()} == ref["batch_size_for_seq_len"]
+    assert ut.BENCHMARK_N_HEADS == ref["benchmark_n_heads"]
