@@ -191,8 +191,12 @@ def test_full_size_properties(name, dtype, B, H, S):
     out = flash_attention.forward(cfg, q, k, v)
     assert torch.isfinite(out.float()).all()
     # (1) linearity in V by a power of two is EXACT in floating point
+    #     (RNE of 2x == 2 RNE of x) wherever the result stays a normal number; fp16
+    #     subnormals (|o| < 2^-14) round on a fixed grid, so those are compared to 1 grid step
     out2 = flash_attention.forward(cfg, q, k, v * 2)
-    assert torch.equal(out2, out * 2)
+    normal = out.float().abs() >= 2.0 ** -14
+    assert torch.equal(out2[normal], (out * 2)[normal])
+    assert (out2.float() - 2 * out.float()).abs().max().item() <= 2.0 ** -23
     # (2) batch-shard independence (the 8-GPU split): a sub-batch gives identical bits
     sub = flash_attention.forward(cfg, q[B // 2:].contiguous(), k[B // 2:].contiguous(), v[B // 2:].contiguous())
     assert torch.equal(sub, out[B // 2:])

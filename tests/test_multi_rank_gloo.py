@@ -1,0 +1,70 @@
+"""CPU tier: the N>1 path of bench.py (batch shard, barrier-bracketed timing,
+max-over-ranks) under torch.distributed with the gloo backend, world_size 2.
+The data path has no collective; the step here is the CPU oracle
+standing in for the kernel, so that shard boundaries and result assembly are checked
+end to end without a GPU."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import bench
+from oracle import fa_oracle as fo
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, global_batch, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    gen = torch.Generator().manual_seed(0)
+    q, k, v = (torch.randn((global_batch, 128, 2, 128), generator=gen).to(torch.bfloat16) for _ in range(3))
+    lo, hi = bench.shard_for_rank(global_batch, world, rank)
+    qs, ks, vs = (t[lo:hi].contiguous() for t in (q, k, v))
+    out = {}
+
+    def step():
+        out["o"] = fo.blockwise_forward(qs, ks, vs, 64, 64, n_threads=1)
+
+    seconds = bench.timed_steps(step, steps=2, warmup=1, sync=lambda: None, barrier=dist.barrier)
+    slowest = bench.max_over_ranks(seconds + rank, world, torch.device("cpu"))
+    torch.save({"lo": lo, "hi": hi, "o": out["o"], "seconds": seconds, "slowest": slowest},
+               os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("global_batch", [4, 5])
+def test_batch_shard_world_size_2(tmp_path, global_batch):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), global_batch, str(tmp_path)), nprocs=world, join=True)
+    parts = [torch.load(tmp_path / f"rank{r}.pt") for r in range(world)]
+    # shards tile the batch exactly once, in order
+    assert parts[0]["lo"] == 0 and parts[-1]["hi"] == global_batch
+    assert parts[0]["hi"] == parts[1]["lo"]
+    # assembled output == unsharded computation, bit for bit (no cross-batch coupling)
+    gen = torch.Generator().manual_seed(0)
+    q, k, v = (torch.randn((global_batch, 128, 2, 128), generator=gen).to(torch.bfloat16) for _ in range(3))
+    whole = fo.blockwise_forward(q, k, v, 64, 64, n_threads=1)
+    assert torch.equal(torch.cat([p["o"] for p in parts]), whole)
+    # max-over-ranks: both ranks agree on the slowest rank's time (rank 1 added 1 s)
+    assert parts[0]["slowest"] == parts[1]["slowest"] >= parts[1]["seconds"] + 1 - 1e-9
+
+
+def test_shard_partition_properties():
+    for gb in range(1, 70):
+        for world in (1, 2, 3, 4, 8):
+            spans = [bench.shard_for_rank(gb, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == gb
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+    assert bench.mfma_flop(4, 16, 4096, 128) == 549755813888
