@@ -69,14 +69,19 @@ const fa::KernelEntry *find_kernel(const fa_fwd_config *c, const char **why) {
     if (c->Q_mma_load_K_tiles != 0 && c->Q_mma_load_K_tiles != c->K_mma_load_K_tiles)
         return nullptr;
     const int rows_per_wave = c->B_r / c->n_warps;
+    // mma_double_buffer_loads selects the software-pipelined loop where one is built;
+    // otherwise it is a hint like the load_K_tiles fields and the plain loop is used.
+    const fa::KernelEntry *plain = nullptr;
     for (const auto &e : registry()) {
         if (e.dtype == c->dtype && e.rows_per_wave == rows_per_wave && e.n_waves == c->n_warps &&
             e.B_c == c->B_c && e.swizzled == (c->swizzled != 0) &&
             e.eager == (c->eager_load_blocks != 0) && e.opt_softmax == (c->optimized_softmax != 0) &&
-            e.async_copy == (c->async_copy != 0))
-            return &e;
+            e.async_copy == (c->async_copy != 0)) {
+            if (e.pipelined == (c->mma_double_buffer_loads != 0)) return &e;
+            if (!e.pipelined) plain = &e;
+        }
     }
-    return nullptr;
+    return plain;
 }
 
 std::once_flag g_init_once;
@@ -242,6 +247,7 @@ int fa_get_kernel(int index, fa_kernel_info *out) {
     out->cfg.eager_load_blocks = e.eager;
     out->cfg.swizzled = e.swizzled;
     out->cfg.optimized_softmax = e.opt_softmax;
+    out->cfg.mma_double_buffer_loads = e.pipelined;
     out->threads = e.threads;
     out->lds_bytes = e.lds_bytes;
     out->rows_per_wave = e.rows_per_wave;

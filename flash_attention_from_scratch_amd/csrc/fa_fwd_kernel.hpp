@@ -45,6 +45,9 @@
 //   SWZ     XOR-swizzled K image             (cfg.swizzled)
 //   EAGER   prefetch next tile, 2 LDS buffers (cfg.eager_load_blocks)
 //   OPT     first KV block skips the rescale  (cfg.optimized_softmax)
+//   PIPE    software-pipelined loop: QK^T of tile j runs beside the O rescale, and
+//           P.V of tile j-1 beside the softmax of tile j, so one wave's stream
+//           always carries MFMA and VALU work together (cfg.mma_double_buffer_loads)
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -65,6 +68,10 @@ struct KernelArgs {
     int32_t n_bh;          // batch * heads
     int32_t n_q_blocks;
     int32_t n_kv_blocks;
+#ifdef FA_TRACE
+    unsigned long long *trace;  // tools/segment_timer.hip only: [wave][visit][8] s_memtime stamps
+    int32_t trace_block;
+#endif
 };
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -124,13 +131,62 @@ static FA_DEV float pair_sum(float x) {
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
-static FA_DEV void glds16(const void *gsrc, char *lds_dst_wave_uniform) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc,
-                                     (FA_LDS(void) *)lds_dst_wave_uniform, 16, 0, 0);
+// 16-byte-per-lane global -> LDS DMA (1 KiB per wave-instruction).  Written as inline
+// asm on purpose: hipcc tracks the builtin form as an LDS write and puts a full
+// `s_waitcnt vmcnt(0)` in front of the next ds_read of the same __shared__ array,
+// which would serialise every prefetch with the compute it is meant to hide under.
+// The kernel counts these loads itself: each wave executes dma_wait_all() before the
+// barrier that publishes a stage (cdna_hip_programming.md 5.7 item 1).
+// LDS destination = M0 (wave-uniform byte address) + lane * 16.
+static FA_DEV void glds16(const void *gsrc, unsigned lds_dst_wave_uniform) {
+    unsigned keep;  // M0 is compiler-reserved: save / restore it inside the statement
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_dst_wave_uniform)
+                 : "memory");
+}
+static FA_DEV void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// workgroup barrier that the compiler may not move LDS traffic across and that does
+// not drain VMEM (in-flight DMA survives it)
+static FA_DEV void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+#ifdef FA_TRACE
+#define FA_STAMP(visit, k)                                                                  \
+    do {                                                                                    \
+        if (blockIdx.x == (unsigned)args.trace_block && visit < 64) {                       \
+            unsigned long long t_;                                                          \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");      \
+            if (lane == 0) args.trace[(wave * 64 + (visit)) * 8 + (k)] = t_;                \
+        }                                                                                   \
+    } while (0)
+#else
+#define FA_STAMP(visit, k) do { } while (0)
+#endif
+
+// Instruction-group pins for the LLVM scheduler (mask: 0x8 MFMA, 0x100 DS read).
+// Left alone, hipcc feeds each MFMA from an LDS read issued one or two instructions
+// earlier, so every MFMA eats the LDS latency (measured 57 cycles per MFMA instead of
+// 32).  These sequences keep `depth` operand reads in flight ahead of the matrix pipe.
+template <int N_MFMA, int READS_PER_MFMA, int DEPTH>
+static FA_DEV void sched_mfma_fed_from_lds() {
+    constexpr int kReads = N_MFMA * READS_PER_MFMA;
+    constexpr int kPre = DEPTH < kReads ? DEPTH : kReads;
+    __builtin_amdgcn_sched_group_barrier(0x100, kPre, 0);
+#pragma unroll
+    for (int i = 0; i < N_MFMA; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+        if (kPre + (i + 1) * READS_PER_MFMA <= kReads)
+            __builtin_amdgcn_sched_group_barrier(0x100, READS_PER_MFMA, 0);
+    }
 }
 
-template <int DT, int QT, int NWAVES, int BC, bool SWZ, bool EAGER, bool OPT>
+static FA_DEV unsigned lds_addr(const char *p) {
+    return (unsigned)(unsigned long long)(FA_LDS(const char) *)p;
+}
+
+template <int DT, int QT, int NWAVES, int BC, bool SWZ, bool EAGER, bool OPT, bool PIPE>
 struct FwdTraits {
+    static_assert(!PIPE || EAGER, "the pipelined loop needs both LDS stages");
     static constexpr int kRowsPerWave = 32 * QT;
     static constexpr int kBr = kRowsPerWave * NWAVES;
     static constexpr int kBc = BC;
@@ -138,27 +194,34 @@ struct FwdTraits {
     static constexpr int kTileBytes = BC * 256;                 // one K or V tile (d = 128)
     static constexpr int kStages = EAGER ? 2 : 1;
     static constexpr int kLdsBytes = 2 * kStages * kTileBytes;  // K + V, all stages
-    static constexpr int kMinWavesPerSimd = (QT == 1) ? 2 : 1;
 };
 
 // ---------------------------------------------------------------------------------
 // The kernel.  d_head is fixed at 128 (reference: README.md:7-15).
 // ---------------------------------------------------------------------------------
-template <int DT, int QT, int NWAVES, int BC, bool SWZ, bool EAGER, bool OPT>
+// ABL (tools/ablate.hip only; 0 in every shipped variant) removes one cost at a time to
+// attribute cycles: 1 no v_exp, 2 no softmax VALU at all, 4 no LDS operand reads,
+// 8 no barriers / DMA waits, 16 no DMA.  Results are wrong by construction when ABL != 0.
+template <int DT, int QT, int NWAVES, int BC, bool SWZ, bool EAGER, bool OPT, bool PIPE, int ABL = 0>
 __global__ void
 __launch_bounds__(NWAVES * 64, (QT == 1) ? 2 : 1)
 fa_fwd_kernel(const KernelArgs args) {
     using E = Elem<DT>;
     using vec8 = typename E::vec8;
-    using TR = FwdTraits<DT, QT, NWAVES, BC, SWZ, EAGER, OPT>;
+    using TR = FwdTraits<DT, QT, NWAVES, BC, SWZ, EAGER, OPT, PIPE>;
     constexpr int D = 128;
     constexpr int NT = BC / 32;              // 32-key tiles per LDS tile
     constexpr int KS = D / 16;               // k steps of the QK^T contraction
     constexpr int DTILES = D / 32;           // 32-wide d tiles of O^T
     constexpr int TILE = TR::kTileBytes;
     constexpr int N_DMA = BC / 4;            // 1-KiB DMA pieces per K (or V) tile
-    static_assert(N_DMA % NWAVES == 0 || NWAVES % N_DMA == 0, "tile/wave split");
-    constexpr int DMA_PER_WAVE = (N_DMA >= NWAVES) ? N_DMA / NWAVES : 1;
+    static_assert(N_DMA % NWAVES == 0, "tile/wave split");
+    constexpr int DMA_PER_WAVE = N_DMA / NWAVES;
+#ifdef FA_NO_SCHED
+    constexpr bool SCHED = false;
+#else
+    constexpr bool SCHED = (QT == 1);
+#endif
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // LDS carve: K stage 0 | K stage 1 | V stage 0 | V stage 1
@@ -204,29 +267,53 @@ fa_fwd_kernel(const KernelArgs args) {
     const int64_t v_lane_row = (v_w >> 2);                                 // key & 7
     const int v_lane_d = (v_w & 3) * 8;
 
-    auto issue_tile = [&](int kv_block, int stage) {
-        const int64_t kv0 = (int64_t)kv_block * BC;
-        char *kdst = smem + stage * TILE;
-        char *vdst = smem + V_BASE + stage * TILE;
+    // KV blocks are visited last-to-first (forward_kernel.cuh:142,175-184): visit
+    // index `it` is sequence block n_kv-1-it.
+    const int n_kv = args.n_kv_blocks;
+    const unsigned smem_base = __builtin_amdgcn_readfirstlane(lds_addr(smem));
+    // per-lane source pointers of this wave's DMA pieces for the tile at sequence block 0;
+    // a visit adds the wave-uniform tile offset (one 64-bit add per piece)
+    const uint16_t *k_src[DMA_PER_WAVE], *v_src[DMA_PER_WAVE];
 #pragma unroll
-        for (int j = 0; j < DMA_PER_WAVE; ++j) {
-            const int i = wave + NWAVES * j;  // piece index, wave-uniform
-            if (N_DMA >= NWAVES || i < N_DMA) {
-                // K piece: keys 4i .. 4i+3
-                const uint16_t *ksrc = Kg + (kv0 + 4 * i) * ss + k_lane_off;
-                glds16(ksrc, kdst + i * 1024);
-                // V piece: subtiles 2i, 2i+1 -> keys 8*(sub>>2) + (w>>2), d (sub&3)*32 + ...
-                const int sub = 2 * i + v_sub_in_piece;
-                const uint16_t *vsrc =
-                    Vg + (kv0 + 8 * (sub >> 2) + v_lane_row) * ss + (sub & 3) * 32 + v_lane_d;
-                glds16(vsrc, vdst + i * 1024);
-            }
-        }
+    for (int j = 0; j < DMA_PER_WAVE; ++j) {
+        const int i = wave + NWAVES * j;  // piece index, wave-uniform; keys 4i .. 4i+3
+        k_src[j] = Kg + (int64_t)(4 * i) * ss + k_lane_off;
+        const int sub = 2 * i + v_sub_in_piece;  // subtiles 2i, 2i+1
+        v_src[j] = Vg + (8 * (sub >> 2) + v_lane_row) * ss + (sub & 3) * 32 + v_lane_d;
+    }
+    const int64_t tile_stride = (int64_t)BC * ss;  // elements between consecutive KV blocks
+    auto issue_k = [&](int it, int stage) {
+        const int64_t tile_off = (int64_t)(n_kv - 1 - it) * tile_stride;
+        const unsigned kdst = smem_base + stage * TILE;
+        if (ABL & 16) return;
+#pragma unroll
+        for (int j = 0; j < DMA_PER_WAVE; ++j)
+            glds16(k_src[j] + tile_off, kdst + (wave + NWAVES * j) * 1024);
+    };
+    auto issue_v = [&](int it, int stage) {
+        const int64_t tile_off = (int64_t)(n_kv - 1 - it) * tile_stride;
+        const unsigned vdst = smem_base + V_BASE + stage * TILE;
+        if (ABL & 16) return;
+#pragma unroll
+        for (int j = 0; j < DMA_PER_WAVE; ++j)
+            glds16(v_src[j] + tile_off, vdst + (wave + NWAVES * j) * 1024);
+    };
+    auto dma_wait = [&]() { if (!(ABL & 8)) dma_wait_all(); };
+    auto barrier = [&]() { if (!(ABL & 8)) wg_barrier(); };
+    auto wait_and_barrier = [&]() {
+        dma_wait();
+        barrier();
     };
 
-    // ---- prologue: first (= last in sequence) KV tile in flight, then Q -> VGPRs --
-    int kv_block = args.n_kv_blocks - 1;
-    if (EAGER) issue_tile(kv_block, 0);
+#ifdef FA_TRACE
+    if (blockIdx.x == (unsigned)args.trace_block && lane == 0)
+        args.trace[(wave * 64 + 63) * 8 + 7] = __builtin_amdgcn_s_getreg((31 << 11) | 4);  // HW_REG_HW_ID
+#endif
+    // ---- prologue: first tiles in flight, then Q -> VGPRs --------------------------
+    if (EAGER) {
+        issue_k(0, 0);
+        issue_v(0, 0);
+    }
 
     vec8 Qr[QT][KS];
 #pragma unroll
@@ -260,32 +347,52 @@ fa_fwd_kernel(const KernelArgs args) {
     const int li = lane & 15, lg = lane >> 4;
     const int va_base = (4 * (lg >> 1) + (li >> 2)) * 64 + (lg & 1) * 32 + (li & 3) * 8;
 
-    auto compute_tile = [&](int stage, auto first_tag) {
-        constexpr bool FIRST = decltype(first_tag)::value;
+    // ---- S^T = K Q^T ------------------------------------------------------------
+    auto qk = [&](int stage, f32x16 (&S)[QT][NT]) {
         const char *kt = smem + stage * TILE;
-        const char *vt = smem + V_BASE + stage * TILE;
-
-        // ---- S^T = K Q^T -------------------------------------------------------
-        f32x16 S[QT][NT];
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) S[qt][nt][r] = 0.0f;
+        // ks outer / key-tile inner: consecutive MFMAs accumulate into different tiles
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
+        for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
+            for (int nt = 0; nt < NT; ++nt) {
                 const int off = nt * 32 * 256 + ka_base + (((2 * ks + hi) ^ ka_swz) << 4);
-                const vec8 a = *(const vec8 *)(kt + off);
+                const vec8 a = (ABL & 4) ? Qr[0][(ks + nt) % KS] : *(const vec8 *)(kt + off);
 #pragma unroll
                 for (int qt = 0; qt < QT; ++qt) S[qt][nt] = E::mfma(a, Qr[qt][ks], S[qt][nt]);
             }
         }
+        if (SCHED && !PIPE) sched_mfma_fed_from_lds<NT * KS * QT, 1, 8>();
+    };
 
-        // ---- online softmax, lane-local (softmax.cuh:85-105) ---------------------
-        vec8 Pb[QT][NT][2];
+    // ---- online softmax, lane-local (softmax.cuh:85-105) --------------------------
+    // Updates m, l; returns P (16-bit, MFMA B-operand order) and the rescale factor
+    // alpha = exp2((m_prev - m_new) c) that (l, O) must be multiplied by BEFORE P.V
+    // of this tile is accumulated (scale_l_O, softmax.cuh:36-49).  l is rescaled here;
+    // O by rescale_O() -- skipped when alpha == 1 in every lane (multiplying by 1.0f is
+    // the identity, so the skip is bit-exact).
+    auto softmax = [&](f32x16 (&S)[QT][NT], vec8 (&Pb)[QT][NT][2], float (&alpha)[QT], auto first_tag) {
+        constexpr bool FIRST = decltype(first_tag)::value;
+        if (ABL & 2) {
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt) {
+                alpha[qt] = 1.0f;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    float p[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) p[r] = S[qt][nt][r];
+                    Pb[qt][nt][0] = E::pack8(p);
+                    Pb[qt][nt][1] = E::pack8(p + 8);
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) {
             float mx = S[qt][0][0];
@@ -297,15 +404,11 @@ fa_fwd_kernel(const KernelArgs args) {
             float m_new;
             if (FIRST && OPT) {
                 m_new = mx;
+                alpha[qt] = 1.0f;
             } else {
                 m_new = fmaxf(m[qt], mx);
-                // scale_l_O, softmax.cuh:36-49
-                const float alpha = __builtin_amdgcn_exp2f((m[qt] - m_new) * c);
-                l[qt] *= alpha;
-#pragma unroll
-                for (int t = 0; t < DTILES; ++t)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) O[qt][t][r] *= alpha;
+                alpha[qt] = __builtin_amdgcn_exp2f((m[qt] - m_new) * c);
+                l[qt] *= alpha[qt];
             }
             m[qt] = m_new;
             const float neg_msc = -(m_new * c);
@@ -316,7 +419,8 @@ fa_fwd_kernel(const KernelArgs args) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     // exponentiate_tensor, softmax.cuh:51-64: exp2(s*c - m*c)
-                    p[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(S[qt][nt][r], c, neg_msc));
+                    p[r] = __builtin_fmaf(S[qt][nt][r], c, neg_msc);
+                    if (!(ABL & 1)) p[r] = __builtin_amdgcn_exp2f(p[r]);
                     rowsum += p[r];  // fp32 P, before rounding (softmax.cuh:66-83)
                 }
                 Pb[qt][nt][0] = E::pack8(p);
@@ -324,14 +428,29 @@ fa_fwd_kernel(const KernelArgs args) {
             }
             l[qt] = (FIRST && OPT) ? rowsum : l[qt] + rowsum;
         }
+    };
 
-        // ---- O^T += V^T P^T ------------------------------------------------------
+    auto rescale_O = [&](const float (&alpha)[QT]) {
 #pragma unroll
-        for (int t = 0; t < DTILES; ++t) {
+        for (int qt = 0; qt < QT; ++qt) {
+            if (__all(alpha[qt] == 1.0f)) continue;  // wave-uniform
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
+            for (int t = 0; t < DTILES; ++t)
 #pragma unroll
-                for (int half = 0; half < 2; ++half) {
+                for (int r = 0; r < 16; ++r) O[qt][t][r] *= alpha[qt];
+        }
+    };
+
+    // ---- O^T += V^T P^T ------------------------------------------------------------
+    auto pv = [&](int stage, const vec8 (&Pb)[QT][NT][2]) {
+        const char *vt = smem + V_BASE + stage * TILE;
+        // 16-key slice outer / d tile inner: consecutive MFMAs hit different accumulators
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+#pragma unroll
+                for (int t = 0; t < DTILES; ++t) {
                     const int s16 = 2 * nt + half;
                     const char *vp = vt + va_base + s16 * 4096 + t * 512;
                     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((FA_LDS(s16x4) *)(vp));
@@ -340,40 +459,174 @@ fa_fwd_kernel(const KernelArgs args) {
                     s16x8 av;
                     av.lo = lo;
                     av.hi = up;
-                    const vec8 a = __builtin_bit_cast(vec8, av);
+                    const vec8 a = (ABL & 4) ? Qr[0][(t + s16) % KS] : __builtin_bit_cast(vec8, av);
 #pragma unroll
                     for (int qt = 0; qt < QT; ++qt)
                         O[qt][t] = E::mfma(a, Pb[qt][nt][half], O[qt][t]);
                 }
             }
         }
+        if (SCHED && !PIPE) sched_mfma_fed_from_lds<DTILES * NT * 2 * QT, 2, 8>();
     };
 
     using TrueTag = BoolTag<true>;
     using FalseTag = BoolTag<false>;
 
-    // ---- main loop over KV tiles, last to first (forward_kernel.cuh:142,175-184) --
-    const int n_kv = args.n_kv_blocks;
-    if (EAGER) {
-        // tile `it` lives in stage it&1; its DMA was issued one iteration earlier.
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (n_kv > 1) issue_tile(kv_block - 1, 1);
-        if (OPT) compute_tile(0, TrueTag{}); else compute_tile(0, FalseTag{});
-        for (int it = 1; it < n_kv; ++it) {
-            const int stage = it & 1;
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();  // tile `it` landed for every wave; stage^1 free again
-            if (it + 1 < n_kv) issue_tile(kv_block - it - 1, stage ^ 1);
-            compute_tile(stage, FalseTag{});
+    if (PIPE) {
+        // In-wave software pipeline with two S accumulators.  While the matrix pipe forms
+        // S(it+1) = K(it+1) Q^T and then O += V(it) P(it), the VALU turns the finished S(it)
+        // into P(it): every MFMA of the visit has ~4-5 independent VALU ops and 1-2 LDS
+        // operand reads scheduled beside it (sched_group_barrier pins the interleave), so a
+        // wave keeps the matrix pipe and the vector ALU busy together regardless of what
+        // its SIMD partner is doing.  Per visit `it` (S_cur = S(it), complete):
+        //   top    : barrier (K(it+1), V(it) landed; stages of K(it), V(it-1) free);
+        //            DMA K(it+2), V(it+1); m/alpha/l update from the row max found last
+        //            visit; O *= alpha only if some lane's max moved
+        //   MFMA   : 8*NT x QK^T(it+1)  ->  4*NT x P.V(it) keys 0-31  ->  ... keys 32-63 ...
+        //   VALU   : P = exp2(S_cur*c - m*c), row sums, 16-bit pack, tile by tile, then the
+        //            row max of S(it+1)
+        // O is only ever rescaled while no P.V is in flight (start of a visit), so the
+        // factor applies to exactly the terms accumulated so far (guide T13 hazard).
+        f32x16 Sa[QT][NT], Sb[QT][NT];
+        float mx[QT];     // row max of the S tile that becomes S_cur next
+        auto row_max = [&](f32x16 (&S)[QT][NT]) {
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt) {
+                float v = S[qt][0][0];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) v = fmaxf(v, S[qt][nt][r]);
+                mx[qt] = pair_max(v);
+            }
+        };
+        auto visit = [&](int it, f32x16 (&S_cur)[QT][NT], f32x16 (&S_nxt)[QT][NT], auto last_tag) {
+            constexpr bool LAST = decltype(last_tag)::value;
+            FA_STAMP(it, 0);
+            wait_and_barrier();
+            FA_STAMP(it, 1);
+            if (it + 2 < n_kv) issue_k(it + 2, it & 1);
+            if (it + 1 < n_kv) issue_v(it + 1, (it + 1) & 1);
+            // scale_l_O (softmax.cuh:36-49) with the new running max
+            float neg_msc[QT], rowsum[QT];
+            bool moved = false;
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt) {
+                const float m_new = fmaxf(m[qt], mx[qt]);
+                const float alpha = __builtin_amdgcn_exp2f((m[qt] - m_new) * c);
+                l[qt] *= alpha;
+                m[qt] = m_new;
+                neg_msc[qt] = -(m_new * c);
+                rowsum[qt] = 0.0f;
+                if (!(OPT && it == 0) && !__all(alpha == 1.0f)) {
+                    moved = true;
+#pragma unroll
+                    for (int t = 0; t < DTILES; ++t)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) O[qt][t][r] *= alpha;
+                }
+            }
+            (void)moved;
+            FA_STAMP(it, 2);
+            // ---- matrix stream 1: S_nxt = K(it+1) Q^T ---------------------------------
+            if (!LAST) qk((it + 1) & 1, S_nxt);
+            // ---- vector stream: P = exp2(S_cur c - m c) (softmax.cuh:51-83) -------------
+            vec8 P[QT][NT][2];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt) {
+                    float p[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        p[r] = __builtin_fmaf(S_cur[qt][nt][r], c, neg_msc[qt]);
+                        if (!(ABL & 1)) p[r] = __builtin_amdgcn_exp2f(p[r]);
+                        rowsum[qt] += p[r];
+                    }
+                    P[qt][nt][0] = E::pack8(p);
+                    P[qt][nt][1] = E::pack8(p + 8);
+                }
+            }
+            // ---- matrix stream 2: O += V(it) P --------------------------------------------
+            pv(it & 1, P);
+            if (!LAST) row_max(S_nxt);
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt) l[qt] += rowsum[qt];
+            if (SCHED) {
+                // interleave: 8 operand reads ahead, then per MFMA 1-2 reads + 5 VALU/TRANS
+                constexpr int N_QK = LAST ? 0 : NT * KS * QT, N_PV = DTILES * NT * 2 * QT;
+                __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+#pragma unroll
+                for (int i = 0; i < N_QK; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x402, 5, 0);
+                }
+#pragma unroll
+                for (int i = 0; i < N_PV; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x402, 5, 0);
+                }
+            }
+            FA_STAMP(it, 3);
+        };
+        wait_and_barrier();  // K(0), V(0) landed
+        if (n_kv > 1) issue_k(1, 1);
+        qk(0, Sa);
+        row_max(Sa);
+        int it = 0;
+        for (; it + 2 < n_kv; it += 2) {
+            visit(it, Sa, Sb, FalseTag{});
+            visit(it + 1, Sb, Sa, FalseTag{});
         }
+        if (it + 2 == n_kv) {
+            visit(it, Sa, Sb, FalseTag{});
+            visit(it + 1, Sb, Sa, TrueTag{});
+        } else {
+            visit(it, Sa, Sb, TrueTag{});
+        }
+    } else if (EAGER) {
+        // tile `it` lives in stage it&1; its DMA was issued one visit earlier.
+        auto visit = [&](int it, auto first_tag) {
+            const int stage = it & 1;
+            FA_STAMP(it, 0);
+            wait_and_barrier();  // tile `it` landed for every wave; stage^1 free again
+            FA_STAMP(it, 1);
+            if (it + 1 < n_kv) {
+                issue_k(it + 1, stage ^ 1);
+                issue_v(it + 1, stage ^ 1);
+            }
+            f32x16 S[QT][NT];
+            vec8 P[QT][NT][2];
+            float alpha[QT];
+            qk(stage, S);
+            FA_STAMP(it, 2);
+            softmax(S, P, alpha, first_tag);
+            if (!decltype(first_tag)::value) rescale_O(alpha);
+            FA_STAMP(it, 3);
+            pv(stage, P);
+            FA_STAMP(it, 4);
+        };
+        if (OPT) visit(0, TrueTag{}); else visit(0, FalseTag{});
+        for (int it = 1; it < n_kv; ++it) visit(it, FalseTag{});
     } else {
         for (int it = 0; it < n_kv; ++it) {
-            if (it > 0) __syncthreads();  // everyone done reading the single stage
-            issue_tile(kv_block - it, 0);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (OPT && it == 0) compute_tile(0, TrueTag{}); else compute_tile(0, FalseTag{});
+            if (it > 0) barrier();  // everyone done reading the single stage
+            issue_k(it, 0);
+            issue_v(it, 0);
+            wait_and_barrier();
+            f32x16 S[QT][NT];
+            vec8 P[QT][NT][2];
+            float alpha[QT];
+            qk(0, S);
+            if (OPT && it == 0) {
+                softmax(S, P, alpha, TrueTag{});
+            } else {
+                softmax(S, P, alpha, FalseTag{});
+                rescale_O(alpha);
+            }
+            pv(0, P);
         }
     }
 

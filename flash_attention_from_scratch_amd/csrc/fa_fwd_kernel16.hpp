@@ -89,10 +89,11 @@ fa_fwd_kernel16(const KernelArgs args) {
     const int64_t k_lane_off = (int64_t)k_row_in_piece * ss + (((lane & 15) ^ k_swz) << 3);
     const int v_w = lane & 31;
 
+    const unsigned smem_base = __builtin_amdgcn_readfirstlane(lds_addr(smem));
     auto issue_tile = [&](int kv_block, int stage) {
         const int64_t kv0 = (int64_t)kv_block * BC;
-        char *kdst = smem + stage * TILE;
-        char *vdst = smem + V_BASE + stage * TILE;
+        const unsigned kdst = smem_base + stage * TILE;
+        const unsigned vdst = smem_base + V_BASE + stage * TILE;
 #pragma unroll
         for (int j = 0; j < DMA_PER_WAVE; ++j) {
             const int i = wave + NWAVES * j;
@@ -201,23 +202,23 @@ fa_fwd_kernel16(const KernelArgs args) {
     using FalseTag = BoolTag<false>;
     const int n_kv = args.n_kv_blocks;
     if (EAGER) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        dma_wait_all();
+        wg_barrier();
         if (n_kv > 1) issue_tile(kv_block - 1, 1);
         if (OPT) compute_tile(0, TrueTag{}); else compute_tile(0, FalseTag{});
         for (int it = 1; it < n_kv; ++it) {
             const int stage = it & 1;
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
+            dma_wait_all();
+            wg_barrier();
             if (it + 1 < n_kv) issue_tile(kv_block - it - 1, stage ^ 1);
             compute_tile(stage, FalseTag{});
         }
     } else {
         for (int it = 0; it < n_kv; ++it) {
-            if (it > 0) __syncthreads();
+            if (it > 0) wg_barrier();
             issue_tile(kv_block - it, 0);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
+            dma_wait_all();
+            wg_barrier();
             if (OPT && it == 0) compute_tile(0, TrueTag{}); else compute_tile(0, FalseTag{});
         }
     }
@@ -242,7 +243,7 @@ fa_fwd_kernel16(const KernelArgs args) {
 template <int DT, int NWAVES, int BC, bool SWZ, bool EAGER, bool OPT>
 constexpr KernelEntry make_entry16() {
     using TR = FwdTraits16<DT, NWAVES, BC, SWZ, EAGER, OPT>;
-    return KernelEntry{DT, 16, NWAVES, BC, SWZ, EAGER, OPT, 1, TR::kThreads, TR::kLdsBytes,
+    return KernelEntry{DT, 16, NWAVES, BC, SWZ, EAGER, OPT, 0, 1, TR::kThreads, TR::kLdsBytes,
                        (kernel_fn)&fa_fwd_kernel16<DT, NWAVES, BC, SWZ, EAGER, OPT>};
 }
 

@@ -14,26 +14,31 @@
 namespace fa {
 namespace {
 
-#define E(NW, BC, SWZ, EAGER, OPT) make_entry<FA_INST_DT, FA_INST_QT, NW, BC, SWZ, EAGER, OPT>()
+#define E1(NW, BC, SWZ, EAGER, OPT) \
+    make_entry<FA_INST_DT, FA_INST_QT, NW, BC, SWZ, EAGER, OPT, false>()
+#define E(NW, BC, SWZ, EAGER, OPT) \
+    make_entry<FA_INST_DT, FA_INST_QT, NW, BC, SWZ, EAGER, OPT, false>(), \
+    make_entry<FA_INST_DT, FA_INST_QT, NW, BC, SWZ, EAGER, OPT, EAGER>()
 
 const KernelEntry kEntries[] = {
 #if FA_INST_QT == 1
     // 32 Q rows per wave: B_r = 128 (4 waves) or 256 (8 waves)
     E(4, 64, true, true, false),  E(4, 64, true, true, true),
     E(4, 32, true, true, false),  E(4, 32, true, true, true),
-    E(4, 128, true, true, false), E(4, 128, true, true, true),
+    E1(4, 128, true, true, false), E1(4, 128, true, true, true),  // pipelined loop spills at B_c=128
     E(8, 64, true, true, false),  E(8, 64, true, true, true),
     E(8, 32, true, true, false),  E(8, 32, true, true, true),
-    E(8, 128, true, true, false), E(8, 128, true, true, true),
+    E1(8, 128, true, true, false), E1(8, 128, true, true, true),
     // progression steps: no swizzle / no eager prefetch
-    E(4, 64, false, false, false), E(4, 64, true, false, false),
+    E1(4, 64, false, false, false), E1(4, 64, true, false, false),
 #else
     // 64 Q rows per wave (one wave per SIMD, whole register file): B_r = 256 (4 waves)
-    E(4, 64, true, true, false),  E(4, 64, true, true, true),
-    E(4, 128, true, true, false), E(4, 128, true, true, true),
+    // (the pipelined loop and B_c = 128 do not fit 512 registers without spilling)
+    E1(4, 64, true, true, false), E1(4, 64, true, true, true),
 #endif
 };
 #undef E
+#undef E1
 
 }  // namespace
 

@@ -19,17 +19,19 @@ struct KernelEntry {
     int swizzled;
     int eager;
     int opt_softmax;
+    int pipelined;      // cfg.mma_double_buffer_loads
     int async_copy;
     int threads;
     int lds_bytes;
     kernel_fn fn;
 };
 
-template <int DT, int QT, int NWAVES, int BC, bool SWZ, bool EAGER, bool OPT>
+template <int DT, int QT, int NWAVES, int BC, bool SWZ, bool EAGER, bool OPT, bool PIPE>
 constexpr KernelEntry make_entry() {
-    using TR = FwdTraits<DT, QT, NWAVES, BC, SWZ, EAGER, OPT>;
-    return KernelEntry{DT, 32 * QT, NWAVES, BC, SWZ, EAGER, OPT, 1, TR::kThreads, TR::kLdsBytes,
-                       (kernel_fn)&fa_fwd_kernel<DT, QT, NWAVES, BC, SWZ, EAGER, OPT>};
+    using TR = FwdTraits<DT, QT, NWAVES, BC, SWZ, EAGER, OPT, PIPE>;
+    return KernelEntry{DT, 32 * QT, NWAVES, BC, SWZ, EAGER, OPT, PIPE, 1, TR::kThreads,
+                       TR::kLdsBytes,
+                       (kernel_fn)&fa_fwd_kernel<DT, QT, NWAVES, BC, SWZ, EAGER, OPT, PIPE>};
 }
 
 struct KernelTable {

@@ -383,17 +383,17 @@ def get_native_kernel_configs(dtypes=(DType.BF16, DType.FP16)):
         (256, 128, 8),
         (256, 32, 8),
         (256, 64, 4),
-        (256, 128, 4),
     ]
     out = []
     for dtype in dtypes:
         for B_r, B_c, n_waves in shapes:
-            for opt in (False, True):
-                out.append(
-                    FlashForwardKernelConfig(
-                        dtype, 128, B_r, B_c, n_waves, True, True, True, 0, 0, 0, False, opt
+            for pipelined in (False, True):
+                for opt in (False, True):
+                    out.append(
+                        FlashForwardKernelConfig(
+                            dtype, 128, B_r, B_c, n_waves, True, True, True, 0, 0, 0, pipelined, opt
+                        )
                     )
-                )
     return out
 
 
@@ -435,5 +435,5 @@ def best_config(dtype=DType.BF16) -> FlashForwardKernelConfig:
     """Config bench.py uses for the headline number (updated from autotune runs;
     see profiles/ and DESIGN.md)."""
     return FlashForwardKernelConfig(
-        DType(dtype), 128, 256, 64, 8, True, True, True, 0, 0, 0, False, True
+        DType(dtype), 128, 256, 64, 8, True, True, True, 0, 0, 0, True, False
     )
