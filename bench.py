@@ -101,6 +101,18 @@ def cpu_baseline(dtype, batch, heads, seq, d, budget_s=12.0):
     }
 
 
+def measured_traffic(kernel_short_form, workload):
+    """HBM bytes per launch from the committed rocprofv3 PMC pass of this kernel on this
+    workload (profiles/traffic_c1.json, written by tools/gpu_pmc.sh); None if absent."""
+    path = os.path.join(ROOT, "profiles", f"traffic_{workload}.json")
+    try:
+        with open(path) as f:
+            rec = json.load(f)
+    except (OSError, ValueError):
+        return None
+    return rec.get("hbm_bytes_per_launch") if rec.get("kernel") == kernel_short_form else None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -224,7 +236,8 @@ def main():
                 "peak": peak,
                 "unit": "TFLOP/s",
                 "frac": achieved / peak,
-                "traffic": None,
+                "traffic": measured_traffic(cfg.short_form(), args.workload),
+                "algorithmic_bytes": 4 * (hi - lo) * seq * heads * d * 2,
                 "kernel_ms": kernel_ms,
                 "flop_per_launch": flop_per_step_rank,
             },

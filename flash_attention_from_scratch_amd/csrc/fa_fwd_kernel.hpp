@@ -146,6 +146,17 @@ static FA_DEV void glds16(const void *gsrc, unsigned lds_dst_wave_uniform) {
                  : "v"(gsrc), "s"(lds_dst_wave_uniform)
                  : "memory");
 }
+// Same with the address split as SGPR base (wave-uniform: tensor + head + tile offset,
+// computed on the scalar ALU) + 32-bit per-lane byte offset: no vector ALU work per piece.
+static FA_DEV void glds16_sv(const void *base_wave_uniform, unsigned lane_byte_off,
+                             unsigned lds_dst_wave_uniform) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(lane_byte_off), "s"(base_wave_uniform), "s"(lds_dst_wave_uniform)
+                 : "memory");
+}
 static FA_DEV void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 // workgroup barrier that the compiler may not move LDS traffic across and that does
 // not drain VMEM (in-flight DMA survives it)
@@ -271,32 +282,32 @@ fa_fwd_kernel(const KernelArgs args) {
     // index `it` is sequence block n_kv-1-it.
     const int n_kv = args.n_kv_blocks;
     const unsigned smem_base = __builtin_amdgcn_readfirstlane(lds_addr(smem));
-    // per-lane source pointers of this wave's DMA pieces for the tile at sequence block 0;
-    // a visit adds the wave-uniform tile offset (one 64-bit add per piece)
-    const uint16_t *k_src[DMA_PER_WAVE], *v_src[DMA_PER_WAVE];
+    // DMA addressing: SGPR base = head base + tile offset (scalar ALU), VGPR = 32-bit
+    // per-lane byte offset of this wave's piece inside a tile (invariant over tiles).
+    unsigned k_off[DMA_PER_WAVE], v_off[DMA_PER_WAVE];
 #pragma unroll
     for (int j = 0; j < DMA_PER_WAVE; ++j) {
         const int i = wave + NWAVES * j;  // piece index, wave-uniform; keys 4i .. 4i+3
-        k_src[j] = Kg + (int64_t)(4 * i) * ss + k_lane_off;
+        k_off[j] = (unsigned)(((int64_t)(4 * i) * ss + k_lane_off) * 2);
         const int sub = 2 * i + v_sub_in_piece;  // subtiles 2i, 2i+1
-        v_src[j] = Vg + (8 * (sub >> 2) + v_lane_row) * ss + (sub & 3) * 32 + v_lane_d;
+        v_off[j] = (unsigned)(((8 * (sub >> 2) + v_lane_row) * ss + (sub & 3) * 32 + v_lane_d) * 2);
     }
     const int64_t tile_stride = (int64_t)BC * ss;  // elements between consecutive KV blocks
     auto issue_k = [&](int it, int stage) {
-        const int64_t tile_off = (int64_t)(n_kv - 1 - it) * tile_stride;
+        const uint16_t *base = Kg + (int64_t)(n_kv - 1 - it) * tile_stride;
         const unsigned kdst = smem_base + stage * TILE;
         if (ABL & 16) return;
 #pragma unroll
         for (int j = 0; j < DMA_PER_WAVE; ++j)
-            glds16(k_src[j] + tile_off, kdst + (wave + NWAVES * j) * 1024);
+            glds16_sv(base, k_off[j], kdst + (wave + NWAVES * j) * 1024);
     };
     auto issue_v = [&](int it, int stage) {
-        const int64_t tile_off = (int64_t)(n_kv - 1 - it) * tile_stride;
+        const uint16_t *base = Vg + (int64_t)(n_kv - 1 - it) * tile_stride;
         const unsigned vdst = smem_base + V_BASE + stage * TILE;
         if (ABL & 16) return;
 #pragma unroll
         for (int j = 0; j < DMA_PER_WAVE; ++j)
-            glds16(v_src[j] + tile_off, vdst + (wave + NWAVES * j) * 1024);
+            glds16_sv(base, v_off[j], vdst + (wave + NWAVES * j) * 1024);
     };
     auto dma_wait = [&]() { if (!(ABL & 8)) dma_wait_all(); };
     auto barrier = [&]() { if (!(ABL & 8)) wg_barrier(); };

@@ -35,5 +35,16 @@ with open(out+"/pmc_summary.txt","w") as fo:
         for c,v in sorted(d.items()):
             fo.write(f"  {c:34s} mean {sum(v)/len(v):16.1f}  n={len(v)}\n")
 print(open(out+"/pmc_summary.txt").read())
+import json
+tr={}
+for k,d in agg.items():
+    if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
+        f=sum(d["FETCH_SIZE"])/len(d["FETCH_SIZE"]); w=sum(d["WRITE_SIZE"])/len(d["WRITE_SIZE"])
+        # rocprofv3 reports KiB; on gfx950 FETCH_SIZE counts 128-B requests as 64 B -> x2
+        # (MI355X_MICROARCH.md, HBM section); WRITE_SIZE used as reported.
+        tr[k]={"fetch_size_kib":f,"write_size_kib":w,"hbm_bytes_per_launch":(2*f+w)*1024,
+               "workload":"c1: bf16 batch=4 heads=16 seq_len=4096 d_head=128",
+               "algorithmic_bytes":268435456}
+json.dump(tr,open(out+"/pmc_traffic.json","w"),indent=1)
 PY
 for n in a b c d e f; do tail -2 $OUT/pmc_$n.log | cut -c1-200; done
