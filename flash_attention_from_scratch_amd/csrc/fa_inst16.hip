@@ -1,22 +1,19 @@
 // fa_inst16.hip -- variant table of the 16-rows-per-wave kernel (B_r = 64 with 4
-// waves: the reference's (64, *, 4) configs), -DFA_INST_DT=<5|15>.
+// waves: the reference's (64, *, 4) configs), -DFA_INST_DT=<5|15>.  List generated into
+// fa_variants.inc (tools/generate_kernel_instantiations.py).
 #include "fa_registry.hpp"
 #include "fa_fwd_kernel16.hpp"
 
 #ifndef FA_INST_DT
 #error "define FA_INST_DT (5 = fp16, 15 = bf16)"
 #endif
+#define FA_INST_ROWS16 1
 
 namespace fa {
 namespace {
-#define E(NW, BC, SWZ, EAGER, OPT) make_entry16<FA_INST_DT, NW, BC, SWZ, EAGER, OPT>()
 const KernelEntry kEntries[] = {
-    E(4, 64, true, true, false), E(4, 64, true, true, true),
-    E(4, 32, true, true, false), E(4, 32, true, true, true),
-    // the reference's progression steps at (64, 64, 4)
-    E(4, 64, false, false, false), E(4, 64, true, false, false),
+#include "fa_variants.inc"
 };
-#undef E
 }  // namespace
 
 #define FA_CAT2(a, b) a##b

@@ -1,0 +1,97 @@
+"""CPU tier: the pure-Python parts of the profiling / ISA tooling."""
+import os
+import textwrap
+
+from flash_attention_from_scratch_amd.tools import isa_stats, kernel_resources, rocprof_bench
+from flash_helpers import kernel_configs as kc
+
+SAMPLE_ASM = textwrap.dedent("""\
+    \t.text
+    _ZN2fa13fa_fwd_kernelILi15ELi1ELi8ELi64ELb1ELb1ELb0ELb1ELi0EEEvNS_10KernelArgsE: ; @k
+    \ts_load_dwordx2 s[0:1], s[4:5], 0x0
+    .LBB0_1:                                ; =>This Inner Loop Header: Depth=1
+    \ts_waitcnt lgkmcnt(7)
+    \tv_mfma_f32_32x32x16_bf16 v[0:15], v[16:19], v[20:23], v[0:15]
+    \tds_read_b128 v[24:27], v28
+    \tds_read_b64_tr_b16 v[30:31], v29
+    \tv_exp_f32_e32 v40, v41
+    \tv_fmamk_f32 v42, v43, 0x3e000000, v44
+    \ts_barrier
+    \ts_cbranch_scc1 .LBB0_1
+    \tglobal_store_dwordx2 v[50:51], v[52:53], off
+    \ts_endpgm
+    """)
+
+
+def test_isa_stats_histogram_and_trace():
+    ks = isa_stats.kernels(SAMPLE_ASM)
+    assert len(ks) == 1
+    (name, lines), = ks.items()
+    loop = isa_stats.hot_loop(lines)
+    ops = isa_stats.histogram(loop)
+    assert ops["v_mfma_f32_32x32x16_bf16"] == 1 and ops["ds_read_b128"] == 1 and "global_store_dwordx2" not in ops
+    cls = isa_stats.class_summary(ops)
+    assert cls["mfma"] == 1 and cls["lds"] == 2 and cls["trans"] == 1 and cls["barrier"] == 1
+    seq = "".join(isa_stats.classify(*isa_stats.opcode(l)) for l in loop if isa_stats.opcode(l)[0])
+    assert seq == "<L7>MdtEv|B|J"
+
+
+def test_symbol_and_mangled_name_round_trip_to_config():
+    cfg = rocprof_bench.symbol_to_config("void fa::fa_fwd_kernel<15, 1, 8, 64, true, true, false, true, 0>(fa::KernelArgs)")
+    assert cfg == kc.best_config(kc.DType.BF16)
+    cfg16 = rocprof_bench.symbol_to_config("void fa::fa_fwd_kernel16<5, 4, 32, true, true, true>(fa::KernelArgs)")
+    assert (cfg16.dtype, cfg16.B_r, cfg16.B_c, cfg16.n_warps, cfg16.optimized_softmax) == (kc.DType.FP16, 64, 32, 4, True)
+    assert rocprof_bench.symbol_to_config("void at::native::foo<float>()") is None
+    v = kernel_resources.demangle_variant("_ZN2fa13fa_fwd_kernelILi15ELi1ELi8ELi64ELb1ELb1ELb0ELb1ELi0EEEvNS_10KernelArgsE")
+    assert v == dict(dtype=15, rows_per_wave=32, n_waves=8, B_c=64, swizzled=1, eager=1, opt_softmax=0, pipelined=1)
+
+
+def test_resource_remark_parser():
+    text = "\n".join([
+        "./fa_fwd_kernel.hpp:150:1: remark: Function Name: _ZN2fa13fa_fwd_kernelILi15ELi1ELi8ELi64ELb1ELb1ELb0ELb1ELi0EEEvNS_10KernelArgsE [-Rpass-analysis=kernel-resource-usage]",
+        "./fa_fwd_kernel.hpp:150:1: remark:     VGPRs: 246 [-Rpass-analysis=kernel-resource-usage]",
+        "./fa_fwd_kernel.hpp:150:1: remark:     AGPRs: 0 [-Rpass-analysis=kernel-resource-usage]",
+        "./fa_fwd_kernel.hpp:150:1: remark:     ScratchSize [bytes/lane]: 0 [-Rpass-analysis=kernel-resource-usage]",
+        "./fa_fwd_kernel.hpp:150:1: remark:     Occupancy [waves/SIMD]: 2 [-Rpass-analysis=kernel-resource-usage]",
+        "./fa_fwd_kernel.hpp:150:1: remark:     VGPRs Spill: 0 [-Rpass-analysis=kernel-resource-usage]",
+    ])
+    (row,) = kernel_resources.parse_remarks(text)
+    assert row["vgprs"] == 246 and row["agprs"] == 0 and row["scratch_bytes"] == 0 and row["occupancy"] == 2
+    assert row["vgpr_spill"] == 0 and row["n_waves"] == 8
+
+
+def test_rocprof_csv_parsers(tmp_path):
+    sym = "void fa::fa_fwd_kernel<15, 1, 8, 64, true, true, false, true, 0>(fa::KernelArgs)"
+    trace = tmp_path / "p_kernel_trace.csv"
+    trace.write_text(
+        "Kind,Agent_Id,Kernel_Name,Start_Timestamp,End_Timestamp,VGPR_Count,Accum_VGPR_Count,LDS_Block_Size,Scratch_Size\n"
+        f'KERNEL_DISPATCH,1,"{sym}",1000,601000,248,0,65536,0\n'
+        f'KERNEL_DISPATCH,1,"{sym}",2000000,2500000,248,0,65536,0\n'
+        'KERNEL_DISPATCH,1,"void at::native::other()",1,2,8,0,0,0\n')
+    pmc = tmp_path / "p_counter_collection.csv"
+    pmc.write_text(
+        "Kernel_Name,Counter_Name,Counter_Value\n"
+        f'"{sym}",TCC_HIT_sum,90\n"{sym}",TCC_MISS_sum,10\n"{sym}",GRBM_GUI_ACTIVE,8000000\n')
+    t = rocprof_bench.parse_kernel_trace(str(trace))
+    c = rocprof_bench.parse_counters(str(pmc))
+    rows = rocprof_bench.table_rows(t, c, 4, 16, 4096, 128, skip_first=1)
+    assert len(rows) == 1
+    r = rows[0]
+    assert r["kernel"] == kc.best_config().short_form()
+    assert abs(r["dur_ms"] - 0.5) < 1e-9 and r["vgpr"] == 248 and r["lds"] == 65536
+    assert abs(r["l2_hit"] - 90.0) < 1e-9 and r["cycles"] == 1e6
+    assert abs(r["mfma_tflops"] - 549755813888 / 0.5e-3 / 1e12) < 1e-6
+
+
+def test_generated_variant_list_is_current_and_covers_every_config():
+    from flash_attention_from_scratch_amd.tools import generate_kernel_instantiations as gen
+    from flash_attention_from_scratch_amd import _capi
+
+    assert gen.main(["--check"]) == 0
+    built = set()
+    for info in _capi.kernels():
+        c = info.cfg
+        built.add((c.dtype, info.rows_per_wave, c.n_warps, c.B_c, bool(c.swizzled), bool(c.eager_load_blocks),
+                   bool(c.optimized_softmax), bool(c.mma_double_buffer_loads)))
+    wanted = {gen.variant_of(cfg) for cfg in kc.get_all_supported_configs()}
+    assert wanted == built
