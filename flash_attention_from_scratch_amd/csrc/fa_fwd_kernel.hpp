@@ -45,6 +45,9 @@
 //   SWZ     XOR-swizzled K image             (cfg.swizzled)
 //   EAGER   prefetch next tile, 2 LDS buffers (cfg.eager_load_blocks)
 //   OPT     first KV block skips the rescale  (cfg.optimized_softmax)
+//   DMA     K/V tiles by global->LDS DMA (cfg.async_copy = 1, the cp.async analogue) or,
+//           DMA = false, through registers: coalesced global_load_dwordx4 issued a visit
+//           ahead, written to LDS with ds_write_b128 after the barrier that frees the stage
 //   PIPE    software-pipelined loop: QK^T of tile j runs beside the O rescale, and
 //           P.V of tile j-1 beside the softmax of tile j, so one wave's stream
 //           always carries MFMA and VALU work together (cfg.mma_double_buffer_loads)
@@ -195,16 +198,19 @@ static FA_DEV unsigned lds_addr(const char *p) {
     return (unsigned)(unsigned long long)(FA_LDS(const char) *)p;
 }
 
-template <int DT, int QT, int NWAVES, int BC, bool SWZ, bool EAGER, bool OPT, bool PIPE>
+template <int DT, int QT, int NWAVES, int BC, bool SWZ, bool EAGER, bool OPT, bool PIPE, bool DMA = true>
 struct FwdTraits {
     static_assert(!PIPE || EAGER, "the pipelined loop needs both LDS stages");
+    static_assert(DMA || EAGER, "register-staged tiles are only built double-buffered");
     static constexpr int kRowsPerWave = 32 * QT;
     static constexpr int kBr = kRowsPerWave * NWAVES;
     static constexpr int kBc = BC;
     static constexpr int kThreads = NWAVES * 64;
     static constexpr int kTileBytes = BC * 256;                 // one K or V tile (d = 128)
     static constexpr int kStages = EAGER ? 2 : 1;
-    static constexpr int kLdsBytes = 2 * kStages * kTileBytes;  // K + V, all stages
+    static constexpr int kKvBytes = 2 * kStages * kTileBytes;   // K + V, all stages
+    static constexpr int kOutBytes = kBr * 256;                 // O tile staged for the epilogue
+    static constexpr int kLdsBytes = kKvBytes > kOutBytes ? kKvBytes : kOutBytes;
 };
 
 // ---------------------------------------------------------------------------------
@@ -213,13 +219,14 @@ struct FwdTraits {
 // ABL (tools/ablate.hip only; 0 in every shipped variant) removes one cost at a time to
 // attribute cycles: 1 no v_exp, 2 no softmax VALU at all, 4 no LDS operand reads,
 // 8 no barriers / DMA waits, 16 no DMA.  Results are wrong by construction when ABL != 0.
-template <int DT, int QT, int NWAVES, int BC, bool SWZ, bool EAGER, bool OPT, bool PIPE, int ABL = 0>
+template <int DT, int QT, int NWAVES, int BC, bool SWZ, bool EAGER, bool OPT, bool PIPE, bool DMA = true,
+          int ABL = 0>
 __global__ void
 __launch_bounds__(NWAVES * 64, (QT == 1) ? 2 : 1)
 fa_fwd_kernel(const KernelArgs args) {
     using E = Elem<DT>;
     using vec8 = typename E::vec8;
-    using TR = FwdTraits<DT, QT, NWAVES, BC, SWZ, EAGER, OPT, PIPE>;
+    using TR = FwdTraits<DT, QT, NWAVES, BC, SWZ, EAGER, OPT, PIPE, DMA>;
     constexpr int D = 128;
     constexpr int NT = BC / 32;              // 32-key tiles per LDS tile
     constexpr int KS = D / 16;               // k steps of the QK^T contraction
@@ -293,23 +300,63 @@ fa_fwd_kernel(const KernelArgs args) {
         v_off[j] = (unsigned)(((8 * (sub >> 2) + v_lane_row) * ss + (sub & 3) * 32 + v_lane_d) * 2);
     }
     const int64_t tile_stride = (int64_t)BC * ss;  // elements between consecutive KV blocks
+    f32x4 abl_dummy[2 * DMA_PER_WAVE];  // ABL & 32 only: landing registers of plain loads
     auto issue_k = [&](int it, int stage) {
         const uint16_t *base = Kg + (int64_t)(n_kv - 1 - it) * tile_stride;
         const unsigned kdst = smem_base + stage * TILE;
         if (ABL & 16) return;
 #pragma unroll
-        for (int j = 0; j < DMA_PER_WAVE; ++j)
-            glds16_sv(base, k_off[j], kdst + (wave + NWAVES * j) * 1024);
+        for (int j = 0; j < DMA_PER_WAVE; ++j) {
+            if (ABL & 32)
+                asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(abl_dummy[j]) : "v"(k_off[j]), "s"(base) : "memory");
+            else
+                glds16_sv(base, k_off[j], kdst + (wave + NWAVES * j) * 1024);
+        }
     };
     auto issue_v = [&](int it, int stage) {
         const uint16_t *base = Vg + (int64_t)(n_kv - 1 - it) * tile_stride;
         const unsigned vdst = smem_base + V_BASE + stage * TILE;
         if (ABL & 16) return;
 #pragma unroll
-        for (int j = 0; j < DMA_PER_WAVE; ++j)
-            glds16_sv(base, v_off[j], vdst + (wave + NWAVES * j) * 1024);
+        for (int j = 0; j < DMA_PER_WAVE; ++j) {
+            if (ABL & 32)
+                asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(abl_dummy[DMA_PER_WAVE + j]) : "v"(v_off[j]), "s"(base) : "memory");
+            else
+                glds16_sv(base, v_off[j], vdst + (wave + NWAVES * j) * 1024);
+        }
     };
-    auto dma_wait = [&]() { if (!(ABL & 8)) dma_wait_all(); };
+    // Register-staged transport (DMA == false).  Piece i = 4 tile rows; lane L moves the
+    // 16-B chunk (row 4i + L/16, chunk L%16): fully coalesced 256-B rows from global, and a
+    // per-lane LDS address builds the same K / V images the DMA path builds by permuting
+    // its source.  One set of landing registers per tile kind lives across a whole visit.
+    f32x4 kreg[DMA_PER_WAVE], vreg[DMA_PER_WAVE];
+    const int st_r = lane >> 4, st_c = lane & 15;
+    const unsigned st_goff = (unsigned)((((int64_t)(4 * wave + st_r)) * ss + st_c * 8) * 2);
+    const unsigned st_gstep = (unsigned)(((int64_t)(4 * NWAVES)) * ss * 2);  // bytes between a wave's pieces
+    const int st_krow = 4 * (wave & 3) + st_r;                               // (tile row) & 15
+    const unsigned st_kwr = wave * 1024 + st_r * 256 + ((st_c ^ (SWZ ? st_krow : 0)) << 4);
+    const unsigned st_vwr = (wave >> 1) * 2048 + ((wave & 1) * 4 + st_r) * 64 + (st_c >> 2) * 512 + (st_c & 3) * 16;
+    auto load_k = [&](int it) {
+        const char *base = (const char *)(Kg + (int64_t)(n_kv - 1 - it) * tile_stride) + st_goff;
+#pragma unroll
+        for (int j = 0; j < DMA_PER_WAVE; ++j) kreg[j] = *(const f32x4 *)(base + j * st_gstep);
+    };
+    auto load_v = [&](int it) {
+        const char *base = (const char *)(Vg + (int64_t)(n_kv - 1 - it) * tile_stride) + st_goff;
+#pragma unroll
+        for (int j = 0; j < DMA_PER_WAVE; ++j) vreg[j] = *(const f32x4 *)(base + j * st_gstep);
+    };
+    auto store_k = [&](int stage) {
+        char *dst = smem + stage * TILE + st_kwr;
+#pragma unroll
+        for (int j = 0; j < DMA_PER_WAVE; ++j) *(f32x4 *)(dst + j * NWAVES * 1024) = kreg[j];
+    };
+    auto store_v = [&](int stage) {
+        char *dst = smem + V_BASE + stage * TILE + st_vwr;
+#pragma unroll
+        for (int j = 0; j < DMA_PER_WAVE; ++j) *(f32x4 *)(dst + j * (NWAVES / 2) * 2048) = vreg[j];
+    };
+    auto dma_wait = [&]() { if (DMA && !(ABL & 8)) dma_wait_all(); };
     auto barrier = [&]() { if (!(ABL & 8)) wg_barrier(); };
     auto wait_and_barrier = [&]() {
         dma_wait();
@@ -321,9 +368,13 @@ fa_fwd_kernel(const KernelArgs args) {
         args.trace[(wave * 64 + 63) * 8 + 7] = __builtin_amdgcn_s_getreg((31 << 11) | 4);  // HW_REG_HW_ID
 #endif
     // ---- prologue: first tiles in flight, then Q -> VGPRs --------------------------
-    if (EAGER) {
+    if (EAGER && DMA) {
         issue_k(0, 0);
         issue_v(0, 0);
+    }
+    if (!DMA) {
+        load_k(0);
+        load_v(0);
     }
 
     vec8 Qr[QT][KS];
@@ -516,8 +567,17 @@ fa_fwd_kernel(const KernelArgs args) {
             FA_STAMP(it, 0);
             wait_and_barrier();
             FA_STAMP(it, 1);
-            if (it + 2 < n_kv) issue_k(it + 2, it & 1);
-            if (it + 1 < n_kv) issue_v(it + 1, (it + 1) & 1);
+            if (DMA) {
+                if (it + 2 < n_kv) issue_k(it + 2, it & 1);
+                if (it + 1 < n_kv) issue_v(it + 1, (it + 1) & 1);
+            } else {
+                // registers hold K(it+2), V(it+1) (loaded during the previous visit); their
+                // LDS stages were freed by the barrier above.  Then start K(it+3), V(it+2).
+                if (it + 2 < n_kv) store_k(it & 1);
+                if (it + 1 < n_kv) store_v((it + 1) & 1);
+                if (it + 3 < n_kv) load_k(it + 3);
+                if (it + 2 < n_kv) load_v(it + 2);
+            }
             // scale_l_O (softmax.cuh:36-49) with the new running max
             float neg_msc[QT], rowsum[QT];
             bool moved = false;
@@ -582,10 +642,24 @@ fa_fwd_kernel(const KernelArgs args) {
             }
             FA_STAMP(it, 3);
         };
-        wait_and_barrier();  // K(0), V(0) landed
-        if (n_kv > 1) issue_k(1, 1);
-        qk(0, Sa);
-        row_max(Sa);
+        if (DMA) {
+            wait_and_barrier();  // K(0), V(0) landed
+            if (n_kv > 1) issue_k(1, 1);
+            qk(0, Sa);
+            row_max(Sa);
+        } else {
+            // registers: K(0), V(0) -> LDS; then K(1), V(1) in flight; after S(0): K(1) -> LDS,
+            // K(2) in flight.  Invariant at the top of visit `it`: LDS holds K(it+1), V(it)
+            // (published by that visit's barrier), registers hold K(it+2), V(it+1).
+            store_k(0);
+            store_v(0);
+            if (n_kv > 1) { load_k(1); load_v(1); }
+            barrier();
+            qk(0, Sa);
+            row_max(Sa);
+            if (n_kv > 1) store_k(1);
+            if (n_kv > 2) load_k(2);
+        }
         int it = 0;
         for (; it + 2 < n_kv; it += 2) {
             visit(it, Sa, Sb, FalseTag{});
@@ -604,9 +678,15 @@ fa_fwd_kernel(const KernelArgs args) {
             FA_STAMP(it, 0);
             wait_and_barrier();  // tile `it` landed for every wave; stage^1 free again
             FA_STAMP(it, 1);
-            if (it + 1 < n_kv) {
-                issue_k(it + 1, stage ^ 1);
-                issue_v(it + 1, stage ^ 1);
+            if (DMA) {
+                if (it + 1 < n_kv) {
+                    issue_k(it + 1, stage ^ 1);
+                    issue_v(it + 1, stage ^ 1);
+                }
+            } else {
+                // registers hold tile it+1 (loaded during the previous visit)
+                if (it + 1 < n_kv) { store_k(stage ^ 1); store_v(stage ^ 1); }
+                if (it + 2 < n_kv) { load_k(it + 2); load_v(it + 2); }
             }
             f32x16 S[QT][NT];
             vec8 P[QT][NT][2];
@@ -619,6 +699,11 @@ fa_fwd_kernel(const KernelArgs args) {
             pv(stage, P);
             FA_STAMP(it, 4);
         };
+        if (!DMA) {
+            store_k(0);
+            store_v(0);
+            if (n_kv > 1) { load_k(1); load_v(1); }
+        }
         if (OPT) visit(0, TrueTag{}); else visit(0, FalseTag{});
         for (int it = 1; it < n_kv; ++it) visit(it, FalseTag{});
     } else {
@@ -641,26 +726,45 @@ fa_fwd_kernel(const KernelArgs args) {
         }
     }
 
+    if ((ABL & 32) && args.seq_len < 0) {  // never true: keeps the landing registers allocated
+#pragma unroll
+        for (int j = 0; j < 2 * DMA_PER_WAVE; ++j) *(f32x4 *)(Og + j * 8 + lane * 64) = abl_dummy[j];
+    }
     // ---- epilogue: finish l, normalise, RNE to 16 bit, store ----------------------
     // (final_softmax_normalization softmax.cuh:107-128; forward_kernel.cuh:186-203)
+    // Like the reference, O goes through shared memory so that global stores are whole
+    // 256-B rows (16 B per lane, 4 rows per wave-instruction) instead of 8-B pieces at a
+    // row stride.  Each wave stages only its own rows; the 16-B chunk index is XORed with
+    // (row & 15) so both the 8-B writes and the 16-B reads are bank-conflict free.
+    barrier();  // every wave is done with the K/V stages
+    {
+        char *stage_o = smem + wave * (TR::kRowsPerWave * 256);
 #pragma unroll
-    for (int qt = 0; qt < QT; ++qt) {
-        const float inv = 1.0f / pair_sum(l[qt]);
-        const int64_t row = (int64_t)qb * TR::kBr + wave * TR::kRowsPerWave + qt * 32 + r31;
-        uint16_t *op = Og + row * ss + hi * 4;
+        for (int qt = 0; qt < QT; ++qt) {
+            const float inv = 1.0f / pair_sum(l[qt]);
+            const int row = qt * 32 + r31;
+            char *wp = stage_o + row * 256 + hi * 8;
 #pragma unroll
-        for (int t = 0; t < DTILES; ++t) {
-            float o[16];
+            for (int t = 0; t < DTILES; ++t) {
+                float o[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) o[r] = O[qt][t][r] * inv;
-            const vec8 lo = E::pack8(o);      // regs 0..7 : d = 32t + {0..3} + 4hi, 32t + 8 + ...
-            const vec8 up = E::pack8(o + 8);  // regs 8..15: d = 32t + 16 + ..., 32t + 24 + ...
-            const s16x8 lo_s = __builtin_bit_cast(s16x8, lo);
-            const s16x8 up_s = __builtin_bit_cast(s16x8, up);
-            *(s16x4 *)(op + t * 32 + 0) = lo_s.lo;
-            *(s16x4 *)(op + t * 32 + 8) = lo_s.hi;
-            *(s16x4 *)(op + t * 32 + 16) = up_s.lo;
-            *(s16x4 *)(op + t * 32 + 24) = up_s.hi;
+                for (int r = 0; r < 16; ++r) o[r] = O[qt][t][r] * inv;
+                // regs 4rq..4rq+3 : d = 32t + 8rq + 4hi + 0..3  -> chunk 4t + rq, half hi
+                const s16x8 lo_s = __builtin_bit_cast(s16x8, E::pack8(o));
+                const s16x8 up_s = __builtin_bit_cast(s16x8, E::pack8(o + 8));
+                *(s16x4 *)(wp + (((4 * t + 0) ^ (row & 15)) << 4)) = lo_s.lo;
+                *(s16x4 *)(wp + (((4 * t + 1) ^ (row & 15)) << 4)) = lo_s.hi;
+                *(s16x4 *)(wp + (((4 * t + 2) ^ (row & 15)) << 4)) = up_s.lo;
+                *(s16x4 *)(wp + (((4 * t + 3) ^ (row & 15)) << 4)) = up_s.hi;
+            }
+        }
+        const int64_t row0 = (int64_t)qb * TR::kBr + wave * TR::kRowsPerWave;
+        const int rsub = lane >> 4, chunk = lane & 15;
+#pragma unroll
+        for (int i = 0; i < TR::kRowsPerWave / 4; ++i) {
+            const int row = 4 * i + rsub;
+            const s16x8 v = *(const s16x8 *)(stage_o + row * 256 + ((chunk ^ (row & 15)) << 4));
+            *(s16x8 *)(Og + (row0 + row) * ss + chunk * 8) = v;
         }
     }
 }

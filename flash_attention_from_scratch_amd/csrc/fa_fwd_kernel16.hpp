@@ -24,7 +24,9 @@ struct FwdTraits16 {
     static constexpr int kThreads = NWAVES * 64;
     static constexpr int kTileBytes = BC * 256;
     static constexpr int kStages = EAGER ? 2 : 1;
-    static constexpr int kLdsBytes = 2 * kStages * kTileBytes;
+    static constexpr int kKvBytes = 2 * kStages * kTileBytes;
+    static constexpr int kOutBytes = kBr * 256;
+    static constexpr int kLdsBytes = kKvBytes > kOutBytes ? kKvBytes : kOutBytes;
 };
 
 static FA_DEV float quad_max(float x) {
@@ -223,20 +225,32 @@ fa_fwd_kernel16(const KernelArgs args) {
         }
     }
 
-    const float inv = 1.0f / quad_sum(l);
-    const int64_t row = (int64_t)qb * TR::kBr + wave * 16 + r15;
-    uint16_t *op = Og + row * ss + g * 4;
+    // epilogue: O staged through LDS (each wave its own 16 rows), stored as whole rows
+    wg_barrier();
+    {
+        const float inv = 1.0f / quad_sum(l);
+        char *stage_o = smem + wave * (16 * 256);
+        char *wp = stage_o + r15 * 256 + (g & 1) * 8;
 #pragma unroll
-    for (int t = 0; t < DT16; t += 2) {
-        float o[8];
+        for (int t = 0; t < DT16; t += 2) {
+            float o[8];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            o[r] = O[t][r] * inv;
-            o[4 + r] = O[t + 1][r] * inv;
+            for (int r = 0; r < 4; ++r) {
+                o[r] = O[t][r] * inv;          // d = 16t + 4g + r      -> chunk 2t + (g>>1), half g&1
+                o[4 + r] = O[t + 1][r] * inv;  // d = 16(t+1) + 4g + r
+            }
+            const s16x8 packed = __builtin_bit_cast(s16x8, E::pack8(o));
+            *(s16x4 *)(wp + (((2 * t + (g >> 1)) ^ r15) << 4)) = packed.lo;
+            *(s16x4 *)(wp + (((2 * (t + 1) + (g >> 1)) ^ r15) << 4)) = packed.hi;
         }
-        const s16x8 packed = __builtin_bit_cast(s16x8, E::pack8(o));
-        *(s16x4 *)(op + t * 16) = packed.lo;
-        *(s16x4 *)(op + (t + 1) * 16) = packed.hi;
+        const int64_t row0 = (int64_t)qb * TR::kBr + wave * 16;
+        const int rsub = lane >> 4, chunk = lane & 15;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = 4 * i + rsub;
+            const s16x8 v = *(const s16x8 *)(stage_o + row * 256 + ((chunk ^ (row & 15)) << 4));
+            *(s16x8 *)(Og + (row0 + row) * ss + chunk * 8) = v;
+        }
     }
 }
 

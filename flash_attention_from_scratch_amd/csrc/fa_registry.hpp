@@ -20,18 +20,18 @@ struct KernelEntry {
     int eager;
     int opt_softmax;
     int pipelined;      // cfg.mma_double_buffer_loads
-    int async_copy;
+    int async_copy;     // 1: LDS-DMA transport, 0: register-staged
     int threads;
     int lds_bytes;
     kernel_fn fn;
 };
 
-template <int DT, int QT, int NWAVES, int BC, bool SWZ, bool EAGER, bool OPT, bool PIPE>
+template <int DT, int QT, int NWAVES, int BC, bool SWZ, bool EAGER, bool OPT, bool PIPE, bool DMA>
 constexpr KernelEntry make_entry() {
-    using TR = FwdTraits<DT, QT, NWAVES, BC, SWZ, EAGER, OPT, PIPE>;
-    return KernelEntry{DT, 32 * QT, NWAVES, BC, SWZ, EAGER, OPT, PIPE, 1, TR::kThreads,
+    using TR = FwdTraits<DT, QT, NWAVES, BC, SWZ, EAGER, OPT, PIPE, DMA>;
+    return KernelEntry{DT, 32 * QT, NWAVES, BC, SWZ, EAGER, OPT, PIPE, DMA, TR::kThreads,
                        TR::kLdsBytes,
-                       (kernel_fn)&fa_fwd_kernel<DT, QT, NWAVES, BC, SWZ, EAGER, OPT, PIPE>};
+                       (kernel_fn)&fa_fwd_kernel<DT, QT, NWAVES, BC, SWZ, EAGER, OPT, PIPE, DMA>};
 }
 
 struct KernelTable {

@@ -7,7 +7,8 @@ fields *select* on CDNA4 is documented in DESIGN.md ("config -> device variant")
 
 * ``B_r`` / ``B_c``      Q rows per workgroup / keys per LDS tile.
 * ``n_warps``            wave64 wavefronts per workgroup (64 lanes, not 32).
-* ``async_copy``         K/V tiles by direct global->LDS DMA (vs register staged).
+* ``async_copy``         K/V tiles by direct global->LDS DMA (the cp.async analogue, no
+  registers) vs ``False``: through registers (coalesced loads a visit ahead, ds_write later).
 * ``eager_load_blocks``  next K/V tile prefetched into the second LDS buffer.
 * ``swizzled``           XOR-swizzled K image (conflict-free ds_read_b128).
 * ``*_mma_load_K_tiles`` / ``mma_double_buffer_loads``  operand-fetch schedule
@@ -384,16 +385,21 @@ def get_native_kernel_configs(dtypes=(DType.BF16, DType.FP16)):
         (256, 32, 8),
         (256, 64, 4),
     ]
+    # async_copy: True = global->LDS DMA, False = through registers (32 rows/wave shapes)
+    reg_staged = {(128, 64, 4), (256, 64, 8), (128, 128, 4), (256, 128, 8)}
     out = []
     for dtype in dtypes:
         for B_r, B_c, n_waves in shapes:
-            for pipelined in (False, True):
-                for opt in (False, True):
-                    out.append(
-                        FlashForwardKernelConfig(
-                            dtype, 128, B_r, B_c, n_waves, True, True, True, 0, 0, 0, pipelined, opt
+            for dma in (True, False):
+                if not dma and (B_r, B_c, n_waves) not in reg_staged:
+                    continue
+                for pipelined in (False, True):
+                    for opt in (False, True):
+                        out.append(
+                            FlashForwardKernelConfig(
+                                dtype, 128, B_r, B_c, n_waves, dma, True, True, 0, 0, 0, pipelined, opt
+                            )
                         )
-                    )
     return out
 
 

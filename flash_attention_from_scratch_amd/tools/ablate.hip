@@ -10,13 +10,13 @@
 static uint16_t *q, *k, *v, *o;
 static const int B = 4, H = 16, D = 128, S = 4096;
 
-template <int NW, int BC, bool PIPE, int ABL>
+template <int NW, int BC, bool PIPE, int ABL, bool DMA = true>
 void run(const char *name) {
     fa::KernelArgs a;
     a.q = q; a.k = k; a.v = v; a.o = o;
     a.batch_stride = (int64_t)S * H * D; a.seq_stride = H * D; a.head_stride = D;
     a.seq_len = S; a.n_heads = H; a.n_bh = B * H; a.n_q_blocks = S / (32 * NW); a.n_kv_blocks = S / BC;
-    auto kern = fa::fa_fwd_kernel<15, 1, NW, BC, true, true, true, PIPE, ABL>;
+    auto kern = fa::fa_fwd_kernel<15, 1, NW, BC, true, true, true, PIPE, DMA, ABL>;
     const int lds = 4 * BC * 256;
     CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
@@ -29,7 +29,7 @@ void run(const char *name) {
         if (rep >= 2) { sum += ms; if (ms < best) best = ms; }
     }
     const double tf = 4.0 * B * H * (double)S * S * D / (sum / 10 * 1e-3) / 1e12;
-    printf("%-44s NW=%d BC=%3d pipe=%d abl=%2d : mean %.4f ms  min %.4f ms  %7.1f TF\n", name, NW, BC, PIPE, ABL, sum / 10, best, tf);
+    printf("%-44s NW=%d BC=%3d pipe=%d dma=%d abl=%2d : mean %.4f ms  min %.4f ms  %7.1f TF\n", name, NW, BC, PIPE, (int)DMA, ABL, sum / 10, best, tf);
 }
 
 int main() {
@@ -44,26 +44,18 @@ int main() {
         }
         CHECK(hipMemcpy(t == 0 ? q : t == 1 ? k : v, h.data(), n * 2, hipMemcpyHostToDevice));
     }
-    run<8, 64, false, 0>("plain");
-    run<8, 64, false, 1>("plain  no-exp");
-    run<8, 64, false, 2>("plain  no-softmax");
-    run<8, 64, false, 4>("plain  no-LDS-reads");
-    run<8, 64, false, 8>("plain  no-barrier");
-    run<8, 64, false, 16>("plain  no-DMA");
-    run<8, 64, false, 6>("plain  no-softmax no-LDS");
-    run<8, 64, false, 30>("plain  MFMA only (no sm, lds, bar, dma)");
-    run<8, 64, true, 0>("pipe");
-    run<8, 64, true, 2>("pipe no-softmax");
-    run<8, 64, true, 4>("pipe no-LDS-reads");
-    run<8, 64, true, 8>("pipe no-barrier");
-    run<8, 64, true, 6>("pipe no-softmax no-LDS");
-    run<8, 64, true, 30>("pipe MFMA only");
-    run<4, 64, false, 0>("plain NW4");
-    run<4, 64, true, 0>("pipe NW4");
-    run<4, 64, true, 30>("pipe NW4 MFMA only");
-    run<8, 128, false, 0>("plain BC128");
-    run<8, 128, false, 2>("plain BC128 no-softmax");
-    run<8, 128, false, 4>("plain BC128 no-LDS-reads");
-    run<8, 128, false, 30>("plain BC128 MFMA only");
+    run<4, 64, false, 0>("plain NW4 (warm-up)");
+    run<4, 64, false, 0>("plain NW4 dma");
+    run<4, 64, false, 0, false>("plain NW4 reg-staged");
+    run<8, 64, false, 0>("plain NW8 dma");
+    run<8, 64, false, 0, false>("plain NW8 reg-staged");
+    run<8, 128, false, 0>("plain NW8 BC128 dma");
+    run<8, 128, false, 0, false>("plain NW8 BC128 reg-staged");
+    run<4, 64, true, 0>("pipe NW4 dma");
+    run<4, 64, true, 0, false>("pipe NW4 reg-staged");
+    run<8, 64, true, 0>("pipe NW8 dma");
+    run<8, 64, true, 0, false>("pipe NW8 reg-staged");
+    run<8, 64, true, 8, false>("pipe NW8 reg-staged no-barrier");
+    run<8, 64, true, 4, false>("pipe NW8 reg-staged no-LDS-reads");
     return 0;
 }

@@ -41,7 +41,7 @@ PMC_GROUPS = [["GRBM_GUI_ACTIVE", "TCC_HIT_sum", "TCC_MISS_sum"]]
 
 
 def symbol_to_config(symbol):
-    """'void fa::fa_fwd_kernel<15, 1, 8, 64, true, true, false, true, 0>(fa::KernelArgs)' ->
+    """'void fa::fa_fwd_kernel<15, 1, 8, 64, true, true, false, true, true, 0>(fa::KernelArgs)' ->
     FlashForwardKernelConfig of that device variant (None for other kernels)."""
     m = re.search(r"fa::fa_fwd_kernel(16)?<([^>]*)>", symbol)
     if not m:
@@ -52,8 +52,10 @@ def symbol_to_config(symbol):
         dt, nw, bc, swz, eager, opt = vals[:6]
         rows, pipe = 16, 0
     else:
-        dt, qt, nw, bc, swz, eager, opt, pipe = vals[:8]
+        dt, qt, nw, bc, swz, eager, opt, pipe, dma = vals[:9]
         rows = 32 * qt
+        return FlashForwardKernelConfig(DType(dt), 128, rows * nw, bc, nw, bool(dma), bool(eager), bool(swz),
+                                        0, 0, 0, bool(pipe), bool(opt))
     return FlashForwardKernelConfig(DType(dt), 128, rows * nw, bc, nw, True, bool(eager), bool(swz),
                                     0, 0, 0, bool(pipe), bool(opt))
 

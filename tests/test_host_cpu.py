@@ -38,7 +38,8 @@ def test_every_enumerated_config_has_a_device_kernel():
         assert _capi.supported(cfg), cfg
         lds = _capi.lds_bytes(cfg)
         stages = 2 if cfg.eager_load_blocks else 1
-        assert lds == 2 * stages * cfg.B_c * 128 * 2
+        # K/V stages, or the O tile staged through LDS in the epilogue, whichever is larger
+        assert lds == max(2 * stages * cfg.B_c * 128 * 2, cfg.B_r * 128 * 2)
         assert lds <= 160 * 1024
 
 
