@@ -147,7 +147,7 @@ def main():
     dtype_name, batch, heads, seq, d = WORKLOADS[args.workload]
     dtype = {"bf16": torch.bfloat16, "fp16": torch.float16}[dtype_name]
     cfg = (kc.parse_kernel_name_into_config(args.kernel) if args.kernel
-           else kc.best_config(kc.DType.BF16 if dtype_name == "bf16" else kc.DType.FP16))
+           else kc.best_config(kc.DType.BF16 if dtype_name == "bf16" else kc.DType.FP16, seq))
 
     # this rank's shard of the global batch (weak scaling: `batch` per GPU)
     lo, hi = shard_for_rank(batch * world, world, rank)

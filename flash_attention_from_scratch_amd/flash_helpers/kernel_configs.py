@@ -437,9 +437,14 @@ def get_kernel_configs(kernels_key=""):
     raise ValueError(f"Invalid kernels env key: {kernels_key}")
 
 
-def best_config(dtype=DType.BF16) -> FlashForwardKernelConfig:
-    """Config bench.py uses for the headline number (updated from autotune runs;
-    see profiles/ and DESIGN.md)."""
+def best_config(dtype=DType.BF16, seq_len=4096) -> FlashForwardKernelConfig:
+    """Autotune winner on MI355X (profiles/): at seq_len >= 4096 the plain loop
+    with 8 waves x 32 rows and 128-key tiles (fewest barriers per key); below that the
+    pipelined 4-wave / 64-key kernel, whose smaller workgroups fill the chip better."""
+    if seq_len >= 4096:
+        return FlashForwardKernelConfig(
+            DType(dtype), 128, 256, 128, 8, True, True, True, 0, 0, 0, False, True
+        )
     return FlashForwardKernelConfig(
-        DType(dtype), 128, 256, 64, 8, True, True, True, 0, 0, 0, True, False
+        DType(dtype), 128, 128, 64, 4, True, True, True, 0, 0, 0, True, False
     )

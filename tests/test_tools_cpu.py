@@ -38,7 +38,7 @@ def test_isa_stats_histogram_and_trace():
 
 def test_symbol_and_mangled_name_round_trip_to_config():
     cfg = rocprof_bench.symbol_to_config("void fa::fa_fwd_kernel<15, 1, 8, 64, true, true, false, true, true, 0>(fa::KernelArgs)")
-    assert cfg == kc.best_config(kc.DType.BF16)
+    assert cfg == kc.FlashForwardKernelConfig(kc.DType.BF16, 128, 256, 64, 8, True, True, True, 0, 0, 0, True, False)
     cfg16 = rocprof_bench.symbol_to_config("void fa::fa_fwd_kernel16<5, 4, 32, true, true, true>(fa::KernelArgs)")
     assert (cfg16.dtype, cfg16.B_r, cfg16.B_c, cfg16.n_warps, cfg16.optimized_softmax) == (kc.DType.FP16, 64, 32, 4, True)
     assert rocprof_bench.symbol_to_config("void at::native::foo<float>()") is None
@@ -77,7 +77,7 @@ def test_rocprof_csv_parsers(tmp_path):
     rows = rocprof_bench.table_rows(t, c, 4, 16, 4096, 128, skip_first=1)
     assert len(rows) == 1
     r = rows[0]
-    assert r["kernel"] == kc.best_config().short_form()
+    assert r["kernel"] == "(BF16, 128, 256, 64, 8): async+eager+swizzled+load_0_0_0_tiles+buffer"
     assert abs(r["dur_ms"] - 0.5) < 1e-9 and r["vgpr"] == 248 and r["lds"] == 65536
     assert abs(r["l2_hit"] - 90.0) < 1e-9 and r["cycles"] == 1e6
     assert abs(r["mfma_tflops"] - 549755813888 / 0.5e-3 / 1e12) < 1e-6
