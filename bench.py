@@ -90,8 +90,18 @@ def cpu_baseline(dtype, batch, heads, seq, d, budget_s=12.0):
         t_total += time.perf_counter() - t0
         reps += 1
     sec = t_total / reps
+    # C0, the reference's own CPU-runnable plumbing case (BASELINE.json configs[0]): fp32 B=2 H=8 S=512
+    q0, k0, v0 = (torch.randn((2, 512, 8, 128), generator=gen) for _ in range(3))
+    c0 = []
+    for _ in range(23):
+        t0 = time.perf_counter()
+        fo.sdpa_cpu(q0, k0, v0)
+        c0.append(time.perf_counter() - t0)
+    c0 = sorted(c0[3:])
     return {
         "value": mfma_flop(batch, heads, seq, d) / sec / 1e12,
+        "c0_fp32_tflops_median": mfma_flop(2, 8, 512, 128) / c0[len(c0) // 2] / 1e12,
+        "c0_fp32_ms_median": c0[len(c0) // 2] * 1e3,
         "unit": "TFLOP/s",
         "cores": torch.get_num_threads(),
         "host_cpus": os.cpu_count(),
@@ -121,6 +131,9 @@ def main():
     ap.add_argument("--workload", default="c1", choices=sorted(WORKLOADS))
     ap.add_argument("--kernel", default="", help="short-form config; default = best_config(dtype)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl (= RCCL) for real multi-GPU runs; gloo lets a 1-GPU box exercise the "
+                         "N>1 code path with every rank on cuda:0 (timings then mean nothing)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -136,13 +149,19 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    if args.dist_backend == "gloo":
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    reduce_device = device if args.dist_backend == "nccl" else torch.device("cpu")
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)  # RCCL; used for barrier + max only
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)  # RCCL; barrier + max only
+        else:
+            dist.init_process_group("gloo")
 
     dtype_name, batch, heads, seq, d = WORKLOADS[args.workload]
     dtype = {"bf16": torch.bfloat16, "fp16": torch.float16}[dtype_name]
@@ -194,7 +213,7 @@ def main():
     sync()
     barrier()
     seconds = time.perf_counter() - t0
-    seconds = max_over_ranks(seconds, world, device)
+    seconds = max_over_ranks(seconds, world, reduce_device)
     kernel_ms = ev0.elapsed_time(ev1) / args.steps  # avg launch duration, this rank
 
     flop_per_step_rank = mfma_flop(hi - lo, heads, seq, d)
