@@ -23,6 +23,7 @@ CONFIG_FIELDS = (
 EXPORTED_SYMBOLS = (
     "fa_init", "fa_fwd_supported", "fa_fwd_lds_bytes", "fa_fwd_launch",
     "fa_fwd_launch_timed", "fa_num_kernels", "fa_get_kernel", "fa_last_error", "fa_version",
+    "fa_fwd_masked_supported", "fa_fwd_launch_masked",
 )
 
 
@@ -46,7 +47,7 @@ class FaKernelInfo(ctypes.Structure):
     _fields_ = [
         ("cfg", FaFwdConfig), ("threads", ctypes.c_int32), ("lds_bytes", ctypes.c_int32),
         ("num_regs", ctypes.c_int32), ("scratch_bytes", ctypes.c_int32),
-        ("rows_per_wave", ctypes.c_int32),
+        ("rows_per_wave", ctypes.c_int32), ("masked", ctypes.c_int32),
     ]
 
 
@@ -85,6 +86,10 @@ def load():
     lib.fa_fwd_launch.argtypes = [args_p, ctypes.c_void_p]
     lib.fa_fwd_launch_timed.restype = ctypes.c_int
     lib.fa_fwd_launch_timed.argtypes = [args_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_float)]
+    lib.fa_fwd_masked_supported.restype = ctypes.c_int
+    lib.fa_fwd_masked_supported.argtypes = [cfg_p]
+    lib.fa_fwd_launch_masked.restype = ctypes.c_int
+    lib.fa_fwd_launch_masked.argtypes = [args_p, ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_float)]
     lib.fa_num_kernels.restype = ctypes.c_int
     lib.fa_num_kernels.argtypes = []
     lib.fa_get_kernel.restype = ctypes.c_int
@@ -119,6 +124,11 @@ def make_config(kernel_cfg) -> FaFwdConfig:
 def supported(kernel_cfg) -> bool:
     cfg = make_config(kernel_cfg)
     return bool(load().fa_fwd_supported(ctypes.byref(cfg)))
+
+
+def masked_supported(kernel_cfg) -> bool:
+    cfg = make_config(kernel_cfg)
+    return bool(load().fa_fwd_masked_supported(ctypes.byref(cfg)))
 
 
 def lds_bytes(kernel_cfg) -> int:

@@ -58,7 +58,7 @@ bool valid_load_tiles(int v) { return v == 0 || v == 2 || v == 4 || v == 8; }
 // buffer) are validated with the reference's rules
 // (static_kernel_configuration.cuh:13-35) and then ignored: on CDNA4 the
 // compiler schedules LDS->MFMA operand reads and all hint values share one variant.
-const fa::KernelEntry *find_kernel(const fa_fwd_config *c, const char **why) {
+const fa::KernelEntry *find_kernel(const fa_fwd_config *c, const char **why, bool masked = false) {
     static const char *kNotFound = "Kernel configuration was not found in the libfa_hip.so registry";
     *why = kNotFound;
     if (c->d_head != 128) { *why = "Only d_head = 128 is supported"; return nullptr; }
@@ -76,7 +76,7 @@ const fa::KernelEntry *find_kernel(const fa_fwd_config *c, const char **why) {
         if (e.dtype == c->dtype && e.rows_per_wave == rows_per_wave && e.n_waves == c->n_warps &&
             e.B_c == c->B_c && e.swizzled == (c->swizzled != 0) &&
             e.eager == (c->eager_load_blocks != 0) && e.opt_softmax == (c->optimized_softmax != 0) &&
-            e.async_copy == (c->async_copy != 0)) {
+            e.async_copy == (c->async_copy != 0) && (e.masked != 0) == masked) {
             if (e.pipelined == (c->mma_double_buffer_loads != 0)) return &e;
             if (!e.pipelined) plain = &e;
         }
@@ -123,24 +123,26 @@ void do_init() {
     }
 }
 
-int validate(const fa_fwd_args *a, const fa::KernelEntry **out) {
+int validate(const fa_fwd_args *a, const fa::KernelEntry **out, bool masked = false) {
     if (!a || !a->q || !a->k || !a->v || !a->o) return fail(FA_ERR_NULL, "null pointer argument");
     if (a->cfg.dtype != FA_FP16 && a->cfg.dtype != FA_BF16)
         return fail(FA_ERR_DTYPE, "Only fp16 and bf16 are supported");
     const char *why = "";
-    const fa::KernelEntry *e = find_kernel(&a->cfg, &why);
-    if (!e) return fail(FA_ERR_NO_KERNEL, "%s", why);
+    const fa::KernelEntry *e = find_kernel(&a->cfg, &why, masked);
+    if (!e)
+        return fail(FA_ERR_NO_KERNEL, "%s%s", why,
+                    masked ? " (no causal / ragged-length variant is built for this configuration)" : "");
     if (a->d_head != a->cfg.d_head)
         return fail(FA_ERR_SHAPE, "Tensor d_head (%lld) does not match kernel configuration d_head (%d)",
                     (long long)a->d_head, a->cfg.d_head);
     if (a->batch <= 0 || a->seq_len <= 0 || a->n_heads <= 0)
         return fail(FA_ERR_SHAPE, "batch, seq_len and n_heads must be positive");
-    if (a->seq_len % a->cfg.B_r != 0)
+    if (!masked && a->seq_len % a->cfg.B_r != 0)
         return fail(FA_ERR_SHAPE, "Only multiples of B_r are supported for seq_len Q currently");
-    if (a->seq_len % a->cfg.B_c != 0)
+    if (!masked && a->seq_len % a->cfg.B_c != 0)
         return fail(FA_ERR_SHAPE, "Only multiples of B_c are supported for seq_len K currently");
-    if (a->seq_len > INT32_MAX || a->batch * a->n_heads > INT32_MAX ||
-        a->batch * a->n_heads * (a->seq_len / a->cfg.B_r) > INT32_MAX)
+    if (a->seq_len > INT32_MAX - 1024 || a->batch * a->n_heads > INT32_MAX ||
+        a->batch * a->n_heads * ((a->seq_len + a->cfg.B_r - 1) / a->cfg.B_r) > INT32_MAX)
         return fail(FA_ERR_SHAPE, "problem too large for a 1-D grid");
     // 16-byte vector accesses: element strides must be multiples of 8, pointers 16-B aligned.
     if ((a->batch_stride | a->seq_stride | a->head_stride) & 7)
@@ -151,7 +153,7 @@ int validate(const fa_fwd_args *a, const fa::KernelEntry **out) {
     return FA_OK;
 }
 
-int launch(const fa_fwd_args *a, const fa::KernelEntry *e, hipStream_t stream) {
+int launch(const fa_fwd_args *a, const fa::KernelEntry *e, hipStream_t stream, int causal = 0) {
     fa::KernelArgs ka;
     ka.q = a->q;
     ka.k = a->k;
@@ -163,8 +165,9 @@ int launch(const fa_fwd_args *a, const fa::KernelEntry *e, hipStream_t stream) {
     ka.seq_len = (int32_t)a->seq_len;
     ka.n_heads = (int32_t)a->n_heads;
     ka.n_bh = (int32_t)(a->batch * a->n_heads);
-    ka.n_q_blocks = (int32_t)(a->seq_len / a->cfg.B_r);
-    ka.n_kv_blocks = (int32_t)(a->seq_len / a->cfg.B_c);
+    ka.n_q_blocks = (int32_t)((a->seq_len + a->cfg.B_r - 1) / a->cfg.B_r);   // exact unless masked
+    ka.n_kv_blocks = (int32_t)((a->seq_len + a->cfg.B_c - 1) / a->cfg.B_c);
+    ka.causal = causal;
     // 1-D grid over (batch*head, Q block); the kernel un-maps it XCD-aware.
     // (reference: dim3(n_Q_blocks, n_heads, batch), flash_attention.cu:110-112)
     const dim3 grid((unsigned)(ka.n_bh * ka.n_q_blocks));
@@ -231,6 +234,36 @@ int fa_fwd_launch_timed(const fa_fwd_args *args, void *stream, float *ms) {
     return FA_OK;
 }
 
+int fa_fwd_masked_supported(const fa_fwd_config *cfg) {
+    if (!cfg) return 0;
+    const char *why;
+    return find_kernel(cfg, &why, true) != nullptr;
+}
+
+int fa_fwd_launch_masked(const fa_fwd_args *args, int causal, void *stream, float *ms) {
+    const fa::KernelEntry *e = nullptr;
+    int rc = validate(args, &e, true);
+    if (rc != FA_OK) return rc;
+    if ((rc = fa_init()) != FA_OK) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    if (!ms) return launch(args, e, s, causal != 0);
+    hipEvent_t start, stop;
+    if (hipEventCreate(&start) != hipSuccess || hipEventCreate(&stop) != hipSuccess)
+        return fail(FA_ERR_LAUNCH, "hipEventCreate failed");
+    (void)hipEventRecord(start, s);
+    rc = launch(args, e, s, causal != 0);
+    (void)hipEventRecord(stop, s);
+    hipError_t hrc = hipEventSynchronize(stop);
+    float elapsed = 0.0f;
+    if (hrc == hipSuccess) hrc = hipEventElapsedTime(&elapsed, start, stop);
+    (void)hipEventDestroy(start);
+    (void)hipEventDestroy(stop);
+    if (rc != FA_OK) return rc;
+    if (hrc != hipSuccess) return fail(FA_ERR_LAUNCH, "kernel execution: %s", hipGetErrorString(hrc));
+    *ms = elapsed;
+    return FA_OK;
+}
+
 int fa_num_kernels(void) { return (int)registry().size(); }
 
 int fa_get_kernel(int index, fa_kernel_info *out) {
@@ -251,6 +284,7 @@ int fa_get_kernel(int index, fa_kernel_info *out) {
     out->threads = e.threads;
     out->lds_bytes = e.lds_bytes;
     out->rows_per_wave = e.rows_per_wave;
+    out->masked = e.masked;
     out->num_regs = -1;
     out->scratch_bytes = -1;
     hipFuncAttributes attr;

@@ -48,6 +48,9 @@
 //   DMA     K/V tiles by global->LDS DMA (cfg.async_copy = 1, the cp.async analogue) or,
 //           DMA = false, through registers: coalesced global_load_dwordx4 issued a visit
 //           ahead, written to LDS with ds_write_b128 after the barrier that frees the stage
+//   MASK    scope widener beyond the reference: seq_len need not be a multiple
+//           of the tiles (keys >= seq_len masked, rows >= seq_len not stored) and an optional
+//           causal mask (KV tiles above the diagonal are never visited)
 //   PIPE    software-pipelined loop: QK^T of tile j runs beside the O rescale, and
 //           P.V of tile j-1 beside the softmax of tile j, so one wave's stream
 //           always carries MFMA and VALU work together (cfg.mma_double_buffer_loads)
@@ -71,6 +74,7 @@ struct KernelArgs {
     int32_t n_bh;          // batch * heads
     int32_t n_q_blocks;
     int32_t n_kv_blocks;
+    int32_t causal;        // MASK variants only: key j contributes to query i iff j <= i
 #ifdef FA_TRACE
     unsigned long long *trace;  // tools/segment_timer.hip only: [wave][visit][8] s_memtime stamps
     int32_t trace_block;
@@ -198,7 +202,8 @@ static FA_DEV unsigned lds_addr(const char *p) {
     return (unsigned)(unsigned long long)(FA_LDS(const char) *)p;
 }
 
-template <int DT, int QT, int NWAVES, int BC, bool SWZ, bool EAGER, bool OPT, bool PIPE, bool DMA = true>
+template <int DT, int QT, int NWAVES, int BC, bool SWZ, bool EAGER, bool OPT, bool PIPE, bool DMA = true,
+          bool MASK = false>
 struct FwdTraits {
     static_assert(!PIPE || EAGER, "the pipelined loop needs both LDS stages");
     static_assert(DMA || EAGER, "register-staged tiles are only built double-buffered");
@@ -220,13 +225,13 @@ struct FwdTraits {
 // attribute cycles: 1 no v_exp, 2 no softmax VALU at all, 4 no LDS operand reads,
 // 8 no barriers / DMA waits, 16 no DMA.  Results are wrong by construction when ABL != 0.
 template <int DT, int QT, int NWAVES, int BC, bool SWZ, bool EAGER, bool OPT, bool PIPE, bool DMA = true,
-          int ABL = 0>
+          bool MASK = false, int ABL = 0>
 __global__ void
 __launch_bounds__(NWAVES * 64, (QT == 1) ? 2 : 1)
 fa_fwd_kernel(const KernelArgs args) {
     using E = Elem<DT>;
     using vec8 = typename E::vec8;
-    using TR = FwdTraits<DT, QT, NWAVES, BC, SWZ, EAGER, OPT, PIPE, DMA>;
+    using TR = FwdTraits<DT, QT, NWAVES, BC, SWZ, EAGER, OPT, PIPE, DMA, MASK>;
     constexpr int D = 128;
     constexpr int NT = BC / 32;              // 32-key tiles per LDS tile
     constexpr int KS = D / 16;               // k steps of the QK^T contraction
@@ -264,6 +269,7 @@ fa_fwd_kernel(const KernelArgs args) {
             qb = bid % nq;
         }
     }
+    if (MASK && args.causal) qb = nq - 1 - qb;  // longest rows first
     const int b = bh / args.n_heads, h = bh % args.n_heads;
     const int64_t ss = args.seq_stride;
     const int64_t head_off = (int64_t)b * args.batch_stride + (int64_t)h * args.head_stride;
@@ -287,7 +293,16 @@ fa_fwd_kernel(const KernelArgs args) {
 
     // KV blocks are visited last-to-first (forward_kernel.cuh:142,175-184): visit
     // index `it` is sequence block n_kv-1-it.
-    const int n_kv = args.n_kv_blocks;
+    // KV tiles this workgroup visits: all of them, or up to its last row's diagonal
+    const int S_len = args.seq_len;
+    const int wg_row0 = qb * TR::kBr;
+    int n_kv_ = args.n_kv_blocks;
+    if (MASK && args.causal) {
+        const int last_row = (wg_row0 + TR::kBr < S_len ? wg_row0 + TR::kBr : S_len) - 1;
+        const int need = last_row / BC + 1;
+        n_kv_ = need < n_kv_ ? need : n_kv_;
+    }
+    const int n_kv = n_kv_;
     const unsigned smem_base = __builtin_amdgcn_readfirstlane(lds_addr(smem));
     // DMA addressing: SGPR base = head base + tile offset (scalar ALU), VGPR = 32-bit
     // per-lane byte offset of this wave's piece inside a tile (invariant over tiles).
@@ -301,10 +316,26 @@ fa_fwd_kernel(const KernelArgs args) {
     }
     const int64_t tile_stride = (int64_t)BC * ss;  // elements between consecutive KV blocks
     f32x4 abl_dummy[2 * DMA_PER_WAVE];  // ABL & 32 only: landing registers of plain loads
+    // MASK: rows of the last sequence block that lie beyond seq_len are fetched from the last
+    // valid row instead (their logits are masked, their P is exactly 0).
+    auto ragged_rows = [&](int it) -> int {  // valid rows of visit it's tile if it is ragged, else 0
+        const int kv0 = (n_kv - 1 - it) * BC;
+        return (MASK && kv0 + BC > S_len) ? S_len - kv0 : 0;
+    };
     auto issue_k = [&](int it, int stage) {
         const uint16_t *base = Kg + (int64_t)(n_kv - 1 - it) * tile_stride;
         const unsigned kdst = smem_base + stage * TILE;
         if (ABL & 16) return;
+        if (const int valid = ragged_rows(it)) {
+#pragma unroll
+            for (int j = 0; j < DMA_PER_WAVE; ++j) {
+                int row = 4 * (wave + NWAVES * j) + k_row_in_piece;
+                row = row < valid ? row : valid - 1;
+                const unsigned off = (unsigned)(((int64_t)row * ss + (((lane & 15) ^ k_swz) << 3)) * 2);
+                glds16_sv(base, off, kdst + (wave + NWAVES * j) * 1024);
+            }
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < DMA_PER_WAVE; ++j) {
             if (ABL & 32)
@@ -317,6 +348,17 @@ fa_fwd_kernel(const KernelArgs args) {
         const uint16_t *base = Vg + (int64_t)(n_kv - 1 - it) * tile_stride;
         const unsigned vdst = smem_base + V_BASE + stage * TILE;
         if (ABL & 16) return;
+        if (const int valid = ragged_rows(it)) {
+#pragma unroll
+            for (int j = 0; j < DMA_PER_WAVE; ++j) {
+                const int sub = 2 * (wave + NWAVES * j) + v_sub_in_piece;
+                int row = 8 * (sub >> 2) + (int)v_lane_row;
+                row = row < valid ? row : valid - 1;
+                const unsigned off = (unsigned)(((int64_t)row * ss + (sub & 3) * 32 + v_lane_d) * 2);
+                glds16_sv(base, off, vdst + (wave + NWAVES * j) * 1024);
+            }
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < DMA_PER_WAVE; ++j) {
             if (ABL & 32)
@@ -336,16 +378,22 @@ fa_fwd_kernel(const KernelArgs args) {
     const int st_krow = 4 * (wave & 3) + st_r;                               // (tile row) & 15
     const unsigned st_kwr = wave * 1024 + st_r * 256 + ((st_c ^ (SWZ ? st_krow : 0)) << 4);
     const unsigned st_vwr = (wave >> 1) * 2048 + ((wave & 1) * 4 + st_r) * 64 + (st_c >> 2) * 512 + (st_c & 3) * 16;
-    auto load_k = [&](int it) {
-        const char *base = (const char *)(Kg + (int64_t)(n_kv - 1 - it) * tile_stride) + st_goff;
+    auto load_tile = [&](const uint16_t *tensor, int it, f32x4 (&reg)[DMA_PER_WAVE]) {
+        const char *tile = (const char *)(tensor + (int64_t)(n_kv - 1 - it) * tile_stride);
+        if (const int valid = ragged_rows(it)) {
 #pragma unroll
-        for (int j = 0; j < DMA_PER_WAVE; ++j) kreg[j] = *(const f32x4 *)(base + j * st_gstep);
-    };
-    auto load_v = [&](int it) {
-        const char *base = (const char *)(Vg + (int64_t)(n_kv - 1 - it) * tile_stride) + st_goff;
+            for (int j = 0; j < DMA_PER_WAVE; ++j) {
+                int row = 4 * (wave + NWAVES * j) + st_r;
+                row = row < valid ? row : valid - 1;
+                reg[j] = *(const f32x4 *)(tile + ((int64_t)row * ss + st_c * 8) * 2);
+            }
+            return;
+        }
 #pragma unroll
-        for (int j = 0; j < DMA_PER_WAVE; ++j) vreg[j] = *(const f32x4 *)(base + j * st_gstep);
+        for (int j = 0; j < DMA_PER_WAVE; ++j) reg[j] = *(const f32x4 *)(tile + st_goff + j * st_gstep);
     };
+    auto load_k = [&](int it) { load_tile(Kg, it, kreg); };
+    auto load_v = [&](int it) { load_tile(Vg, it, vreg); };
     auto store_k = [&](int stage) {
         char *dst = smem + stage * TILE + st_kwr;
 #pragma unroll
@@ -380,7 +428,8 @@ fa_fwd_kernel(const KernelArgs args) {
     vec8 Qr[QT][KS];
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
-        const int64_t row = (int64_t)qb * TR::kBr + wave * TR::kRowsPerWave + qt * 32 + r31;
+        int64_t row = (int64_t)qb * TR::kBr + wave * TR::kRowsPerWave + qt * 32 + r31;
+        if (MASK && row >= S_len) row = S_len - 1;  // rows past the end are computed, never stored
         const uint16_t *qp = Qg + row * ss + hi * 8;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) Qr[qt][ks] = *(const vec8 *)(qp + ks * 16);
@@ -408,6 +457,30 @@ fa_fwd_kernel(const KernelArgs args) {
     //   V^T A-operand (transpose read): see header comment
     const int li = lane & 15, lg = lane >> 4;
     const int va_base = (4 * (lg >> 1) + (li >> 2)) * 64 + (lg & 1) * 32 + (li & 3) * 8;
+
+    // ---- MASK: logits of keys >= seq_len, or above the causal diagonal, become -inf ---------
+    const int wave_row0 = wg_row0 + wave * TR::kRowsPerWave;
+    auto tile_needs_mask = [&](int it) -> bool {  // wave-uniform
+        const int kv0 = (n_kv - 1 - it) * BC;
+        return MASK && (kv0 + BC > S_len || (args.causal && kv0 + BC - 1 > wave_row0));
+    };
+    auto mask_S = [&](f32x16 (&S)[QT][NT], int it) {
+        const int kv0 = (n_kv - 1 - it) * BC;
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+            const int q_row = wave_row0 + qt * 32 + r31;
+            const int limit = args.causal ? (q_row < S_len - 1 ? q_row : S_len - 1) : S_len - 1;  // last live key
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kv0 + 32 * nt + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    S[qt][nt][r] = key > limit ? -__builtin_inff() : S[qt][nt][r];
+                }
+        }
+    };
+    // a row whose keys were all masked so far has m = -inf: exponentiate against 0 instead
+    auto finite_or_zero = [&](float mval) { return (MASK && mval == -__builtin_inff()) ? 0.0f : mval; };
 
     // ---- S^T = K Q^T ------------------------------------------------------------
     auto qk = [&](int stage, f32x16 (&S)[QT][NT]) {
@@ -469,11 +542,11 @@ fa_fwd_kernel(const KernelArgs args) {
                 alpha[qt] = 1.0f;
             } else {
                 m_new = fmaxf(m[qt], mx);
-                alpha[qt] = __builtin_amdgcn_exp2f((m[qt] - m_new) * c);
+                alpha[qt] = __builtin_amdgcn_exp2f((m[qt] - finite_or_zero(m_new)) * c);
                 l[qt] *= alpha[qt];
             }
             m[qt] = m_new;
-            const float neg_msc = -(m_new * c);
+            const float neg_msc = -(finite_or_zero(m_new) * c);
             float rowsum = 0.0f;
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
@@ -584,10 +657,10 @@ fa_fwd_kernel(const KernelArgs args) {
 #pragma unroll
             for (int qt = 0; qt < QT; ++qt) {
                 const float m_new = fmaxf(m[qt], mx[qt]);
-                const float alpha = __builtin_amdgcn_exp2f((m[qt] - m_new) * c);
+                const float alpha = __builtin_amdgcn_exp2f((m[qt] - finite_or_zero(m_new)) * c);
                 l[qt] *= alpha;
                 m[qt] = m_new;
-                neg_msc[qt] = -(m_new * c);
+                neg_msc[qt] = -(finite_or_zero(m_new) * c);
                 rowsum[qt] = 0.0f;
                 if (!(OPT && it == 0) && !__all(alpha == 1.0f)) {
                     moved = true;
@@ -600,7 +673,10 @@ fa_fwd_kernel(const KernelArgs args) {
             (void)moved;
             FA_STAMP(it, 2);
             // ---- matrix stream 1: S_nxt = K(it+1) Q^T ---------------------------------
-            if (!LAST) qk((it + 1) & 1, S_nxt);
+            if (!LAST) {
+                qk((it + 1) & 1, S_nxt);
+                if (MASK && tile_needs_mask(it + 1)) mask_S(S_nxt, it + 1);
+            }
             // ---- vector stream: P = exp2(S_cur c - m c) (softmax.cuh:51-83) -------------
             vec8 P[QT][NT][2];
 #pragma unroll
@@ -646,6 +722,7 @@ fa_fwd_kernel(const KernelArgs args) {
             wait_and_barrier();  // K(0), V(0) landed
             if (n_kv > 1) issue_k(1, 1);
             qk(0, Sa);
+            if (MASK && tile_needs_mask(0)) mask_S(Sa, 0);
             row_max(Sa);
         } else {
             // registers: K(0), V(0) -> LDS; then K(1), V(1) in flight; after S(0): K(1) -> LDS,
@@ -656,6 +733,7 @@ fa_fwd_kernel(const KernelArgs args) {
             if (n_kv > 1) { load_k(1); load_v(1); }
             barrier();
             qk(0, Sa);
+            if (MASK && tile_needs_mask(0)) mask_S(Sa, 0);
             row_max(Sa);
             if (n_kv > 1) store_k(1);
             if (n_kv > 2) load_k(2);
@@ -692,6 +770,7 @@ fa_fwd_kernel(const KernelArgs args) {
             vec8 P[QT][NT][2];
             float alpha[QT];
             qk(stage, S);
+            if (MASK && tile_needs_mask(it)) mask_S(S, it);
             FA_STAMP(it, 2);
             softmax(S, P, alpha, first_tag);
             if (!decltype(first_tag)::value) rescale_O(alpha);
@@ -716,6 +795,7 @@ fa_fwd_kernel(const KernelArgs args) {
             vec8 P[QT][NT][2];
             float alpha[QT];
             qk(0, S);
+            if (MASK && tile_needs_mask(it)) mask_S(S, it);
             if (OPT && it == 0) {
                 softmax(S, P, alpha, TrueTag{});
             } else {
@@ -764,7 +844,7 @@ fa_fwd_kernel(const KernelArgs args) {
         for (int i = 0; i < TR::kRowsPerWave / 4; ++i) {
             const int row = 4 * i + rsub;
             const s16x8 v = *(const s16x8 *)(stage_o + row * 256 + ((chunk ^ (row & 15)) << 4));
-            *(s16x8 *)(Og + (row0 + row) * ss + chunk * 8) = v;
+            if (!MASK || row0 + row < S_len) *(s16x8 *)(Og + (row0 + row) * ss + chunk * 8) = v;
         }
     }
 }

@@ -21,17 +21,19 @@ struct KernelEntry {
     int opt_softmax;
     int pipelined;      // cfg.mma_double_buffer_loads
     int async_copy;     // 1: LDS-DMA transport, 0: register-staged
+    int masked;         // 1: handles ragged seq_len and the causal mask
     int threads;
     int lds_bytes;
     kernel_fn fn;
 };
 
-template <int DT, int QT, int NWAVES, int BC, bool SWZ, bool EAGER, bool OPT, bool PIPE, bool DMA>
+template <int DT, int QT, int NWAVES, int BC, bool SWZ, bool EAGER, bool OPT, bool PIPE, bool DMA,
+          bool MASK = false>
 constexpr KernelEntry make_entry() {
-    using TR = FwdTraits<DT, QT, NWAVES, BC, SWZ, EAGER, OPT, PIPE, DMA>;
-    return KernelEntry{DT, 32 * QT, NWAVES, BC, SWZ, EAGER, OPT, PIPE, DMA, TR::kThreads,
+    using TR = FwdTraits<DT, QT, NWAVES, BC, SWZ, EAGER, OPT, PIPE, DMA, MASK>;
+    return KernelEntry{DT, 32 * QT, NWAVES, BC, SWZ, EAGER, OPT, PIPE, DMA, MASK, TR::kThreads,
                        TR::kLdsBytes,
-                       (kernel_fn)&fa_fwd_kernel<DT, QT, NWAVES, BC, SWZ, EAGER, OPT, PIPE, DMA>};
+                       (kernel_fn)&fa_fwd_kernel<DT, QT, NWAVES, BC, SWZ, EAGER, OPT, PIPE, DMA, MASK>};
 }
 
 struct KernelTable {

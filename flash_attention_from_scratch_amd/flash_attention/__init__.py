@@ -15,3 +15,11 @@ def forward(kernel_cfg, q, k, v, o=None):
 def forward_timed(kernel_cfg, q, k, v, o=None):
     out, runtime_ms = flash_attention_kernels.forward(kernel_cfg, q, k, v, o, benchmark=True)
     return out, runtime_ms
+
+
+def forward_ex(kernel_cfg, q, k, v, o=None, causal=False, timed=False):
+    """Scope wideners beyond the reference API: optional causal mask, and any
+    seq_len (not only multiples of B_r / B_c).  Returns Tensor, or (Tensor, ms) if timed."""
+    out, ms = flash_attention_kernels.forward(kernel_cfg, q, k, v, o, benchmark=timed, causal=causal,
+                                              allow_ragged=True)
+    return (out, ms) if timed else out

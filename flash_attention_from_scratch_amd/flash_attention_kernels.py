@@ -26,7 +26,11 @@ def _check_input(t, name):
         raise RuntimeError(f"{name} must be contiguous")
 
 
-def forward(kernel_cfg, q, k, v, o=None, benchmark=False):
+def forward(kernel_cfg, q, k, v, o=None, benchmark=False, causal=False, allow_ragged=False):
+    """Reference signature plus two keyword-only-by-convention wideners (default off, so the
+    reference behaviour -- including its errors for seq_len not a multiple of the tiles -- is
+    unchanged): `causal` applies a causal mask, `allow_ragged` accepts any seq_len."""
+    masked = bool(causal or allow_ragged)
     _check_input(q, "q")
     _check_input(k, "k")
     _check_input(v, "v")
@@ -43,6 +47,8 @@ def forward(kernel_cfg, q, k, v, o=None, benchmark=False):
     lib = _capi.load()
     if not lib.fa_fwd_supported(ctypes.byref(cfg)):
         raise RuntimeError("Kernel configuration was not found in flash_kernels (libfa_hip.so registry)")
+    if masked and not lib.fa_fwd_masked_supported(ctypes.byref(cfg)):
+        raise RuntimeError("Kernel configuration has no causal / ragged-length variant in libfa_hip.so")
     cfg_dtype = kernel_cfg.dtype.to_torch_dtype() if hasattr(kernel_cfg.dtype, "to_torch_dtype") else None
     if cfg_dtype is None:
         cfg_dtype = {5: torch.float16, 15: torch.bfloat16}[int(kernel_cfg.dtype)]
@@ -54,9 +60,9 @@ def forward(kernel_cfg, q, k, v, o=None, benchmark=False):
     if q.shape != v.shape:
         raise RuntimeError("Query and value tensors have same shape")
     batch, seq_len, n_heads, d_head = q.shape
-    if seq_len % cfg.B_r != 0:
+    if not masked and seq_len % cfg.B_r != 0:
         raise RuntimeError("Only multiples of B_r are supported for seq_len Q currently")
-    if seq_len % cfg.B_c != 0:
+    if not masked and seq_len % cfg.B_c != 0:
         raise RuntimeError("Only multiples of B_c are supported for seq_len K currently")
 
     if o is not None:
@@ -76,6 +82,11 @@ def forward(kernel_cfg, q, k, v, o=None, benchmark=False):
     )
     with torch.cuda.device(q.device):
         stream = ctypes.c_void_p(torch.cuda.current_stream(q.device).cuda_stream)
+        if masked:
+            ms = ctypes.c_float(0.0)
+            _capi.check(lib.fa_fwd_launch_masked(ctypes.byref(args), int(bool(causal)), stream,
+                                                 ctypes.byref(ms) if benchmark else None))
+            return o, float(ms.value)
         if benchmark:
             ms = ctypes.c_float(0.0)
             _capi.check(lib.fa_fwd_launch_timed(ctypes.byref(args), stream, ctypes.byref(ms)))

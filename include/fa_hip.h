@@ -99,6 +99,7 @@ typedef struct fa_kernel_info {
     int32_t num_regs;        /* VGPR+AGPR per lane (hipFuncAttributes.numRegs) */
     int32_t scratch_bytes;   /* per-thread scratch; 0 = no spills */
     int32_t rows_per_wave;   /* Q rows owned by one wavefront */
+    int32_t masked;          /* 1: the causal / ragged-length variant of cfg */
 } fa_kernel_info;
 
 /* One-time setup for the current device (idempotent; also called lazily). */
@@ -115,6 +116,16 @@ int fa_fwd_launch(const fa_fwd_args *args, void *stream);
 
 /* Same, bracketed by hipEvents on `stream`; blocks; *ms = elapsed milliseconds. */
 int fa_fwd_launch_timed(const fa_fwd_args *args, void *stream, float *ms);
+
+/*
+ * Scope wideners beyond the reference (README.md:7-15 lists them as unsupported):
+ * an optional causal mask (key j contributes to query i iff j <= i; equal Q/K lengths) and
+ * seq_len that is NOT a multiple of B_r / B_c.  Same argument contract as fa_fwd_launch
+ * otherwise.  ms == NULL: asynchronous; ms != NULL: timed like fa_fwd_launch_timed.
+ * fa_fwd_masked_supported: 1 if a masked device variant exists for cfg.
+ */
+int fa_fwd_masked_supported(const fa_fwd_config *cfg);
+int fa_fwd_launch_masked(const fa_fwd_args *args, int causal, void *stream, float *ms);
 
 /* Registry enumeration: distinct device variants built into this library. */
 int fa_num_kernels(void);

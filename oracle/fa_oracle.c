@@ -110,9 +110,17 @@ typedef struct {
 static void q_block_forward(const tensors_t *t, int64_t b, int64_t h, int64_t qb, int B_r,
                             int B_c, int round_p, int optimized_softmax, const float *kf,
                             const float *vf, float *S, float *O, float *m, float *l,
-                            float *qrow, float *m_trace, float *l_trace) {
+                            float *qrow, float *m_trace, float *l_trace, int causal) {
     const int64_t d = t->d;
-    const int64_t n_kv = t->seq / B_c;
+    /* Scope wideners (not in the reference): seq need not be a multiple of the
+     * tiles, and an optional causal mask.  Masked logits are -inf; a row whose keys were all
+     * masked so far keeps m = -inf and exponentiates against 0 (as the device kernel does). */
+    const int64_t rows = (qb * B_r + B_r <= t->seq) ? B_r : t->seq - qb * B_r;
+    int64_t n_kv = (t->seq + B_c - 1) / B_c;
+    if (causal) {
+        const int64_t need = (qb * B_r + rows - 1) / B_c + 1;
+        if (need < n_kv) n_kv = need;
+    }
     /* forward_kernel.cuh:150-151: rsqrt(d) * M_LOG2E evaluated in fp32 */
     const float c = (float)((double)(1.0f / sqrtf((float)d)) * M_LOG2E);
     for (int r = 0; r < B_r; ++r) { m[r] = -INFINITY; l[r] = 0.0f; }
@@ -121,24 +129,27 @@ static void q_block_forward(const tensors_t *t, int64_t b, int64_t h, int64_t qb
     for (int64_t blk = n_kv - 1; blk >= 0; --blk) { /* forward_kernel.cuh:142,179-184 */
         const int is_first = (blk == n_kv - 1);
         /* S = Q K^T, fp32 accumulate (gemm.cuh:45-87, mma f32 accum) */
-        for (int r = 0; r < B_r; ++r) {
+        for (int r = 0; r < rows; ++r) {
             const int64_t qi = qb * B_r + r;
             const uint16_t *qp = t->q + b * t->bs + qi * t->ss + h * t->hs;
             for (int64_t x = 0; x < d; ++x) qrow[x] = b16_to_f32(qp[x], t->dtype);
             for (int cidx = 0; cidx < B_c; ++cidx) {
-                const float *kp = kf + (blk * B_c + cidx) * d;
+                const int64_t key = blk * B_c + cidx;
+                if (key >= t->seq || (causal && key > qi)) { S[r * B_c + cidx] = -INFINITY; continue; }
+                const float *kp = kf + key * d;
                 float acc = 0.0f;
                 for (int64_t x = 0; x < d; ++x) acc = fmaf(qrow[x], kp[x], acc);
                 S[r * B_c + cidx] = acc;
             }
         }
         /* local_softmax, softmax.cuh:85-105 */
-        for (int r = 0; r < B_r; ++r) {
+        for (int r = 0; r < rows; ++r) {
             float *s = S + r * B_c;
             const float m_prev = m[r];
             float mx = is_first ? s[0] : fmaxf(m_prev, s[0]);
             for (int cidx = 1; cidx < B_c; ++cidx) mx = fmaxf(mx, s[cidx]);
             m[r] = mx;
+            if (mx == -INFINITY) mx = 0.0f; /* all keys masked so far (widened modes only) */
             if (!(is_first && optimized_softmax)) {
                 /* scale_l_O: exp2f((m_prev - m_cur) * softmax_scale), softmax.cuh:42 */
                 const float scale = exp2f((m_prev - mx) * c);
@@ -156,17 +167,18 @@ static void q_block_forward(const tensors_t *t, int64_t b, int64_t h, int64_t qb
             l[r] = (is_first && optimized_softmax) ? rowsum : l[r] + rowsum;
         }
         /* O += P V, fp32 accumulate */
-        for (int r = 0; r < B_r; ++r) {
+        for (int r = 0; r < rows; ++r) {
             float *orow = O + r * d;
             for (int cidx = 0; cidx < B_c; ++cidx) {
                 const float p = S[r * B_c + cidx];
+                if (blk * B_c + cidx >= t->seq) continue; /* p == 0 there */
                 const float *vp = vf + (blk * B_c + cidx) * d;
                 for (int64_t x = 0; x < d; ++x) orow[x] = fmaf(p, vp[x], orow[x]);
             }
         }
     }
     /* final_softmax_normalization + convert + store, forward_kernel.cuh:186-203 */
-    for (int r = 0; r < B_r; ++r) {
+    for (int r = 0; r < rows; ++r) {
         const int64_t qi = qb * B_r + r;
         const float inv = 1.0f / l[r];
         uint16_t *op = t->o + b * t->bs + qi * t->ss + h * t->hs;
@@ -181,18 +193,19 @@ static void q_block_forward(const tensors_t *t, int64_t b, int64_t h, int64_t qb
  * -1 bad dtype, -2 seq not a multiple of B_r/B_c (flash_attention.cu:79-82),
  * -3 allocation failure.
  */
-int fa_oracle_forward_blockwise(const uint16_t *q, const uint16_t *k, const uint16_t *v,
-                                uint16_t *o, int dtype, int64_t batch, int64_t seq,
-                                int64_t heads, int64_t d_head, int64_t batch_stride,
-                                int64_t seq_stride, int64_t head_stride, int B_r, int B_c,
-                                int round_p, int optimized_softmax, float *m_trace,
-                                float *l_trace, int n_threads) {
+static int blockwise_impl(const uint16_t *q, const uint16_t *k, const uint16_t *v,
+                          uint16_t *o, int dtype, int64_t batch, int64_t seq,
+                          int64_t heads, int64_t d_head, int64_t batch_stride,
+                          int64_t seq_stride, int64_t head_stride, int B_r, int B_c,
+                          int round_p, int optimized_softmax, float *m_trace,
+                          float *l_trace, int n_threads, int masked, int causal) {
     if (dtype != FA_ORACLE_FP16 && dtype != FA_ORACLE_BF16) return -1;
-    if (B_r <= 0 || B_c <= 0 || seq % B_r != 0 || seq % B_c != 0) return -2;
+    if (B_r <= 0 || B_c <= 0 || seq <= 0) return -2;
+    if (!masked && (seq % B_r != 0 || seq % B_c != 0)) return -2;
     tensors_t t = {q, k, v, o, dtype, batch, seq, heads, d_head,
                    batch_stride, seq_stride, head_stride};
     const int64_t n_heads_total = batch * heads;
-    const int64_t n_q = seq / B_r;
+    const int64_t n_q = (seq + B_r - 1) / B_r;
     int failed = 0;
 #ifdef _OPENMP
     if (n_threads > 0) omp_set_num_threads(n_threads);
@@ -223,12 +236,34 @@ int fa_oracle_forward_blockwise(const uint16_t *q, const uint16_t *k, const uint
                 }
                 for (int64_t qb = 0; qb < n_q; ++qb)
                     q_block_forward(&t, b, h, qb, B_r, B_c, round_p, optimized_softmax, kf, vf,
-                                    S, O, ml, ml + B_r, ml + 2 * B_r, m_trace, l_trace);
+                                    S, O, ml, ml + B_r, ml + 2 * B_r, m_trace, l_trace, causal);
             }
         }
         free(kf); free(vf); free(S); free(O); free(ml);
     }
     return failed ? -3 : 0;
+}
+
+int fa_oracle_forward_blockwise(const uint16_t *q, const uint16_t *k, const uint16_t *v,
+                                uint16_t *o, int dtype, int64_t batch, int64_t seq,
+                                int64_t heads, int64_t d_head, int64_t batch_stride,
+                                int64_t seq_stride, int64_t head_stride, int B_r, int B_c,
+                                int round_p, int optimized_softmax, float *m_trace,
+                                float *l_trace, int n_threads) {
+    return blockwise_impl(q, k, v, o, dtype, batch, seq, heads, d_head, batch_stride, seq_stride,
+                          head_stride, B_r, B_c, round_p, optimized_softmax, m_trace, l_trace,
+                          n_threads, 0, 0);
+}
+
+/* Widened modes (causal mask, any seq): same arithmetic, see q_block_forward. */
+int fa_oracle_forward_blockwise_masked(const uint16_t *q, const uint16_t *k, const uint16_t *v,
+                                       uint16_t *o, int dtype, int64_t batch, int64_t seq,
+                                       int64_t heads, int64_t d_head, int64_t batch_stride,
+                                       int64_t seq_stride, int64_t head_stride, int B_r, int B_c,
+                                       int optimized_softmax, int causal, int n_threads) {
+    return blockwise_impl(q, k, v, o, dtype, batch, seq, heads, d_head, batch_stride, seq_stride,
+                          head_stride, B_r, B_c, 1, optimized_softmax, NULL, NULL, n_threads, 1,
+                          causal);
 }
 
 /*

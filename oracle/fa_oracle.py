@@ -58,6 +58,11 @@ def lib():
             ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
             ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
         ]
+        L.fa_oracle_forward_blockwise_masked.restype = ctypes.c_int
+        L.fa_oracle_forward_blockwise_masked.argtypes = [
+            u16p, u16p, u16p, u16p, ctypes.c_int, i64, i64, i64, i64, i64, i64, i64,
+            ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+        ]
         L.fa_oracle_forward_eager.restype = ctypes.c_int
         L.fa_oracle_forward_eager.argtypes = [
             u16p, u16p, u16p, u16p, ctypes.c_void_p, ctypes.c_int, i64, i64, i64, i64,
@@ -106,6 +111,36 @@ def blockwise_forward(q, k, v, B_r, B_c, round_p=True, optimized_softmax=False,
     if rc != 0:
         raise RuntimeError(f"fa_oracle_forward_blockwise failed: {rc}")
     return (o, m, l) if return_stats else o
+
+
+def blockwise_forward_masked(q, k, v, B_r, B_c, causal=False, optimized_softmax=False, n_threads=0):
+    """Widened modes (not in the reference): any seq_len, optional causal mask."""
+    _check(q, k, v)
+    B, S, H, D = q.shape
+    o = torch.empty_like(q)
+    rc = lib().fa_oracle_forward_blockwise_masked(
+        q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), _code(q.dtype),
+        B, S, H, D, q.stride(0), q.stride(1), q.stride(2), B_r, B_c,
+        int(optimized_softmax), int(causal), n_threads,
+    )
+    if rc != 0:
+        raise RuntimeError(f"fa_oracle_forward_blockwise_masked failed: {rc}")
+    return o
+
+
+def eager_attention_masked(q, k, v, causal=False, upcast=True):
+    """softmax(mask(q k^T / sqrt(d))) v in fp32 (or the input dtype): the eager statement of
+    the widened modes, same op order as eager_attention."""
+    dtype_in = q.dtype
+    if upcast:
+        q, k, v = q.float(), k.float(), v.float()
+    scores = torch.einsum("bqhd,bkhd->bqhk", q, k) / (q.shape[-1] ** 0.5)
+    if causal:
+        S = q.shape[1]
+        dead = torch.ones((S, S), dtype=torch.bool, device=q.device).triu(1)
+        scores = scores.masked_fill(dead[None, :, None, :], float("-inf"))
+    out = torch.einsum("bqhk,bkhd->bqhd", scores.softmax(dim=-1), v)
+    return out.to(dtype_in) if upcast else out
 
 
 def eager_forward_c(q, k, v, upcast=True, return_f32=False, n_threads=0):

@@ -237,3 +237,73 @@ def test_full_size_properties(name, dtype, B, H, S):
     other = replace(cfg, B_r=128, B_c=64, n_warps=4, optimized_softmax=False)
     oo = flash_attention.forward(other, q, k, v)
     assert (oo.float() - out.float()).abs().max().item() <= TOL[dtype]
+
+
+# ---- scope wideners beyond the reference: causal mask, ragged seq_len -----------
+MASKED = [c for c in VARIANTS if _capi.masked_supported(c)]
+
+
+def _rel_ok(out, ref, dtype):
+    ulp = 2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -10
+    return bool(((out.float() - ref.float()).abs() <= ulp + ulp * ref.float().abs()).all())
+
+
+@pytest.mark.parametrize("causal", [False, True], ids=["full", "causal"])
+@pytest.mark.parametrize("S", [1, 100, 257, 1000, 2048, 2500])
+def test_masked_variants_against_eager_sdpa_and_oracle(S, causal):
+    assert len(MASKED) >= 10
+    for dtype in (torch.bfloat16, torch.float16):
+        gen = torch.Generator(device=DEV).manual_seed(S + causal)
+        q, k, v = (torch.randn((2, S, 3, 128), dtype=dtype, device=DEV, generator=gen) for _ in range(3))
+        ref = fo.eager_attention_masked(q, k, v, causal)            # fp32 eager statement, on the GPU
+        sdpa = torch.nn.functional.scaled_dot_product_attention(
+            q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2), is_causal=causal).transpose(1, 2)
+        oracle = None
+        for cfg in MASKED:
+            if cfg.dtype.to_torch_dtype() != dtype:
+                continue
+            out = flash_attention.forward_ex(cfg, q, k, v, causal=causal)
+            assert torch.isfinite(out.float()).all(), (str(cfg), S, causal)
+            assert _rel_ok(out, ref, dtype), (str(cfg), S, causal, (out.float() - ref.float()).abs().max().item())
+            assert _rel_ok(out, sdpa, dtype) or (out.float() - sdpa.float()).abs().max().item() <= 2 * TOL[dtype]
+            if S <= 1000 and oracle is None:
+                oracle = fo.blockwise_forward_masked(q.cpu(), k.cpu(), v.cpu(), cfg.B_r, cfg.B_c, causal,
+                                                     optimized_softmax=cfg.optimized_softmax)
+                assert _rel_ok(out.cpu(), oracle, dtype)
+
+
+def test_masked_variant_equals_plain_kernel_when_nothing_is_masked():
+    """At a tile-multiple seq_len without causal mask the widened variant must reproduce the
+    reference-scope kernel bit for bit."""
+    for cfg in MASKED:
+        dtype = cfg.dtype.to_torch_dtype()
+        gen = torch.Generator(device=DEV).manual_seed(3)
+        q, k, v = (torch.randn((2, 1024, 4, 128), dtype=dtype, device=DEV, generator=gen) for _ in range(3))
+        assert torch.equal(flash_attention.forward_ex(cfg, q, k, v), flash_attention.forward(cfg, q, k, v)), str(cfg)
+
+
+def test_reference_errors_unchanged_without_the_wideners():
+    cfg = kc.best_config(kc.DType.BF16)
+    q = torch.zeros((1, 320, 2, 128), dtype=torch.bfloat16, device=DEV)
+    with pytest.raises(RuntimeError, match="multiples of B_r"):
+        flash_attention.forward(cfg, q, q, q)
+    assert flash_attention.forward_ex(cfg, q, q, q).shape == q.shape
+    no_mask = kc.FlashForwardKernelConfig(kc.DType.BF16, 128, 64, 32, 4, True, True, True, 2, 2, 0, False, False)
+    with pytest.raises(RuntimeError, match="no causal"):
+        flash_attention.forward_ex(no_mask, q, q, q, causal=True)
+
+
+def test_causal_full_size_timing_sanity():
+    """C1 shape, causal: about half the FLOPs -> clearly faster than the full mask."""
+    cfg = kc.best_config(kc.DType.BF16)
+    qc = ut.QKVConfig(n_heads=16, d_head=128, batch_size=4, seq_len=4096, dtype=torch.bfloat16,
+                      device=torch.device(DEV))
+    q, k, v = ut.generate_qkv(qc, seed=0)
+    for _ in range(3):
+        flash_attention.forward_ex(cfg, q, k, v, causal=True)
+    t_causal = min(flash_attention.forward_ex(cfg, q, k, v, causal=True, timed=True)[1] for _ in range(5))
+    t_full = min(flash_attention.forward_timed(cfg, q, k, v)[1] for _ in range(5))
+    assert t_causal < 0.75 * t_full, (t_causal, t_full)
+    ref = fo.eager_attention_masked(q[:1, :, :2].contiguous(), k[:1, :, :2].contiguous(), v[:1, :, :2].contiguous(), True)
+    out = flash_attention.forward_ex(cfg, q[:1, :, :2].contiguous(), k[:1, :, :2].contiguous(), v[:1, :, :2].contiguous(), causal=True)
+    assert _rel_ok(out, ref, torch.bfloat16)

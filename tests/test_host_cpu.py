@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layout_matches_header():
     assert ctypes.sizeof(_capi.FaFwdConfig) == 13 * 4
     assert ctypes.sizeof(_capi.FaFwdArgs) == 4 * 8 + 7 * 8 + 13 * 4 + 4  # tail padding to 8
-    assert ctypes.sizeof(_capi.FaKernelInfo) == 13 * 4 + 5 * 4
+    assert ctypes.sizeof(_capi.FaKernelInfo) == 13 * 4 + 6 * 4
 
 
 def test_every_enumerated_config_has_a_device_kernel():
