@@ -49,8 +49,8 @@ def test_registry_enumeration_is_consistent():
     seen = set()
     for info in infos:
         key = tuple(getattr(info.cfg, f) for f in _capi.CONFIG_FIELDS)
-        assert key not in seen
-        seen.add(key)
+        assert (key, info.masked) not in seen
+        seen.add((key, info.masked))
         assert info.threads == 64 * info.cfg.n_warps
         assert info.rows_per_wave * info.cfg.n_warps == info.cfg.B_r
         assert info.rows_per_wave in (16, 32, 64)

@@ -88,10 +88,12 @@ def test_generated_variant_list_is_current_and_covers_every_config():
     from flash_attention_from_scratch_amd import _capi
 
     assert gen.main(["--check"]) == 0
-    built = set()
+    built, masked = set(), set()
     for info in _capi.kernels():
         c = info.cfg
-        built.add((c.dtype, info.rows_per_wave, c.n_warps, c.B_c, bool(c.swizzled), bool(c.eager_load_blocks),
-                   bool(c.optimized_softmax), bool(c.mma_double_buffer_loads), bool(c.async_copy)))
+        key = (c.dtype, info.rows_per_wave, c.n_warps, c.B_c, bool(c.swizzled), bool(c.eager_load_blocks),
+               bool(c.optimized_softmax), bool(c.mma_double_buffer_loads), bool(c.async_copy))
+        (masked if info.masked else built).add(key)
     wanted = {gen.variant_of(cfg) for cfg in kc.get_all_supported_configs()}
     assert wanted == built
+    assert masked == {v for v in wanted if gen.has_masked_variant(v)} and masked
