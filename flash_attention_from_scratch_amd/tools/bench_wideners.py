@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Timing of the scope wideners (causal mask, ragged seq_len) next to the reference-scope
+kernel and torch SDPA on the same device.  FLOPs: full = 4BHS^2d; causal = half of that
+(the masked upper triangle is not computed: KV tiles above the diagonal are skipped)."""
+import torch
+
+import flash_attention
+from flash_helpers import kernel_configs as kc
+from flash_helpers.test import utils as ut
+
+
+def timed(fn, reps=20):
+    for _ in range(5):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def main():
+    print("shape (B,S,H) | mode | kernel ms | TFLOP/s (useful) | torch SDPA ms | TFLOP/s")
+    for dtype, name in ((torch.bfloat16, kc.DType.BF16),):
+        for B, S, H in ((4, 4096, 16), (4, 4000, 16), (2, 16384, 16), (16, 1000, 16)):
+            cfg = kc.best_config(name, S)
+            qc = ut.QKVConfig(n_heads=H, d_head=128, batch_size=B, seq_len=S, dtype=dtype, device=torch.device("cuda:0"))
+            q, k, v = ut.generate_qkv(qc, seed=0)
+            o = torch.empty_like(q)
+            qt, kt, vt = (t.transpose(1, 2) for t in (q, k, v))
+            for causal in (False, True):
+                flop = 4 * B * H * S * S * 128 * (0.5 if causal else 1.0)
+                ms = timed(lambda: flash_attention.forward_ex(cfg, q, k, v, o, causal=causal))
+                ms_ref = timed(lambda: torch.nn.functional.scaled_dot_product_attention(qt, kt, vt, is_causal=causal), reps=8)
+                print(f"({B},{S},{H}) | {'causal' if causal else 'full  '} | {ms:8.4f} | {flop / ms / 1e9:8.1f} | "
+                      f"{ms_ref:8.4f} | {flop / ms_ref / 1e9:8.1f}   [{cfg.short_form()}]")
+
+
+if __name__ == "__main__":
+    main()
