@@ -37,7 +37,7 @@
 //    same XCD (block id mod 8) and share that XCD's L2 copy of the head's K/V.
 //
 // Template parameters select the device variant behind the reference's 13-field
-// config (see fa_capi.cpp for the mapping):
+// config (fa_capi.hip maps config -> variant; tools/generate_kernel_instantiations.py lists them):
 //   DT      5 = fp16, 15 = bf16 (torch ScalarType codes)
 //   QT      32-row Q tiles per wave (rows per wave = 32*QT)
 //   NWAVES  wave64 wavefronts per workgroup  (B_r = 32*QT*NWAVES)
@@ -51,9 +51,11 @@
 //   MASK    scope widener beyond the reference: seq_len need not be a multiple
 //           of the tiles (keys >= seq_len masked, rows >= seq_len not stored) and an optional
 //           causal mask (KV tiles above the diagonal are never visited)
-//   PIPE    software-pipelined loop: QK^T of tile j runs beside the O rescale, and
-//           P.V of tile j-1 beside the softmax of tile j, so one wave's stream
-//           always carries MFMA and VALU work together (cfg.mma_double_buffer_loads)
+//   PIPE    software-pipelined loop with two S accumulators: while the matrix pipe forms
+//           S(i+1) = K(i+1) Q^T and then O += V(i) P(i), the vector ALU turns the finished
+//           S(i) into P(i); every MFMA has ~4-5 VALU ops and 1-2 LDS operand reads pinned
+//           beside it (cfg.mma_double_buffer_loads; 32 rows per wave, B_c <= 64)
+//   ABL     0 in every shipped variant; tools/ablate.hip removes one cost at a time
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -653,7 +655,6 @@ fa_fwd_kernel(const KernelArgs args) {
             }
             // scale_l_O (softmax.cuh:36-49) with the new running max
             float neg_msc[QT], rowsum[QT];
-            bool moved = false;
 #pragma unroll
             for (int qt = 0; qt < QT; ++qt) {
                 const float m_new = fmaxf(m[qt], mx[qt]);
@@ -663,14 +664,12 @@ fa_fwd_kernel(const KernelArgs args) {
                 neg_msc[qt] = -(finite_or_zero(m_new) * c);
                 rowsum[qt] = 0.0f;
                 if (!(OPT && it == 0) && !__all(alpha == 1.0f)) {
-                    moved = true;
 #pragma unroll
                     for (int t = 0; t < DTILES; ++t)
 #pragma unroll
                         for (int r = 0; r < 16; ++r) O[qt][t][r] *= alpha;
                 }
             }
-            (void)moved;
             FA_STAMP(it, 2);
             // ---- matrix stream 1: S_nxt = K(it+1) Q^T ---------------------------------
             if (!LAST) {

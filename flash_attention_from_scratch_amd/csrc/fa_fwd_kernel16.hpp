@@ -92,19 +92,23 @@ fa_fwd_kernel16(const KernelArgs args) {
     const int v_w = lane & 31;
 
     const unsigned smem_base = __builtin_amdgcn_readfirstlane(lds_addr(smem));
+    // SGPR base (head + tile, scalar ALU) + 32-bit per-lane byte offset, invariant over tiles
+    unsigned k_off[DMA_PER_WAVE], v_off[DMA_PER_WAVE];
+#pragma unroll
+    for (int j = 0; j < DMA_PER_WAVE; ++j) {
+        const int i = wave + NWAVES * j;
+        k_off[j] = (unsigned)(((int64_t)(4 * i) * ss + k_lane_off) * 2);
+        const int sub = 2 * i + (lane >> 5);
+        v_off[j] = (unsigned)((((int64_t)(16 * (sub >> 3) + (v_w >> 1))) * ss + (sub & 7) * 16 + (v_w & 1) * 8) * 2);
+    }
     auto issue_tile = [&](int kv_block, int stage) {
         const int64_t kv0 = (int64_t)kv_block * BC;
         const unsigned kdst = smem_base + stage * TILE;
         const unsigned vdst = smem_base + V_BASE + stage * TILE;
 #pragma unroll
         for (int j = 0; j < DMA_PER_WAVE; ++j) {
-            const int i = wave + NWAVES * j;
-            const uint16_t *ksrc = Kg + (kv0 + 4 * i) * ss + k_lane_off;
-            glds16(ksrc, kdst + i * 1024);
-            const int sub = 2 * i + (lane >> 5);
-            const uint16_t *vsrc = Vg + (kv0 + 16 * (sub >> 3) + (v_w >> 1)) * ss +
-                                   (sub & 7) * 16 + (v_w & 1) * 8;
-            glds16(vsrc, vdst + i * 1024);
+            glds16_sv(Kg + kv0 * ss, k_off[j], kdst + (wave + NWAVES * j) * 1024);
+            glds16_sv(Vg + kv0 * ss, v_off[j], vdst + (wave + NWAVES * j) * 1024);
         }
     };
 
@@ -140,16 +144,21 @@ fa_fwd_kernel16(const KernelArgs args) {
 
         f32x4 S[KT];
 #pragma unroll
-        for (int kt = 0; kt < KT; ++kt) {
+        for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) S[kt][r] = 0.0f;
+        // k step outer / key tile inner: consecutive MFMAs accumulate into different tiles;
+        // operand reads kept 8 ahead of the matrix pipe (see fa_fwd_kernel.hpp 3.2)
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
+        for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) {
                 const int off = kt * 16 * 256 + ka_base + (((4 * ks + g) ^ ka_swz) << 4);
                 const vec8 a = *(const vec8 *)(kt_ptr + off);
                 S[kt] = E::mfma16(a, Qr[ks], S[kt]);
             }
         }
+        sched_mfma_fed_from_lds<KT * KS, 1, 8>();
 
         float mx = S[0][0];
 #pragma unroll
@@ -164,10 +173,12 @@ fa_fwd_kernel16(const KernelArgs args) {
             m_new = fmaxf(m, mx);
             const float alpha = __builtin_amdgcn_exp2f((m - m_new) * c);
             l *= alpha;
+            if (!__all(alpha == 1.0f)) {  // multiplying by 1.0f is the identity: bit-exact skip
 #pragma unroll
-            for (int t = 0; t < DT16; ++t)
+                for (int t = 0; t < DT16; ++t)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) O[t][r] *= alpha;
+                    for (int r = 0; r < 4; ++r) O[t][r] *= alpha;
+            }
         }
         m = m_new;
         const float neg_msc = -(m_new * c);
@@ -186,9 +197,9 @@ fa_fwd_kernel16(const KernelArgs args) {
         l = (FIRST && OPT) ? rowsum : l + rowsum;
 
 #pragma unroll
-        for (int t = 0; t < DT16; ++t) {
+        for (int u = 0; u < KU; ++u) {
 #pragma unroll
-            for (int u = 0; u < KU; ++u) {
+            for (int t = 0; t < DT16; ++t) {
                 const char *vp = vt_ptr + va_base + u * 8192 + t * 512;
                 const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((FA_LDS(s16x4) *)(vp));
                 const s16x4 up = __builtin_amdgcn_ds_read_tr16_b64_v4i16((FA_LDS(s16x4) *)(vp + 4096));
@@ -198,6 +209,7 @@ fa_fwd_kernel16(const KernelArgs args) {
                 O[t] = E::mfma16(__builtin_bit_cast(vec8, av), Pb[u], O[t]);
             }
         }
+        sched_mfma_fed_from_lds<DT16 * KU, 2, 8>();
     };
 
     using TrueTag = BoolTag<true>;
