@@ -38,6 +38,47 @@ WORKLOADS = {
     "c3": ("fp16", 2, 32, 16384, 128),     # long context
     "c4": ("bf16", 8, 32, 8192, 128),      # the 8-GPU shard (64/8 per GPU)
 }
+# BASELINE.json configs[2]: bf16 sweep, batch per seq_len from the reference's table
+# (py/flash_helpers/test/utils.py:9-16), heads 16, harmonic mean of TFLOP/s
+C2_SWEEP = [(512, 16), (1024, 16), (2048, 16), (4096, 16), (8192, 8), (16384, 4)]
+
+
+def run_c2_sweep(args, device):
+    """--workload c2: one JSON line whose value is the harmonic mean over the sweep."""
+    import statistics
+
+    import flash_attention
+    from flash_helpers import kernel_configs as kc
+
+    per_s = {}
+    for seq, batch in C2_SWEEP:
+        cfg = kc.parse_kernel_name_into_config(args.kernel) if args.kernel else kc.best_config(kc.DType.BF16, seq)
+        gen = torch.Generator(device=device).manual_seed(seq)
+        q, k, v = (torch.randn((batch, seq, 16, 128), dtype=torch.bfloat16, device=device, generator=gen)
+                   for _ in range(3))
+        o = torch.empty_like(q)
+        for _ in range(args.warmup):
+            flash_attention.forward(cfg, q, k, v, o)
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            flash_attention.forward(cfg, q, k, v, o)
+        torch.cuda.synchronize(device)
+        sec = (time.perf_counter() - t0) / args.steps
+        per_s[seq] = {"tflops": mfma_flop(batch, 16, seq, 128) / sec / 1e12, "ms": sec * 1e3,
+                      "batch": batch, "kernel": cfg.short_form()}
+    value = statistics.harmonic_mean([r["tflops"] for r in per_s.values()])
+    print(json.dumps({
+        "metric": "bf16 TFLOPs, harmonic mean over seq_len {512..16384}, d_head=128", "value": value,
+        "unit": "TFLOP/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": sum(r["ms"] for r in per_s.values()), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": "c2: FA2 forward bf16 sweep S in {512,1024,2048,4096,8192,16384}, heads=16, "
+                               "batch {16,16,16,16,8,4}, a step = one pass over all six shapes"},
+        "per_seq_len": per_s,
+        "roofline": {"bound": "mfma", "achieved": value, "peak": PEAK_TFLOPS["bf16"], "unit": "TFLOP/s",
+                     "frac": value / PEAK_TFLOPS["bf16"], "traffic": None},
+    }), flush=True)
 
 
 def mfma_flop(batch, heads, seq, d):
@@ -128,7 +169,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", default="c1", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="c1", choices=sorted(WORKLOADS) + ["c2"])
     ap.add_argument("--kernel", default="", help="short-form config; default = best_config(dtype)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
@@ -163,6 +204,10 @@ def main():
         else:
             dist.init_process_group("gloo")
 
+    if args.workload == "c2":
+        if world != 1:
+            raise SystemExit("the c2 sweep is a single-GPU workload")
+        return run_c2_sweep(args, device)
     dtype_name, batch, heads, seq, d = WORKLOADS[args.workload]
     dtype = {"bf16": torch.bfloat16, "fp16": torch.float16}[dtype_name]
     cfg = (kc.parse_kernel_name_into_config(args.kernel) if args.kernel

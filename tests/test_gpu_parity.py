@@ -307,3 +307,26 @@ def test_causal_full_size_timing_sanity():
     ref = fo.eager_attention_masked(q[:1, :, :2].contiguous(), k[:1, :, :2].contiguous(), v[:1, :, :2].contiguous(), True)
     out = flash_attention.forward_ex(cfg, q[:1, :, :2].contiguous(), k[:1, :, :2].contiguous(), v[:1, :, :2].contiguous(), causal=True)
     assert _rel_ok(out, ref, torch.bfloat16)
+
+
+def test_extreme_logit_ranges_stay_finite_and_accurate():
+    """Edge inputs: huge logits (near one-hot softmax), tiny logits (uniform softmax), identical
+    keys (exact ties), and a constant shift of all logits of a row (softmax-invariant)."""
+    for dtype in (torch.bfloat16, torch.float16):
+        cfgs = [kc.best_config(kc.DType.BF16 if dtype == torch.bfloat16 else kc.DType.FP16, s) for s in (4096, 512)]
+        qc = ut.QKVConfig(n_heads=4, d_head=128, batch_size=2, seq_len=1024, dtype=dtype, device=torch.device(DEV))
+        q, k, v = ut.generate_qkv(qc, seed=21)
+        cases = {
+            "huge": (q * 6, k * 6, v),            # |logit| up to ~2000 before scaling
+            "tiny": (q * 1e-3, k * 1e-3, v),
+            "ties": (q, k[:, :1].expand_as(k).contiguous(), v),
+            "zeros": (torch.zeros_like(q), k, v),
+        }
+        for name, (qq, kk, vv) in cases.items():
+            ref = ut.py_flash_attention(qq, kk, vv, upcast=True)
+            for cfg in cfgs:
+                out = flash_attention.forward(cfg, qq, kk, vv)
+                assert torch.isfinite(out.float()).all(), (name, str(cfg))
+                err = (out.float() - ref.float()).abs()
+                tol = TOL[dtype] * (1 + ref.float().abs())
+                assert (err <= tol).all(), (name, str(cfg), err.max().item())
