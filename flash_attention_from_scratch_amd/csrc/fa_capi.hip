@@ -61,7 +61,7 @@ bool valid_load_tiles(int v) { return v == 0 || v == 2 || v == 4 || v == 8; }
 const fa::KernelEntry *find_kernel(const fa_fwd_config *c, const char **why, bool masked = false) {
     static const char *kNotFound = "Kernel configuration was not found in the libfa_hip.so registry";
     *why = kNotFound;
-    if (c->d_head != 128) { *why = "Only d_head = 128 is supported"; return nullptr; }
+    if (c->d_head != 128 && c->d_head != 64) { *why = "Only d_head = 128 (and 64) is supported"; return nullptr; }
     if (c->n_warps <= 0 || c->B_r <= 0 || c->B_r % c->n_warps != 0) return nullptr;
     if (!valid_load_tiles(c->Q_mma_load_K_tiles) || !valid_load_tiles(c->K_mma_load_K_tiles) ||
         !valid_load_tiles(c->V_mma_load_K_tiles))
@@ -73,7 +73,8 @@ const fa::KernelEntry *find_kernel(const fa_fwd_config *c, const char **why, boo
     // otherwise it is a hint like the load_K_tiles fields and the plain loop is used.
     const fa::KernelEntry *plain = nullptr;
     for (const auto &e : registry()) {
-        if (e.dtype == c->dtype && e.rows_per_wave == rows_per_wave && e.n_waves == c->n_warps &&
+        if (e.d_head == c->d_head && e.dtype == c->dtype && e.rows_per_wave == rows_per_wave &&
+            e.n_waves == c->n_warps &&
             e.B_c == c->B_c && e.swizzled == (c->swizzled != 0) &&
             e.eager == (c->eager_load_blocks != 0) && e.opt_softmax == (c->optimized_softmax != 0) &&
             e.async_copy == (c->async_copy != 0) && (e.masked != 0) == masked) {
@@ -272,7 +273,7 @@ int fa_get_kernel(int index, fa_kernel_info *out) {
     const fa::KernelEntry &e = registry()[index];
     memset(out, 0, sizeof(*out));
     out->cfg.dtype = e.dtype;
-    out->cfg.d_head = 128;
+    out->cfg.d_head = e.d_head;
     out->cfg.B_r = e.rows_per_wave * e.n_waves;
     out->cfg.B_c = e.B_c;
     out->cfg.n_warps = e.n_waves;

@@ -205,41 +205,49 @@ static FA_DEV unsigned lds_addr(const char *p) {
 }
 
 template <int DT, int QT, int NWAVES, int BC, bool SWZ, bool EAGER, bool OPT, bool PIPE, bool DMA = true,
-          bool MASK = false>
+          bool MASK = false, int D = 128>
 struct FwdTraits {
     static_assert(!PIPE || EAGER, "the pipelined loop needs both LDS stages");
     static_assert(DMA || EAGER, "register-staged tiles are only built double-buffered");
+    static_assert(D == 128 || D == 64, "d_head 128 (the reference's scope) or 64 (widener)");
+    static_assert(DMA || D == 128, "the register-staged transport is only built for d_head 128");
     static constexpr int kRowsPerWave = 32 * QT;
     static constexpr int kBr = kRowsPerWave * NWAVES;
     static constexpr int kBc = BC;
     static constexpr int kThreads = NWAVES * 64;
-    static constexpr int kTileBytes = BC * 256;                 // one K or V tile (d = 128)
+    static constexpr int kTileBytes = BC * 2 * D;               // one K or V tile
     static constexpr int kStages = EAGER ? 2 : 1;
     static constexpr int kKvBytes = 2 * kStages * kTileBytes;   // K + V, all stages
-    static constexpr int kOutBytes = kBr * 256;                 // O tile staged for the epilogue
+    static constexpr int kOutBytes = kBr * 2 * D;               // O tile staged for the epilogue
     static constexpr int kLdsBytes = kKvBytes > kOutBytes ? kKvBytes : kOutBytes;
 };
 
 // ---------------------------------------------------------------------------------
-// The kernel.  d_head is fixed at 128 (reference: README.md:7-15).
+// The kernel.  d_head = 128 is the reference's scope (README.md:7-15); D = 64 is a widener.
 // ---------------------------------------------------------------------------------
 // ABL (tools/ablate.hip only; 0 in every shipped variant) removes one cost at a time to
 // attribute cycles: 1 no v_exp, 2 no softmax VALU at all, 4 no LDS operand reads,
 // 8 no barriers / DMA waits, 16 no DMA.  Results are wrong by construction when ABL != 0.
 template <int DT, int QT, int NWAVES, int BC, bool SWZ, bool EAGER, bool OPT, bool PIPE, bool DMA = true,
-          bool MASK = false, int ABL = 0>
+          bool MASK = false, int D = 128, int ABL = 0>
 __global__ void
 __launch_bounds__(NWAVES * 64, (QT == 1) ? 2 : 1)
 fa_fwd_kernel(const KernelArgs args) {
     using E = Elem<DT>;
     using vec8 = typename E::vec8;
-    using TR = FwdTraits<DT, QT, NWAVES, BC, SWZ, EAGER, OPT, PIPE, DMA, MASK>;
-    constexpr int D = 128;
+    using TR = FwdTraits<DT, QT, NWAVES, BC, SWZ, EAGER, OPT, PIPE, DMA, MASK, D>;
+    constexpr int ROWB = 2 * D;              // bytes per K / V / O row (256, or 128 at d_head 64)
+    constexpr int CPR = D / 8;               // 16-B chunks per row (16 / 8)
+    constexpr int RPP = 64 / CPR;            // tile rows per 1-KiB DMA piece (4 / 8)
+    constexpr int DSUB = D / 32;             // 32-wide d subtiles per key group of the V image
+    // row -> XOR mask of the 16-B chunk index: 16 consecutive rows must land on 16 distinct
+    // 16-B slots of the 256-B LDS bank row (d_head 64: two rows share a bank row)
+    auto swz_of = [](int row) { return D == 128 ? (row & 15) : ((row >> 1) & 7); };
     constexpr int NT = BC / 32;              // 32-key tiles per LDS tile
     constexpr int KS = D / 16;               // k steps of the QK^T contraction
     constexpr int DTILES = D / 32;           // 32-wide d tiles of O^T
     constexpr int TILE = TR::kTileBytes;
-    constexpr int N_DMA = BC / 4;            // 1-KiB DMA pieces per K (or V) tile
+    constexpr int N_DMA = BC / RPP;          // 1-KiB DMA pieces per K (or V) tile
     static_assert(N_DMA % NWAVES == 0, "tile/wave split");
     constexpr int DMA_PER_WAVE = N_DMA / NWAVES;
 #ifdef FA_NO_SCHED
@@ -285,9 +293,10 @@ fa_fwd_kernel(const KernelArgs args) {
     //   K: chunk p -> key p>>4, 16-B chunk (p&15) ^ (key&15)
     //   V: chunk p -> subtile p>>5 = (key>>3)*4 + (d>>5); inside: key&7 = (p&31)>>2,
     //      d&31 = (p&3)*8
-    const int k_row_in_piece = lane >> 4;                                  // 0..3
-    const int k_swz = SWZ ? (((wave & 3) * 4 + k_row_in_piece) & 15) : 0;  // (key & 15)
-    const int64_t k_lane_off = (int64_t)k_row_in_piece * ss + (((lane & 15) ^ k_swz) << 3);
+    const int k_row_in_piece = lane / CPR;                                 // 0..RPP-1
+    // swizzle of tile row RPP*i + k_row_in_piece; i = wave + NWAVES*j and RPP*NWAVES % 16 == 0
+    const int k_swz = SWZ ? swz_of(RPP * wave + k_row_in_piece) : 0;
+    const int64_t k_lane_off = (int64_t)k_row_in_piece * ss + (((lane & (CPR - 1)) ^ k_swz) << 3);
     const int v_sub_in_piece = lane >> 5;                                  // 0..1
     const int v_w = lane & 31;
     const int64_t v_lane_row = (v_w >> 2);                                 // key & 7
@@ -312,9 +321,9 @@ fa_fwd_kernel(const KernelArgs args) {
 #pragma unroll
     for (int j = 0; j < DMA_PER_WAVE; ++j) {
         const int i = wave + NWAVES * j;  // piece index, wave-uniform; keys 4i .. 4i+3
-        k_off[j] = (unsigned)(((int64_t)(4 * i) * ss + k_lane_off) * 2);
+        k_off[j] = (unsigned)(((int64_t)(RPP * i) * ss + k_lane_off) * 2);
         const int sub = 2 * i + v_sub_in_piece;  // subtiles 2i, 2i+1
-        v_off[j] = (unsigned)(((8 * (sub >> 2) + v_lane_row) * ss + (sub & 3) * 32 + v_lane_d) * 2);
+        v_off[j] = (unsigned)(((8 * (sub / DSUB) + v_lane_row) * ss + (sub % DSUB) * 32 + v_lane_d) * 2);
     }
     const int64_t tile_stride = (int64_t)BC * ss;  // elements between consecutive KV blocks
     f32x4 abl_dummy[2 * DMA_PER_WAVE];  // ABL & 32 only: landing registers of plain loads
@@ -331,9 +340,9 @@ fa_fwd_kernel(const KernelArgs args) {
         if (const int valid = ragged_rows(it)) {
 #pragma unroll
             for (int j = 0; j < DMA_PER_WAVE; ++j) {
-                int row = 4 * (wave + NWAVES * j) + k_row_in_piece;
+                int row = RPP * (wave + NWAVES * j) + k_row_in_piece;
                 row = row < valid ? row : valid - 1;
-                const unsigned off = (unsigned)(((int64_t)row * ss + (((lane & 15) ^ k_swz) << 3)) * 2);
+                const unsigned off = (unsigned)(((int64_t)row * ss + (((lane & (CPR - 1)) ^ k_swz) << 3)) * 2);
                 glds16_sv(base, off, kdst + (wave + NWAVES * j) * 1024);
             }
             return;
@@ -354,9 +363,9 @@ fa_fwd_kernel(const KernelArgs args) {
 #pragma unroll
             for (int j = 0; j < DMA_PER_WAVE; ++j) {
                 const int sub = 2 * (wave + NWAVES * j) + v_sub_in_piece;
-                int row = 8 * (sub >> 2) + (int)v_lane_row;
+                int row = 8 * (sub / DSUB) + (int)v_lane_row;
                 row = row < valid ? row : valid - 1;
-                const unsigned off = (unsigned)(((int64_t)row * ss + (sub & 3) * 32 + v_lane_d) * 2);
+                const unsigned off = (unsigned)(((int64_t)row * ss + (sub % DSUB) * 32 + v_lane_d) * 2);
                 glds16_sv(base, off, vdst + (wave + NWAVES * j) * 1024);
             }
             return;
@@ -454,8 +463,8 @@ fa_fwd_kernel(const KernelArgs args) {
 
     // per-lane LDS read offsets
     //   K A-operand: row 32*nt + r31, chunk (2*ks + hi) ^ (r31 & 15)
-    const int ka_swz = SWZ ? (r31 & 15) : 0;
-    const int ka_base = r31 * 256;
+    const int ka_swz = SWZ ? swz_of(r31) : 0;
+    const int ka_base = r31 * ROWB;
     //   V^T A-operand (transpose read): see header comment
     const int li = lane & 15, lg = lane >> 4;
     const int va_base = (4 * (lg >> 1) + (li >> 2)) * 64 + (lg & 1) * 32 + (li & 3) * 8;
@@ -498,7 +507,7 @@ fa_fwd_kernel(const KernelArgs args) {
         for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                const int off = nt * 32 * 256 + ka_base + (((2 * ks + hi) ^ ka_swz) << 4);
+                const int off = nt * 32 * ROWB + ka_base + (((2 * ks + hi) ^ ka_swz) << 4);
                 const vec8 a = (ABL & 4) ? Qr[0][(ks + nt) % KS] : *(const vec8 *)(kt + off);
 #pragma unroll
                 for (int qt = 0; qt < QT; ++qt) S[qt][nt] = E::mfma(a, Qr[qt][ks], S[qt][nt]);
@@ -589,10 +598,10 @@ fa_fwd_kernel(const KernelArgs args) {
 #pragma unroll
                 for (int t = 0; t < DTILES; ++t) {
                     const int s16 = 2 * nt + half;
-                    const char *vp = vt + va_base + s16 * 4096 + t * 512;
+                    const char *vp = vt + va_base + s16 * (DSUB * 1024) + t * 512;
                     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((FA_LDS(s16x4) *)(vp));
                     const s16x4 up =
-                        __builtin_amdgcn_ds_read_tr16_b64_v4i16((FA_LDS(s16x4) *)(vp + 2048));
+                        __builtin_amdgcn_ds_read_tr16_b64_v4i16((FA_LDS(s16x4) *)(vp + DSUB * 512));
                     s16x8 av;
                     av.lo = lo;
                     av.hi = up;
@@ -817,12 +826,12 @@ fa_fwd_kernel(const KernelArgs args) {
     // (row & 15) so both the 8-B writes and the 16-B reads are bank-conflict free.
     barrier();  // every wave is done with the K/V stages
     {
-        char *stage_o = smem + wave * (TR::kRowsPerWave * 256);
+        char *stage_o = smem + wave * (TR::kRowsPerWave * ROWB);
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) {
             const float inv = 1.0f / pair_sum(l[qt]);
             const int row = qt * 32 + r31;
-            char *wp = stage_o + row * 256 + hi * 8;
+            char *wp = stage_o + row * ROWB + hi * 8;
 #pragma unroll
             for (int t = 0; t < DTILES; ++t) {
                 float o[16];
@@ -831,18 +840,18 @@ fa_fwd_kernel(const KernelArgs args) {
                 // regs 4rq..4rq+3 : d = 32t + 8rq + 4hi + 0..3  -> chunk 4t + rq, half hi
                 const s16x8 lo_s = __builtin_bit_cast(s16x8, E::pack8(o));
                 const s16x8 up_s = __builtin_bit_cast(s16x8, E::pack8(o + 8));
-                *(s16x4 *)(wp + (((4 * t + 0) ^ (row & 15)) << 4)) = lo_s.lo;
-                *(s16x4 *)(wp + (((4 * t + 1) ^ (row & 15)) << 4)) = lo_s.hi;
-                *(s16x4 *)(wp + (((4 * t + 2) ^ (row & 15)) << 4)) = up_s.lo;
-                *(s16x4 *)(wp + (((4 * t + 3) ^ (row & 15)) << 4)) = up_s.hi;
+                *(s16x4 *)(wp + (((4 * t + 0) ^ swz_of(row)) << 4)) = lo_s.lo;
+                *(s16x4 *)(wp + (((4 * t + 1) ^ swz_of(row)) << 4)) = lo_s.hi;
+                *(s16x4 *)(wp + (((4 * t + 2) ^ swz_of(row)) << 4)) = up_s.lo;
+                *(s16x4 *)(wp + (((4 * t + 3) ^ swz_of(row)) << 4)) = up_s.hi;
             }
         }
         const int64_t row0 = (int64_t)qb * TR::kBr + wave * TR::kRowsPerWave;
-        const int rsub = lane >> 4, chunk = lane & 15;
+        const int rsub = lane / CPR, chunk = lane & (CPR - 1);
 #pragma unroll
-        for (int i = 0; i < TR::kRowsPerWave / 4; ++i) {
-            const int row = 4 * i + rsub;
-            const s16x8 v = *(const s16x8 *)(stage_o + row * 256 + ((chunk ^ (row & 15)) << 4));
+        for (int i = 0; i < TR::kRowsPerWave / RPP; ++i) {
+            const int row = RPP * i + rsub;
+            const s16x8 v = *(const s16x8 *)(stage_o + row * ROWB + ((chunk ^ swz_of(row)) << 4));
             if (!MASK || row0 + row < S_len) *(s16x8 *)(Og + (row0 + row) * ss + chunk * 8) = v;
         }
     }

@@ -22,18 +22,19 @@ struct KernelEntry {
     int pipelined;      // cfg.mma_double_buffer_loads
     int async_copy;     // 1: LDS-DMA transport, 0: register-staged
     int masked;         // 1: handles ragged seq_len and the causal mask
+    int d_head;         // 128 (reference scope) or 64
     int threads;
     int lds_bytes;
     kernel_fn fn;
 };
 
 template <int DT, int QT, int NWAVES, int BC, bool SWZ, bool EAGER, bool OPT, bool PIPE, bool DMA,
-          bool MASK = false>
+          bool MASK = false, int D = 128>
 constexpr KernelEntry make_entry() {
-    using TR = FwdTraits<DT, QT, NWAVES, BC, SWZ, EAGER, OPT, PIPE, DMA, MASK>;
-    return KernelEntry{DT, 32 * QT, NWAVES, BC, SWZ, EAGER, OPT, PIPE, DMA, MASK, TR::kThreads,
+    using TR = FwdTraits<DT, QT, NWAVES, BC, SWZ, EAGER, OPT, PIPE, DMA, MASK, D>;
+    return KernelEntry{DT, 32 * QT, NWAVES, BC, SWZ, EAGER, OPT, PIPE, DMA, MASK, D, TR::kThreads,
                        TR::kLdsBytes,
-                       (kernel_fn)&fa_fwd_kernel<DT, QT, NWAVES, BC, SWZ, EAGER, OPT, PIPE, DMA, MASK>};
+                       (kernel_fn)&fa_fwd_kernel<DT, QT, NWAVES, BC, SWZ, EAGER, OPT, PIPE, DMA, MASK, D>};
 }
 
 struct KernelTable {

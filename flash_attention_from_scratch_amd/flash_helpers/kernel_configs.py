@@ -394,12 +394,31 @@ def get_native_kernel_configs(dtypes=(DType.BF16, DType.FP16)):
                 if not dma and (B_r, B_c, n_waves) not in reg_staged:
                     continue
                 for pipelined in (False, True):
+                    if pipelined and not dma and n_waves == 4:
+                        continue  # 4 landing registers per tile kind: the pipelined loop would spill
                     for opt in (False, True):
                         out.append(
                             FlashForwardKernelConfig(
                                 dtype, 128, B_r, B_c, n_waves, dma, True, True, 0, 0, 0, pipelined, opt
                             )
                         )
+    return out
+
+
+def get_d64_kernel_configs(dtypes=(DType.BF16, DType.FP16)):
+    """d_head = 64 (a scope widener; the reference's config comments allow [64, 128] but only
+    128 was ever built): the 32-rows-per-wave kernel at three tile shapes."""
+    out = []
+    for dtype in dtypes:
+        for B_r, B_c, n_waves, pipes in ((128, 64, 4, (False, True)), (256, 64, 8, (False, True)),
+                                         (256, 128, 8, (False,))):
+            for pipelined in pipes:
+                for opt in (False, True):
+                    out.append(
+                        FlashForwardKernelConfig(
+                            dtype, 64, B_r, B_c, n_waves, True, True, True, 0, 0, 0, pipelined, opt
+                        )
+                    )
     return out
 
 
@@ -412,6 +431,7 @@ def get_all_supported_configs():
     """Everything libfa_hip.so accepts that these helpers can enumerate."""
     cfgs = set(get_autotuning_kernel_configs())
     cfgs.update(get_native_kernel_configs())
+    cfgs.update(get_d64_kernel_configs())
     cfgs.update(get_kernel_progression_configs())
     return sorted(cfgs)
 
@@ -428,6 +448,8 @@ def get_kernel_configs(kernels_key=""):
         return get_autotuning_kernel_configs()
     if kernels_key == "native":
         return get_native_kernel_configs()
+    if kernels_key == "d64":
+        return get_d64_kernel_configs()
     if kernels_key == "best":
         return [best_config(DType.BF16), best_config(DType.FP16)]
     if "," in kernels_key:

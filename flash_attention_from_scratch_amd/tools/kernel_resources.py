@@ -25,11 +25,11 @@ def demangle_variant(name):
     if "fa_fwd_kernel16" in name and len(nums) >= 6:
         dt, nw, bc, swz, eager, opt = map(int, nums[:6])
         return dict(dtype=dt, rows_per_wave=16, n_waves=nw, B_c=bc, swizzled=swz, eager=eager,
-                    opt_softmax=opt, pipelined=0, dma=1)
-    if len(nums) >= 9:
-        dt, qt, nw, bc, swz, eager, opt, pipe, dma = map(int, nums[:9])
+                    opt_softmax=opt, pipelined=0, dma=1, masked=0, d_head=128)
+    if len(nums) >= 11:
+        dt, qt, nw, bc, swz, eager, opt, pipe, dma, masked, d_head = map(int, nums[:11])
         return dict(dtype=dt, rows_per_wave=32 * qt, n_waves=nw, B_c=bc, swizzled=swz, eager=eager,
-                    opt_softmax=opt, pipelined=pipe, dma=dma)
+                    opt_softmax=opt, pipelined=pipe, dma=dma, masked=masked, d_head=d_head)
     return {}
 
 
@@ -61,7 +61,7 @@ def collect():
     for r in rows:
         r["B_r"] = r.get("rows_per_wave", 0) * r.get("n_waves", 0)
         stages = 2 if r.get("eager") else 1
-        r["lds_bytes"] = max(2 * stages * r.get("B_c", 0) * 256, r["B_r"] * 256)
+        r["lds_bytes"] = max(2 * stages * r.get("B_c", 0), r["B_r"]) * 2 * r.get("d_head", 128)
     return rows
 
 
@@ -70,12 +70,13 @@ def main(argv=None):
     ap.add_argument("--csv")
     args = ap.parse_args(argv)
     rows = collect()
-    cols = ["dtype", "B_r", "B_c", "n_waves", "rows_per_wave", "pipelined", "dma", "opt_softmax", "swizzled", "eager",
+    cols = ["dtype", "d_head", "B_r", "B_c", "n_waves", "rows_per_wave", "pipelined", "dma", "masked", "opt_softmax",
+            "swizzled", "eager",
             "vgprs", "agprs", "sgprs", "scratch_bytes", "vgpr_spill", "occupancy", "lds_bytes"]
     out = open(args.csv, "w", newline="") if args.csv else sys.stdout
     w = csv.writer(out)
     w.writerow(cols)
-    for r in sorted(rows, key=lambda r: [r.get(c, 0) for c in cols[:10]]):
+    for r in sorted(rows, key=lambda r: [r.get(c, 0) for c in cols[:12]]):
         w.writerow([r.get(c, "") for c in cols])
     spilled = [r["kernel"] for r in rows if r.get("scratch_bytes") or r.get("vgpr_spill")]
     if spilled:

@@ -41,7 +41,7 @@ PMC_GROUPS = [["GRBM_GUI_ACTIVE", "TCC_HIT_sum", "TCC_MISS_sum"]]
 
 
 def symbol_to_config(symbol):
-    """'void fa::fa_fwd_kernel<15, 1, 8, 64, true, true, false, true, true, 0>(fa::KernelArgs)' ->
+    """'void fa::fa_fwd_kernel<15, 1, 8, 64, true, true, false, true, true, false, 128, 0>(fa::KernelArgs)' ->
     FlashForwardKernelConfig of that device variant (None for other kernels)."""
     m = re.search(r"fa::fa_fwd_kernel(16)?<([^>]*)>", symbol)
     if not m:
@@ -53,11 +53,21 @@ def symbol_to_config(symbol):
         rows, pipe = 16, 0
     else:
         dt, qt, nw, bc, swz, eager, opt, pipe, dma = vals[:9]
+        d_head = vals[10] if len(vals) > 10 else 128
         rows = 32 * qt
-        return FlashForwardKernelConfig(DType(dt), 128, rows * nw, bc, nw, bool(dma), bool(eager), bool(swz),
+        return FlashForwardKernelConfig(DType(dt), d_head, rows * nw, bc, nw, bool(dma), bool(eager), bool(swz),
                                         0, 0, 0, bool(pipe), bool(opt))
     return FlashForwardKernelConfig(DType(dt), 128, rows * nw, bc, nw, True, bool(eager), bool(swz),
                                     0, 0, 0, bool(pipe), bool(opt))
+
+
+def lds_of(cfg):
+    try:
+        from flash_attention_from_scratch_amd import _capi
+
+        return _capi.lds_bytes(cfg) if cfg else None
+    except Exception:
+        return None
 
 
 def git_commit():
@@ -115,7 +125,9 @@ def table_rows(trace, counters, batch, heads, seq_len, d_head, skip_first=1):
             "kernel": cfg.short_form() if cfg else symbol[:60],
             "dur_ms": ms,
             "cycles": c.get("GRBM_GUI_ACTIVE", 0) / 8 if c.get("GRBM_GUI_ACTIVE") else None,  # 8 XCDs
-            "vgpr": rec.get("vgpr"), "agpr": rec.get("agpr"), "lds": rec.get("lds"), "scratch": rec.get("scratch"),
+            # rocprofv3 reports only static LDS; these kernels use dynamic LDS -> ask the library
+            "vgpr": rec.get("vgpr"), "agpr": rec.get("agpr"), "lds": rec.get("lds") or lds_of(cfg),
+            "scratch": rec.get("scratch"),
             "l2_hit": 100 * hit / (hit + miss) if hit is not None and miss else None,
             "attn_tflops": calc_self_attn_flop(batch, heads, seq_len, d_head) / (ms * 1e-3) / 1e12,
             "mfma_tflops": calc_mfma_flop(batch, heads, seq_len, d_head) / (ms * 1e-3) / 1e12,

@@ -35,7 +35,7 @@ def _unique_variants(cfgs):
     """One config per device variant (the operand-fetch hints share device code)."""
     seen, out = set(), []
     for c in cfgs:
-        key = (c.dtype, c.B_r, c.B_c, c.n_warps, c.async_copy, c.eager_load_blocks, c.swizzled,
+        key = (c.dtype, c.d_head, c.B_r, c.B_c, c.n_warps, c.async_copy, c.eager_load_blocks, c.swizzled,
                c.optimized_softmax, c.mma_double_buffer_loads and c.B_r // c.n_warps == 32 and c.B_c <= 64)
         if key not in seen:
             seen.add(key)
@@ -43,8 +43,9 @@ def _unique_variants(cfgs):
     return out
 
 
-ALL = kc.get_all_supported_configs()
+ALL = [c for c in kc.get_all_supported_configs() if c.d_head == 128]   # the reference's scope
 VARIANTS = _unique_variants(ALL)
+D64 = _unique_variants(kc.get_d64_kernel_configs())                      # scope widener
 
 
 def test_library_loaded_and_device_is_gfx950():
@@ -330,3 +331,31 @@ def test_extreme_logit_ranges_stay_finite_and_accurate():
                 err = (out.float() - ref.float()).abs()
                 tol = TOL[dtype] * (1 + ref.float().abs())
                 assert (err <= tol).all(), (name, str(cfg), err.max().item())
+
+
+
+@pytest.mark.parametrize("cfg", D64, ids=str)
+def test_d_head_64_widener(cfg):
+    """d_head = 64 (the reference's config comments allow it, no kernel was ever built): parity
+    against the fp32 eager statement, torch SDPA, the C oracle and the reference's rule."""
+    dtype = cfg.dtype.to_torch_dtype()
+    for B, S, H in ((2, 512, 3), (1, 2048, 4)):
+        gen = torch.Generator(device=DEV).manual_seed(S)
+        q, k, v = (torch.randn((B, S, H, 64), dtype=dtype, device=DEV, generator=gen) for _ in range(3))
+        out = flash_attention.forward(cfg, q, k, v)
+        ref_f32 = ut.py_flash_attention(q, k, v, upcast=True)
+        ref_b16 = ut.py_flash_attention(q, k, v, upcast=False)
+        assert torch.isfinite(out.float()).all()
+        assert (out.float() - ref_f32.float()).abs().max().item() <= TOL[dtype]
+        lhs, rhs = fo.tolerance_rule(out, ref_b16, ref_f32)
+        assert lhs <= rhs
+        assert (out.float() - ut.sdpa_attention(q, k, v).float()).abs().max().item() <= 2 * TOL[dtype]
+        again = flash_attention.forward(cfg, q, k, v)
+        assert torch.equal(out, again)
+        if S == 512:
+            oracle = fo.blockwise_forward(q.cpu(), k.cpu(), v.cpu(), cfg.B_r, cfg.B_c,
+                                          optimized_softmax=cfg.optimized_softmax)
+            assert (out.cpu().float() - oracle.float()).abs().max().item() <= TOL[dtype]
+    with pytest.raises(RuntimeError, match="d_head"):
+        bad = torch.zeros((1, 512, 2, 128), dtype=dtype, device=DEV)
+        flash_attention.forward(cfg, bad, bad, bad)

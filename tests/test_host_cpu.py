@@ -39,7 +39,7 @@ def test_every_enumerated_config_has_a_device_kernel():
         lds = _capi.lds_bytes(cfg)
         stages = 2 if cfg.eager_load_blocks else 1
         # K/V stages, or the O tile staged through LDS in the epilogue, whichever is larger
-        assert lds == max(2 * stages * cfg.B_c * 128 * 2, cfg.B_r * 128 * 2)
+        assert lds == max(2 * stages * cfg.B_c * cfg.d_head * 2, cfg.B_r * cfg.d_head * 2)
         assert lds <= 160 * 1024
 
 
@@ -54,6 +54,7 @@ def test_registry_enumeration_is_consistent():
         assert info.threads == 64 * info.cfg.n_warps
         assert info.rows_per_wave * info.cfg.n_warps == info.cfg.B_r
         assert info.rows_per_wave in (16, 32, 64)
+        assert info.cfg.d_head in (64, 128)
         cfg = kc.FlashForwardKernelConfig(kc.DType(info.cfg.dtype), *key[1:5], *map(bool, key[5:8]),
                                           *key[8:11], *map(bool, key[11:13]))
         assert _capi.supported(cfg)
@@ -63,13 +64,14 @@ def test_unsupported_configs_are_rejected():
     base = kc.get_kernels_to_build()[0]
     from dataclasses import replace
 
-    assert not _capi.supported(replace(base, d_head=64))
+    assert not _capi.supported(replace(base, d_head=96))
+    assert not _capi.supported(replace(base, d_head=64))  # no 16-rows-per-wave kernel at d_head 64
     assert not _capi.supported(replace(base, B_c=48))
     assert not _capi.supported(replace(base, n_warps=3))
     assert not _capi.supported(replace(base, Q_mma_load_K_tiles=2, K_mma_load_K_tiles=0))
     assert not _capi.supported(replace(base, K_mma_load_K_tiles=3))
     with pytest.raises(_capi.FaError) as e:
-        _capi.lds_bytes(replace(base, d_head=64))
+        _capi.lds_bytes(replace(base, d_head=96))
     assert "d_head" in str(e.value)
 
 

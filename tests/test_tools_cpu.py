@@ -37,18 +37,19 @@ def test_isa_stats_histogram_and_trace():
 
 
 def test_symbol_and_mangled_name_round_trip_to_config():
-    cfg = rocprof_bench.symbol_to_config("void fa::fa_fwd_kernel<15, 1, 8, 64, true, true, false, true, true, 0>(fa::KernelArgs)")
+    cfg = rocprof_bench.symbol_to_config("void fa::fa_fwd_kernel<15, 1, 8, 64, true, true, false, true, true, false, 128, 0>(fa::KernelArgs)")
     assert cfg == kc.FlashForwardKernelConfig(kc.DType.BF16, 128, 256, 64, 8, True, True, True, 0, 0, 0, True, False)
     cfg16 = rocprof_bench.symbol_to_config("void fa::fa_fwd_kernel16<5, 4, 32, true, true, true>(fa::KernelArgs)")
     assert (cfg16.dtype, cfg16.B_r, cfg16.B_c, cfg16.n_warps, cfg16.optimized_softmax) == (kc.DType.FP16, 64, 32, 4, True)
     assert rocprof_bench.symbol_to_config("void at::native::foo<float>()") is None
-    v = kernel_resources.demangle_variant("_ZN2fa13fa_fwd_kernelILi15ELi1ELi8ELi64ELb1ELb1ELb0ELb1ELb0ELi0EEEvNS_10KernelArgsE")
-    assert v == dict(dtype=15, rows_per_wave=32, n_waves=8, B_c=64, swizzled=1, eager=1, opt_softmax=0, pipelined=1, dma=0)
+    v = kernel_resources.demangle_variant("_ZN2fa13fa_fwd_kernelILi15ELi1ELi8ELi64ELb1ELb1ELb0ELb1ELb0ELb0ELi128ELi0EEEvNS_10KernelArgsE")
+    assert v == dict(dtype=15, rows_per_wave=32, n_waves=8, B_c=64, swizzled=1, eager=1, opt_softmax=0, pipelined=1, dma=0,
+                     masked=0, d_head=128)
 
 
 def test_resource_remark_parser():
     text = "\n".join([
-        "./fa_fwd_kernel.hpp:150:1: remark: Function Name: _ZN2fa13fa_fwd_kernelILi15ELi1ELi8ELi64ELb1ELb1ELb0ELb1ELb1ELi0EEEvNS_10KernelArgsE [-Rpass-analysis=kernel-resource-usage]",
+        "./fa_fwd_kernel.hpp:150:1: remark: Function Name: _ZN2fa13fa_fwd_kernelILi15ELi1ELi8ELi64ELb1ELb1ELb0ELb1ELb1ELb0ELi128ELi0EEEvNS_10KernelArgsE [-Rpass-analysis=kernel-resource-usage]",
         "./fa_fwd_kernel.hpp:150:1: remark:     VGPRs: 246 [-Rpass-analysis=kernel-resource-usage]",
         "./fa_fwd_kernel.hpp:150:1: remark:     AGPRs: 0 [-Rpass-analysis=kernel-resource-usage]",
         "./fa_fwd_kernel.hpp:150:1: remark:     ScratchSize [bytes/lane]: 0 [-Rpass-analysis=kernel-resource-usage]",
@@ -61,7 +62,7 @@ def test_resource_remark_parser():
 
 
 def test_rocprof_csv_parsers(tmp_path):
-    sym = "void fa::fa_fwd_kernel<15, 1, 8, 64, true, true, false, true, true, 0>(fa::KernelArgs)"
+    sym = "void fa::fa_fwd_kernel<15, 1, 8, 64, true, true, false, true, true, false, 128, 0>(fa::KernelArgs)"
     trace = tmp_path / "p_kernel_trace.csv"
     trace.write_text(
         "Kind,Agent_Id,Kernel_Name,Start_Timestamp,End_Timestamp,VGPR_Count,Accum_VGPR_Count,LDS_Block_Size,Scratch_Size\n"
@@ -92,7 +93,7 @@ def test_generated_variant_list_is_current_and_covers_every_config():
     for info in _capi.kernels():
         c = info.cfg
         key = (c.dtype, info.rows_per_wave, c.n_warps, c.B_c, bool(c.swizzled), bool(c.eager_load_blocks),
-               bool(c.optimized_softmax), bool(c.mma_double_buffer_loads), bool(c.async_copy))
+               bool(c.optimized_softmax), bool(c.mma_double_buffer_loads), bool(c.async_copy), c.d_head)
         (masked if info.masked else built).add(key)
     wanted = {gen.variant_of(cfg) for cfg in kc.get_all_supported_configs()}
     assert wanted == built
