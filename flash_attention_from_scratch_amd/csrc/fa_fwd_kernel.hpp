@@ -227,7 +227,9 @@ struct FwdTraits {
 // ---------------------------------------------------------------------------------
 // ABL (tools/ablate.hip only; 0 in every shipped variant) removes one cost at a time to
 // attribute cycles: 1 no v_exp, 2 no softmax VALU at all, 4 no LDS operand reads,
-// 8 no barriers / DMA waits, 16 no DMA.  Results are wrong by construction when ABL != 0.
+// 8 no barriers / DMA waits, 16 no DMA, 32 plain loads instead of DMA (data discarded);
+// experiments: 64 s_setprio(1) around the MFMA clusters (-3 %), 128 operand prefetch 12 deep
+// (no change).  Results are wrong by construction when ABL & 63 != 0.
 template <int DT, int QT, int NWAVES, int BC, bool SWZ, bool EAGER, bool OPT, bool PIPE, bool DMA = true,
           bool MASK = false, int D = 128, int ABL = 0>
 __global__ void
@@ -513,7 +515,7 @@ fa_fwd_kernel(const KernelArgs args) {
                 for (int qt = 0; qt < QT; ++qt) S[qt][nt] = E::mfma(a, Qr[qt][ks], S[qt][nt]);
             }
         }
-        if (SCHED && !PIPE) sched_mfma_fed_from_lds<NT * KS * QT, 1, 8>();
+        if (SCHED && !PIPE) sched_mfma_fed_from_lds<NT * KS * QT, 1, (ABL & 128) ? 12 : 8>();
     };
 
     // ---- online softmax, lane-local (softmax.cuh:85-105) --------------------------
@@ -612,7 +614,7 @@ fa_fwd_kernel(const KernelArgs args) {
                 }
             }
         }
-        if (SCHED && !PIPE) sched_mfma_fed_from_lds<DTILES * NT * 2 * QT, 2, 8>();
+        if (SCHED && !PIPE) sched_mfma_fed_from_lds<DTILES * NT * 2 * QT, 2, (ABL & 128) ? 12 : 8>();
     };
 
     using TrueTag = BoolTag<true>;
@@ -777,13 +779,17 @@ fa_fwd_kernel(const KernelArgs args) {
             f32x16 S[QT][NT];
             vec8 P[QT][NT][2];
             float alpha[QT];
+            if (ABL & 64) __builtin_amdgcn_s_setprio(1);
             qk(stage, S);
+            if (ABL & 64) __builtin_amdgcn_s_setprio(0);
             if (MASK && tile_needs_mask(it)) mask_S(S, it);
             FA_STAMP(it, 2);
             softmax(S, P, alpha, first_tag);
             if (!decltype(first_tag)::value) rescale_O(alpha);
             FA_STAMP(it, 3);
+            if (ABL & 64) __builtin_amdgcn_s_setprio(1);
             pv(stage, P);
+            if (ABL & 64) __builtin_amdgcn_s_setprio(0);
             FA_STAMP(it, 4);
         };
         if (!DMA) {

@@ -16,7 +16,7 @@ void run(const char *name) {
     a.q = q; a.k = k; a.v = v; a.o = o;
     a.batch_stride = (int64_t)S * H * D; a.seq_stride = H * D; a.head_stride = D;
     a.seq_len = S; a.n_heads = H; a.n_bh = B * H; a.n_q_blocks = S / (32 * NW); a.n_kv_blocks = S / BC;
-    auto kern = fa::fa_fwd_kernel<15, 1, NW, BC, true, true, true, PIPE, DMA, ABL>;
+    auto kern = fa::fa_fwd_kernel<15, 1, NW, BC, true, true, true, PIPE, DMA, false, 128, ABL>;
     const int lds = 4 * BC * 256;
     CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
@@ -44,18 +44,13 @@ int main() {
         }
         CHECK(hipMemcpy(t == 0 ? q : t == 1 ? k : v, h.data(), n * 2, hipMemcpyHostToDevice));
     }
-    run<4, 64, false, 0>("plain NW4 (warm-up)");
-    run<4, 64, false, 0>("plain NW4 dma");
-    run<4, 64, false, 0, false>("plain NW4 reg-staged");
-    run<8, 64, false, 0>("plain NW8 dma");
-    run<8, 64, false, 0, false>("plain NW8 reg-staged");
-    run<8, 128, false, 0>("plain NW8 BC128 dma");
-    run<8, 128, false, 0, false>("plain NW8 BC128 reg-staged");
-    run<4, 64, true, 0>("pipe NW4 dma");
-    run<4, 64, true, 0, false>("pipe NW4 reg-staged");
-    run<8, 64, true, 0>("pipe NW8 dma");
-    run<8, 64, true, 0, false>("pipe NW8 reg-staged");
-    run<8, 64, true, 8, false>("pipe NW8 reg-staged no-barrier");
-    run<8, 64, true, 4, false>("pipe NW8 reg-staged no-LDS-reads");
+    run<8, 128, false, 0>("plain NW8 BC128 (warm-up)");
+    for (int rep = 0; rep < 3; ++rep) {
+        run<8, 128, false, 0>("plain NW8 BC128");
+        run<8, 128, false, 64>("plain NW8 BC128 +setprio");
+        run<8, 128, false, 128>("plain NW8 BC128 prefetch 12");
+        run<8, 64, false, 0>("plain NW8 BC64");
+        run<8, 64, false, 64>("plain NW8 BC64 +setprio");
+    }
     return 0;
 }

@@ -34,7 +34,7 @@ int run(int S) {
     a.batch_stride = (int64_t)S * H * D; a.seq_stride = H * D; a.head_stride = D;
     a.seq_len = S; a.n_heads = H; a.n_bh = B * H; a.n_q_blocks = S / 256; a.n_kv_blocks = S / 64;
     a.trace = tr; a.trace_block = 700;
-    auto kern = fa::fa_fwd_kernel<15, 1, 8, 64, true, true, true, PIPE, true>;
+    auto kern = fa::fa_fwd_kernel<15, 1, 8, 64, true, true, true, PIPE, true, false, 128>;
     CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
     for (int rep = 0; rep < 3; ++rep) {
         hipLaunchKernelGGL(kern, dim3(a.n_bh * a.n_q_blocks), dim3(512), 65536, 0, a);
