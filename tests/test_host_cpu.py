@@ -158,3 +158,30 @@ def test_short_form_round_trips_and_env_selector(monkeypatch):
         kc.get_kernel_configs()
     assert kc.DType.from_string("bf16") is kc.DType.BF16 and kc.DType.from_string("5") is kc.DType.FP16
     assert kc.transform_kernel_name("not a kernel") == "not a kernel"
+
+
+def test_config_name_round_trips_property():
+    """Any field combination survives short_form -> parse and to_cpp_struct -> parse (hypothesis)."""
+    from hypothesis import given, settings, strategies as st
+
+    cfgs = st.builds(
+        kc.FlashForwardKernelConfig,
+        dtype=st.sampled_from(list(kc.DType)), d_head=st.sampled_from([64, 128]),
+        B_r=st.sampled_from([64, 128, 256]), B_c=st.sampled_from([32, 64, 128]), n_warps=st.sampled_from([4, 8]),
+        async_copy=st.booleans(), eager_load_blocks=st.booleans(), swizzled=st.booleans(),
+        Q_mma_load_K_tiles=st.sampled_from([0, 2, 4]), K_mma_load_K_tiles=st.sampled_from([0, 2, 4]),
+        V_mma_load_K_tiles=st.sampled_from([0, 2, 4]), mma_double_buffer_loads=st.booleans(),
+        optimized_softmax=st.booleans(),
+    )
+
+    @settings(max_examples=200, deadline=None)
+    @given(cfgs)
+    def check(cfg):
+        assert kc.parse_kernel_name_into_config(cfg.short_form()) == cfg
+        demangled = "void flash_forward_kernel<" + cfg.to_cpp_struct().replace("torch::kFloat16", "5").replace(
+            "torch::kBFloat16", "15") + ">(args)"
+        assert kc.parse_kernel_name_into_config(demangled) == cfg
+        assert _capi.make_config(cfg).B_r == cfg.B_r and tuple(cfg.to_c_abi_tuple())[0] == int(cfg.dtype)
+        assert cfg.total_flop(2, 3, 256) == kc.calc_total_flop(2, 3, 256, cfg.B_r, cfg.B_c, cfg.d_head)
+
+    check()
