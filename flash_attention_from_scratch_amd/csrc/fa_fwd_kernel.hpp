@@ -85,6 +85,7 @@ struct KernelArgs {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -94,6 +95,16 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 #define FA_DEV __device__ __forceinline__
 
 template <bool B> struct BoolTag { static constexpr bool value = B; };
+template <int I> struct IntTag { static constexpr int value = I; };
+// f(IntTag<I>{}) for I = BEGIN .. END-1: unrolled by construction (a `#pragma unroll` loop whose
+// unrolled size passes LLVM's pragma threshold is silently left rolled, and every register array
+// it indexes then lives in scratch)
+template <int BEGIN, int END, class F> __device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (BEGIN < END) {
+        f(IntTag<BEGIN>{});
+        static_for<BEGIN + 1, END>(f);
+    }
+}
 
 template <int DT> struct Elem;
 
@@ -104,6 +115,31 @@ template <> struct Elem<15> {  // bf16
     }
     static FA_DEV f32x4 mfma16(vec8 a, vec8 b, f32x4 c) {
         return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    }
+    // Inline-asm MFMA forms with the register FILE of each operand chosen by hand (64-rows-per-
+    // wave schedule): accumulator in AGPRs ("a") or VGPRs ("v"), B operand Q resident in AGPRs.
+    // hipcc neither schedules nor hazard-pads these: see the call sites for the wait states.
+    static FA_DEV void mfma_acc_a_q(f32x16 &acc, vec8 a, vec8 q) {  // acc(AGPR) += a * q(AGPR)
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "a"(q));
+    }
+    static FA_DEV void mfma_acc_a_q0(f32x16 &acc, vec8 a, vec8 q) {  // acc(AGPR) = a * q(AGPR)
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=a"(acc) : "v"(a), "a"(q));
+    }
+    static FA_DEV void mfma_acc_v_q(f32x16 &acc, vec8 a, vec8 q) {  // acc(VGPR) += a * q(AGPR)
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "a"(q));
+    }
+    static FA_DEV void mfma_acc_v_q0(f32x16 &acc, vec8 a, vec8 q) {
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=v"(acc) : "v"(a), "a"(q));
+    }
+    static FA_DEV void mfma_acc_a_p(f32x16 &acc, vec8 a, u32x4 p) {  // acc(AGPR) += a * p(VGPR, packed >= 1 step ago)
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(p));
+    }
+    static FA_DEV unsigned pack2(float x, float y) {  // RNE, low half = x
+        typedef __bf16 pair_t __attribute__((ext_vector_type(2)));
+        pair_t r;
+        r[0] = (__bf16)x;
+        r[1] = (__bf16)y;
+        return __builtin_bit_cast(unsigned, r);
     }
     // RNE fp32 -> bf16 (v_cvt_pk_bf16_f32), load_store.cuh:345-349 semantics
     static FA_DEV vec8 pack8(const float *p) {
@@ -122,6 +158,31 @@ template <> struct Elem<5> {  // fp16
     static FA_DEV f32x4 mfma16(vec8 a, vec8 b, f32x4 c) {
         return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
     }
+    // Inline-asm MFMA forms with the register FILE of each operand chosen by hand (64-rows-per-
+    // wave schedule): accumulator in AGPRs ("a") or VGPRs ("v"), B operand Q resident in AGPRs.
+    // hipcc neither schedules nor hazard-pads these: see the call sites for the wait states.
+    static FA_DEV void mfma_acc_a_q(f32x16 &acc, vec8 a, vec8 q) {  // acc(AGPR) += a * q(AGPR)
+        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "a"(q));
+    }
+    static FA_DEV void mfma_acc_a_q0(f32x16 &acc, vec8 a, vec8 q) {  // acc(AGPR) = a * q(AGPR)
+        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=a"(acc) : "v"(a), "a"(q));
+    }
+    static FA_DEV void mfma_acc_v_q(f32x16 &acc, vec8 a, vec8 q) {  // acc(VGPR) += a * q(AGPR)
+        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "a"(q));
+    }
+    static FA_DEV void mfma_acc_v_q0(f32x16 &acc, vec8 a, vec8 q) {
+        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=v"(acc) : "v"(a), "a"(q));
+    }
+    static FA_DEV void mfma_acc_a_p(f32x16 &acc, vec8 a, u32x4 p) {  // acc(AGPR) += a * p(VGPR, packed >= 1 step ago)
+        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(p));
+    }
+    static FA_DEV unsigned pack2(float x, float y) {  // RNE, low half = x
+        typedef _Float16 pair_t __attribute__((ext_vector_type(2)));
+        pair_t r;
+        r[0] = (_Float16)x;
+        r[1] = (_Float16)y;
+        return __builtin_bit_cast(unsigned, r);
+    }
     static FA_DEV vec8 pack8(const float *p) {
         vec8 r;
 #pragma unroll
@@ -129,6 +190,19 @@ template <> struct Elem<5> {  // fp16
         return r;
     }
 };
+
+// Single-instruction VALU forms for the hand-placed schedule: plain C++ lets hipcc SLP-pack adjacent
+// f32 adds into v_pk_add_f32 and canonicalise fmaxf inputs, both slower beside MFMAs.
+static FA_DEV float vmax3(float a, float b, float c) {
+    float d;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+static FA_DEV float vadd(float a, float b) {
+    float d;
+    asm("v_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
 
 // max over the two lanes that share a query column (lane, lane^32).
 static FA_DEV float pair_max(float x) {
@@ -620,7 +694,170 @@ fa_fwd_kernel(const KernelArgs args) {
     using TrueTag = BoolTag<true>;
     using FalseTag = BoolTag<false>;
 
-    if (PIPE) {
+    if constexpr (QT == 2 && PIPE) {
+        // ---- 64 rows per wave, one wave per SIMD, hand-placed registers and order ----------
+        // Each K / V operand read from LDS feeds TWO MFMAs (the wave's two 32-row Q tiles), which
+        // halves LDS traffic, DMA issue and barriers per MFMA.  512 registers per lane, by file:
+        //   AGPR  O (128) | Q (64)
+        //   VGPR  two S tiles (128) | P (32) | operand ring (16) | softmax temporaries
+        // All MFMAs are inline asm so that O and Q never leave the accumulator file; hipcc does
+        // not schedule or hazard-pad them, so the stream is pinned gap by gap (one MFMA + its
+        // fillers, then sched_barrier(0)) and the wait states are kept by distance:
+        //   * S(it+1) is accumulated in phase 1 and first read (row max) >= 2 MFMAs later;
+        //   * a packed P operand is consumed >= 1 step after its v_cvt_pk;
+        //   * O is read by VALU only in the rare rescale and in the epilogue, behind s_nop pads.
+        // One wave per SIMD hides about five single-issue instructions per 32-cycle MFMA
+        // (MI355X_MICROARCH.md, per-instruction constants), so the softmax of tile `it` is cut
+        // into 32 two-element units {2 fma, 2 exp2, 2 add, 1 pack} and dealt over the gaps:
+        //   phase 1 (32 MFMAs, S(it+1) = K(it+1) Q^T): K operand reads, 8 DMA pieces, 20 units
+        //   phase 2 (32 MFMAs, O += V(it) P(it)):      V operand reads, 12 units, row max of S(it+1)
+        //
+        // Rescaling is lazy: O and l stay relative to a reference max m that is only moved (and
+        // O, l multiplied by 2^((m_old - m_new) c)) when some row's max rose by more than
+        // TAU / c logit units, so P <= 2^TAU.  The result is the same real number as the
+        // reference's eager rescale (softmax.cuh:36-49); only the rounding point of P differs,
+        // with the same relative error.  With O in the accumulator file a rescale costs ~200
+        // issue slots per Q tile, and for random data some row of 32 finds a new max in most tiles.
+        static_assert(DMA && !MASK && D == 128 && BC == 64 && NT == 2, "64-row pinned schedule: DMA, d=128, B_c=64");
+        constexpr float TAU = 8.0f;
+        f32x16 Sa[2][NT], Sb[2][NT];
+        u32x4 Pw[2][4];          // P[qt][16-key slice]: B operand of O^T += V^T P^T
+        float neg_msc[2];        // -(m c)
+        float m_pend[2];         // candidate reference max found during the previous visit
+        bool resc[2] = {false, false};
+        auto k_frag = [&](const char *kt, int step) -> vec8 {  // step = 2*ks + nt
+            const int ks = step >> 1, nt = step & 1;
+            return *(const vec8 *)(kt + nt * 32 * ROWB + ka_base + (((2 * ks + hi) ^ ka_swz) << 4));
+        };
+        auto v_frag = [&](const char *vt, int step) -> vec8 {  // step = 4*s16 + t
+            const int s16 = step >> 2, t = step & 3;
+            const char *vp = vt + va_base + s16 * (DSUB * 1024) + t * 512;
+            s16x8 av;
+            av.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((FA_LDS(s16x4) *)(vp));
+            av.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((FA_LDS(s16x4) *)(vp + DSUB * 512));
+            return __builtin_bit_cast(vec8, av);
+        };
+        auto qk_mfma = [&](auto &S, int step, int qt, vec8 a) {
+            const int ks = step >> 1, nt = step & 1;
+            if (ks == 0) E::mfma_acc_v_q0(S[qt][nt], a, Qr[qt][ks]);
+            else E::mfma_acc_v_q(S[qt][nt], a, Qr[qt][ks]);
+        };
+        auto visit = [&](int it, auto &S_cur, auto &S_nxt) {
+            wait_and_barrier();
+            // next tiles' DMA: K(it+2) -> stage it&1, V(it+1) -> stage (it+1)&1.  Past the end the
+            // last tile is fetched again into a stage nobody reads: no branch in the stream.
+            const int itk = it + 2 < n_kv ? it + 2 : n_kv - 1, itv = it + 1 < n_kv ? it + 1 : n_kv - 1;
+            const uint16_t *kb = Kg + (int64_t)(n_kv - 1 - itk) * tile_stride;
+            const uint16_t *vb = Vg + (int64_t)(n_kv - 1 - itv) * tile_stride;
+            const unsigned kdst = smem_base + (it & 1) * TILE + wave * 1024;
+            const unsigned vdst = smem_base + V_BASE + ((it + 1) & 1) * TILE + wave * 1024;
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+                if (resc[qt]) {  // wave-uniform, rare
+                    asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");  // MFMA D (O) -> VALU read
+                    const float alpha = __builtin_amdgcn_exp2f((m[qt] - m_pend[qt]) * c);
+                    m[qt] = m_pend[qt];
+                    neg_msc[qt] = -(m[qt] * c);
+                    l[qt] *= alpha;
+#pragma unroll
+                    for (int t = 0; t < DTILES; ++t)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) O[qt][t][r] *= alpha;
+                }
+            }
+            const char *kt = smem + ((it + 1) & 1) * TILE;
+            const char *vt = smem + V_BASE + (it & 1) * TILE;
+            float rs[2][2] = {{0.0f, 0.0f}, {0.0f, 0.0f}};
+            float vm[2];
+            auto exp_unit = [&](int u) {  // u = 8*s16 + 2*j + qt: in the order P.V consumes P
+                const int qt = u & 1, j = (u >> 1) & 3, s16 = u >> 3;
+                const int r = 8 * (s16 & 1) + 2 * j;
+                float p0 = __builtin_fmaf(S_cur[qt][s16 >> 1][r], c, neg_msc[qt]);
+                float p1 = __builtin_fmaf(S_cur[qt][s16 >> 1][r + 1], c, neg_msc[qt]);
+                if (!(ABL & 1)) {
+                    p0 = __builtin_amdgcn_exp2f(p0);
+                    p1 = __builtin_amdgcn_exp2f(p1);
+                }
+                rs[qt][0] = vadd(rs[qt][0], p0);  // fp32 P, before rounding (softmax.cuh:66-83)
+                rs[qt][1] = vadd(rs[qt][1], p1);
+                Pw[qt][s16][j] = E::pack2(p0, p1);
+            };
+            auto max_unit = [&](int u) {  // u = 0..31: tile (nt = u>>4, qt = (u>>3)&1), elements 2(u&7), +1
+                const int nt = u >> 4, qt = (u >> 3) & 1, e = 2 * (u & 7);
+                if ((u & 7) == 0 && nt == 0) vm[qt] = fmaxf(S_nxt[qt][nt][0], S_nxt[qt][nt][1]);
+                else vm[qt] = vmax3(vm[qt], S_nxt[qt][nt][e], S_nxt[qt][nt][e + 1]);
+            };
+            vec8 ring[4];  // operand ring over the 32 operands of a visit (16 K, then 16 V)
+            auto operand = [&](int u) -> vec8 { return u < 16 ? k_frag(kt, u) : v_frag(vt, u - 16); };
+            ring[0] = operand(0);
+            ring[1] = operand(1);
+            __builtin_amdgcn_sched_barrier(0);
+            static_for<0, 64>([&](auto gap_tag) {
+                constexpr int g = decltype(gap_tag)::value;
+                constexpr int step = g >> 1, qt = g & 1;
+                if constexpr (qt == 0 && step + 2 < 32) ring[(step + 2) % 4] = operand(step + 2);
+                if constexpr (g < 32) {
+                    qk_mfma(S_nxt, step, qt, ring[step % 4]);
+                    constexpr int g8 = g & 7;
+                    if constexpr ((g & 3) == 0) {  // one 1-KiB DMA piece
+                        constexpr int j = g >> 3;
+                        if constexpr ((g & 4) == 0) glds16_sv(kb, k_off[j], kdst + NWAVES * j * 1024);
+                        else glds16_sv(vb, v_off[j], vdst + NWAVES * j * 1024);
+                    } else if constexpr (g8 != 6) {  // 5 units per 8 gaps: 20 in phase 1
+                        exp_unit(5 * (g >> 3) + (g8 < 4 ? g8 - 1 : (g8 == 5 ? 3 : 4)));
+                    }
+                } else {
+                    constexpr int h = g - 32, s2 = h >> 1, s16 = s2 >> 2, t = s2 & 3;
+                    E::mfma_acc_a_p(O[qt][t], ring[step % 4], Pw[qt][s16]);
+                    if constexpr (qt == 1 && h < 24) exp_unit(20 + (h >> 1));  // 12 units, done by gap 55
+                    if constexpr (h < 16) {
+                        if constexpr (qt == 0) { max_unit(h); max_unit(h + 1); }
+                    } else if constexpr (h < 24) {
+                        max_unit(16 + 2 * (h - 16)); max_unit(17 + 2 * (h - 16));
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            });
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+                l[qt] += rs[qt][0] + rs[qt][1];
+                const float m_new = fmaxf(m[qt], pair_max(vm[qt]));
+                m_pend[qt] = m_new;
+                resc[qt] = __any((m_new - m[qt]) * c > TAU);
+            }
+        };
+        // prologue: S(0) and its row max, which becomes the first reference max (O = l = 0)
+        wait_and_barrier();
+        issue_k(n_kv > 1 ? 1 : 0, 1);
+        {
+            const char *kt = smem;
+            static_for<0, 16>([&](auto step_tag) {
+                constexpr int step = decltype(step_tag)::value;
+                const vec8 a = k_frag(kt, step);
+                qk_mfma(Sa, step, 0, a);
+                qk_mfma(Sa, step, 1, a);
+            });
+            asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // MFMA D -> VALU read
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+                float v = Sa[qt][0][0];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) v = fmaxf(v, Sa[qt][nt][r]);
+                m[qt] = pair_max(v);
+                neg_msc[qt] = -(m[qt] * c);
+                m_pend[qt] = m[qt];
+            }
+        }
+        // seq_len is a multiple of B_r = 256, so n_kv = seq_len / 64 is even: visits come in pairs
+        for (int it = 0; it < n_kv; it += 2) {
+            visit(it, Sa, Sb);
+            visit(it + 1, Sb, Sa);
+        }
+        dma_wait();  // the re-fetched last tiles must land before the epilogue reuses the LDS
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // last P.V -> epilogue reads of O
+    } else if (PIPE) {
         // In-wave software pipeline with two S accumulators.  While the matrix pipe forms
         // S(it+1) = K(it+1) Q^T and then O += V(it) P(it), the VALU turns the finished S(it)
         // into P(it): every MFMA of the visit has ~4-5 independent VALU ops and 1-2 LDS

@@ -10,14 +10,14 @@
 static uint16_t *q, *k, *v, *o;
 static const int B = 4, H = 16, D = 128, S = 4096;
 
-template <int NW, int BC, bool PIPE, int ABL, bool DMA = true>
+template <int NW, int BC, bool PIPE, int ABL, bool DMA = true, int QT = 1>
 void run(const char *name) {
     fa::KernelArgs a;
     a.q = q; a.k = k; a.v = v; a.o = o;
     a.batch_stride = (int64_t)S * H * D; a.seq_stride = H * D; a.head_stride = D;
-    a.seq_len = S; a.n_heads = H; a.n_bh = B * H; a.n_q_blocks = S / (32 * NW); a.n_kv_blocks = S / BC;
-    auto kern = fa::fa_fwd_kernel<15, 1, NW, BC, true, true, true, PIPE, DMA, false, 128, ABL>;
-    const int lds = 4 * BC * 256;
+    a.seq_len = S; a.n_heads = H; a.n_bh = B * H; a.n_q_blocks = S / (32 * QT * NW); a.n_kv_blocks = S / BC;
+    auto kern = fa::fa_fwd_kernel<15, QT, NW, BC, true, true, true, PIPE, DMA, false, 128, ABL>;
+    const int lds = (4 * BC * 256 > 32 * QT * NW * 256) ? 4 * BC * 256 : 32 * QT * NW * 256;
     CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
     float best = 1e9, sum = 0;
@@ -44,13 +44,14 @@ int main() {
         }
         CHECK(hipMemcpy(t == 0 ? q : t == 1 ? k : v, h.data(), n * 2, hipMemcpyHostToDevice));
     }
-    run<8, 128, false, 0>("plain NW8 BC128 (warm-up)");
-    for (int rep = 0; rep < 3; ++rep) {
-        run<8, 128, false, 0>("plain NW8 BC128");
-        run<8, 128, false, 64>("plain NW8 BC128 +setprio");
-        run<8, 128, false, 128>("plain NW8 BC128 prefetch 12");
-        run<8, 64, false, 0>("plain NW8 BC64");
-        run<8, 64, false, 64>("plain NW8 BC64 +setprio");
-    }
+    run<4, 64, false, 0, true, 2>("QT2 plain (warm-up)");
+    run<4, 64, false, 0, true, 2>("QT2 plain BC64");
+    run<4, 64, false, 1, true, 2>("QT2 plain BC64 no-exp");
+    run<4, 64, false, 2, true, 2>("QT2 plain BC64 no-softmax");
+    run<4, 64, false, 4, true, 2>("QT2 plain BC64 no-LDS-reads");
+    run<4, 64, false, 6, true, 2>("QT2 plain BC64 no-softmax no-LDS");
+    run<4, 64, false, 8, true, 2>("QT2 plain BC64 no-barrier");
+    run<4, 64, false, 30, true, 2>("QT2 plain BC64 MFMA only");
+    run<8, 128, false, 0>("QT1 plain NW8 BC128");
     return 0;
 }

@@ -36,7 +36,7 @@ def _unique_variants(cfgs):
     seen, out = set(), []
     for c in cfgs:
         key = (c.dtype, c.d_head, c.B_r, c.B_c, c.n_warps, c.async_copy, c.eager_load_blocks, c.swizzled,
-               c.optimized_softmax, c.mma_double_buffer_loads and c.B_r // c.n_warps == 32 and c.B_c <= 64)
+               c.optimized_softmax, c.mma_double_buffer_loads and ((c.B_r // c.n_warps == 32 and c.B_c <= 64) or (c.B_r // c.n_warps == 64 and c.B_c == 64)))
         if key not in seen:
             seen.add(key)
             out.append(c)
