@@ -240,6 +240,15 @@ static FA_DEV void glds16_sv(const void *base_wave_uniform, unsigned lane_byte_o
                  : "v"(lane_byte_off), "s"(base_wave_uniform), "s"(lds_dst_wave_uniform)
                  : "memory");
 }
+// Variant that leaves M0 changed (3 instructions instead of 5).  Only for kernels in which hipcc
+// itself never needs M0 (no LDS-DMA builtin, no s_movrel / sendmsg): the 64-row pinned schedule.
+static FA_DEV void glds16_sv_m0(const void *base_wave_uniform, unsigned lane_byte_off,
+                                unsigned lds_dst_wave_uniform) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                 :
+                 : "v"(lane_byte_off), "s"(base_wave_uniform), "s"(lds_dst_wave_uniform)
+                 : "memory");
+}
 static FA_DEV void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 // workgroup barrier that the compiler may not move LDS traffic across and that does
 // not drain VMEM (in-flight DMA survives it)
@@ -290,11 +299,70 @@ struct FwdTraits {
     static constexpr int kBc = BC;
     static constexpr int kThreads = NWAVES * 64;
     static constexpr int kTileBytes = BC * 2 * D;               // one K or V tile
-    static constexpr int kStages = EAGER ? 2 : 1;
+    // LDS ring depth per tensor: 4 for the 64-rows-per-wave schedule (tiles fetched 3 visits ahead)
+    static constexpr int kStages = (QT == 2 && PIPE) ? 4 : (EAGER ? 2 : 1);
     static constexpr int kKvBytes = 2 * kStages * kTileBytes;   // K + V, all stages
     static constexpr int kOutBytes = kBr * 2 * D;               // O tile staged for the epilogue
     static constexpr int kLdsBytes = kKvBytes > kOutBytes ? kKvBytes : kOutBytes;
 };
+
+// Filler plan of the 64-rows-per-wave schedule: what rides in the gap after MFMA g (g = 0..63 of a
+// visit; 0..31 = QK^T of tile it+1, 32..63 = P.V of tile it).  Built at compile time so that
+// placements can be compared by changing one function (tools/tune64.hip).
+struct Plan64 {
+    signed char exp_first[64], exp_n[64];  // softmax units (2 elements each), 32 per visit, in P.V order
+    signed char max_first[64], max_n[64];  // row-max units over S(it+1), 32 per visit
+    signed char dma[64];                   // DMA piece 0..7 (even = K, odd = V) or -1
+    signed char tail[64];                  // end-of-visit chain step 1.. or 0
+};
+constexpr Plan64 make_plan64(bool dma_late, int n_phase1) {
+    Plan64 p{};
+    int e = 0, m = 0, d = 0;
+    for (int g = 0; g < 64; ++g) {
+        const int h = g - 32;
+        int ne = 0, nm = 0, dm = -1, tl = 0;
+        if (g < 32) {
+            // gaps g % 4 == 0 carry the operand wait + two K reads (and a DMA piece in the early plan)
+            if ((g & 3) == 0) {
+                if (!dma_late) dm = d++;
+            } else if (e < n_phase1) {
+                // spread n_phase1 units over the 24 gaps with g % 4 != 0
+                const int slot = (g >> 2) * 3 + (g & 3) - 1;          // 0..23
+                if ((slot + 1) * n_phase1 / 24 > slot * n_phase1 / 24) ne = 1;
+            }
+        } else {
+            if ((h & 1) && h <= 21 && e < 32) {                       // odd gaps up to 53: the rest of the units
+                const int gaps_left = (21 - h) / 2 + 1;
+                ne = (32 - e + gaps_left - 1) / gaps_left;            // 1, or 2 while behind
+            }
+            if (h < 24) {
+                if (!(h & 1)) nm = 2;                                 // even gaps (with the V reads): 2
+                else if (h >= 9) nm = 1;                              // late odd gaps: 1  -> 24 + 8 = 32
+            }
+            if (dma_late && h >= 24) dm = d++;
+            if (h >= 25 && h <= 30) tl = h - 24;                      // chain steps 1..6
+        }
+        p.exp_first[g] = (signed char)e; p.exp_n[g] = (signed char)ne; e += ne;
+        p.max_first[g] = (signed char)m; p.max_n[g] = (signed char)nm; m += nm;
+        p.dma[g] = (signed char)dm; p.tail[g] = (signed char)tl;
+    }
+    return p;
+}
+constexpr bool plan64_ok(const Plan64 &p) {
+    int e = 0, m = 0, d = 0;
+    for (int g = 0; g < 64; ++g) {
+        // P of 16-key slice s16 is consumed from gap 32 + 8 s16 on: its units must be >= 2 gaps older
+        for (int u = p.exp_first[g]; u < p.exp_first[g] + p.exp_n[g]; ++u)
+            if (g + 2 > 32 + 8 * (u >> 3)) return false;
+        // S(it+1) tiles: nt = 0 last written at gap 29, nt = 1 at gap 31; read >= 2 MFMAs later
+        for (int u = p.max_first[g]; u < p.max_first[g] + p.max_n[g]; ++u)
+            if (g < ((u >> 4) ? 34 : 32)) return false;
+        if (p.tail[g] && m + p.max_n[g] < 32 && p.tail[g] == 1) return false;
+        e += p.exp_n[g]; m += p.max_n[g]; d += p.dma[g] >= 0;
+        if (p.tail[g] == 1 && m < 32) return false;
+    }
+    return e == 32 && m == 32 && d == 8;
+}
 
 // ---------------------------------------------------------------------------------
 // The kernel.  d_head = 128 is the reference's scope (README.md:7-15); D = 64 is a widener.
@@ -704,13 +772,21 @@ fa_fwd_kernel(const KernelArgs args) {
         // not schedule or hazard-pad them, so the stream is pinned gap by gap (one MFMA + its
         // fillers, then sched_barrier(0)) and the wait states are kept by distance:
         //   * S(it+1) is accumulated in phase 1 and first read (row max) >= 2 MFMAs later;
-        //   * a packed P operand is consumed >= 1 step after its v_cvt_pk;
+        //   * a packed P operand is consumed >= 2 gaps after its v_cvt_pk;
         //   * O is read by VALU only in the rare rescale and in the epilogue, behind s_nop pads.
         // One wave per SIMD hides about five single-issue instructions per 32-cycle MFMA
         // (MI355X_MICROARCH.md, per-instruction constants), so the softmax of tile `it` is cut
-        // into 32 two-element units {2 fma, 2 exp2, 2 add, 1 pack} and dealt over the gaps:
-        //   phase 1 (32 MFMAs, S(it+1) = K(it+1) Q^T): K operand reads, 8 DMA pieces, 20 units
-        //   phase 2 (32 MFMAs, O += V(it) P(it)):      V operand reads, 12 units, row max of S(it+1)
+        // into 32 two-element units {2 fma, 2 exp2, 2 add, 1 pack} and dealt over the gaps by
+        // a compile-time plan (Plan64):
+        //   phase 1 (32 MFMAs, S(it+1) = K(it+1) Q^T): K operand reads, most of the units
+        //   phase 2 (32 MFMAs, O += V(it) P(it)):      V operand reads, the other units, the row max
+        //            of S(it+1), the 8 DMA pieces of the tiles three visits ahead, the m / rescale test
+        // K and V each ring through 4 LDS stages (128 KB; the 512-register waves allow one
+        // workgroup per CU anyway).  A tile is requested three visits before it is read and must have
+        // landed two visits after the request: the wait in front of the per-visit barrier is
+        // COUNTED (vmcnt(8): the youngest visit's pieces stay in flight), so an HBM-latency fetch
+        // does not stall the matrix pipe, and the barrier publishes a tile one visit early, which
+        // lets the last gaps of a visit prefetch the next visit's first operands.
         //
         // Rescaling is lazy: O and l stay relative to a reference max m that is only moved (and
         // O, l multiplied by 2^((m_old - m_new) c)) when some row's max rose by more than
@@ -718,8 +794,11 @@ fa_fwd_kernel(const KernelArgs args) {
         // reference's eager rescale (softmax.cuh:36-49); only the rounding point of P differs,
         // with the same relative error.  With O in the accumulator file a rescale costs ~200
         // issue slots per Q tile, and for random data some row of 32 finds a new max in most tiles.
-        static_assert(DMA && !MASK && D == 128 && BC == 64 && NT == 2, "64-row pinned schedule: DMA, d=128, B_c=64");
+        static_assert(DMA && !MASK && D == 128 && BC == 64 && NT == 2 && NWAVES == 4, "64-row pinned schedule");
+        static_assert(TR::kStages == 4, "ring depth");
         constexpr float TAU = 8.0f;
+        constexpr Plan64 plan = make_plan64((ABL & 256) != 0, (ABL & 512) ? 24 : ((ABL & 1024) ? 20 : 22));
+        static_assert(plan64_ok(plan), "filler plan violates a wait-state distance");
         f32x16 Sa[2][NT], Sb[2][NT];
         u32x4 Pw[2][4];          // P[qt][16-key slice]: B operand of O^T += V^T P^T
         float neg_msc[2];        // -(m c)
@@ -742,15 +821,35 @@ fa_fwd_kernel(const KernelArgs args) {
             if (ks == 0) E::mfma_acc_v_q0(S[qt][nt], a, Qr[qt][ks]);
             else E::mfma_acc_v_q(S[qt][nt], a, Qr[qt][ks]);
         };
-        auto visit = [&](int it, auto &S_cur, auto &S_nxt) {
-            wait_and_barrier();
-            // next tiles' DMA: K(it+2) -> stage it&1, V(it+1) -> stage (it+1)&1.  Past the end the
-            // last tile is fetched again into a stage nobody reads: no branch in the stream.
-            const int itk = it + 2 < n_kv ? it + 2 : n_kv - 1, itv = it + 1 < n_kv ? it + 1 : n_kv - 1;
-            const uint16_t *kb = Kg + (int64_t)(n_kv - 1 - itk) * tile_stride;
-            const uint16_t *vb = Vg + (int64_t)(n_kv - 1 - itv) * tile_stride;
-            const unsigned kdst = smem_base + (it & 1) * TILE + wave * 1024;
-            const unsigned vdst = smem_base + V_BASE + ((it + 1) & 1) * TILE + wave * 1024;
+        // tile j (visit index) -> global pointer; past the end the last tile is fetched again into
+        // a stage nobody reads, so the instruction stream has no branch and the DMA count per
+        // visit is constant (the counted wait depends on it)
+        auto tile_ptr = [&](const uint16_t *T, int j) {
+            j = j < n_kv ? j : n_kv - 1;
+            return T + (int64_t)(n_kv - 1 - j) * tile_stride;
+        };
+        auto dma_k = [&](int tile, int stage) {
+            const uint16_t *src = tile_ptr(Kg, tile);
+#pragma unroll
+            for (int j = 0; j < DMA_PER_WAVE; ++j)
+                glds16_sv_m0(src, k_off[j], smem_base + stage * TILE + (wave + NWAVES * j) * 1024);
+        };
+        auto dma_v = [&](int tile, int stage) {
+            const uint16_t *src = tile_ptr(Vg, tile);
+#pragma unroll
+            for (int j = 0; j < DMA_PER_WAVE; ++j)
+                glds16_sv_m0(src, v_off[j], smem_base + V_BASE + stage * TILE + (wave + NWAVES * j) * 1024);
+        };
+        const uint16_t *kq = tile_ptr(Kg, 4), *vq = tile_ptr(Vg, 3);  // next tiles to request
+        vec8 ring[4];  // operand ring: slot u % 4, rewritten two steps after the MFMAs that read it
+        auto visit = [&](int it, auto &S_cur, auto &S_nxt, auto r_tag) {
+            constexpr int R = decltype(r_tag)::value;  // it & 3
+            // K(it+2), V(it+1) landed (requested two visits ago; K(it+1), V(it) were published by
+            // the previous barrier); the 8 youngest pieces may fly on
+            if (!(ABL & 8)) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            barrier();
+            const unsigned kdst = smem_base + R * TILE + wave * 1024;                        // K(it+4) -> stage of K(it)
+            const unsigned vdst = smem_base + V_BASE + ((R + 3) & 3) * TILE + wave * 1024;   // V(it+3) -> stage of V(it-1)
 #pragma unroll
             for (int qt = 0; qt < 2; ++qt) {
                 if (resc[qt]) {  // wave-uniform, rare
@@ -765,12 +864,13 @@ fa_fwd_kernel(const KernelArgs args) {
                         for (int r = 0; r < 16; ++r) O[qt][t][r] *= alpha;
                 }
             }
-            const char *kt = smem + ((it + 1) & 1) * TILE;
-            const char *vt = smem + V_BASE + (it & 1) * TILE;
+            const char *kt = smem + ((R + 1) & 3) * TILE;
+            const char *vt = smem + V_BASE + R * TILE;
             float rs[2][2] = {{0.0f, 0.0f}, {0.0f, 0.0f}};
-            float vm[2];
+            float vm[2], m_new[2];
             auto exp_unit = [&](int u) {  // u = 8*s16 + 2*j + qt: in the order P.V consumes P
                 const int qt = u & 1, j = (u >> 1) & 3, s16 = u >> 3;
+                if constexpr (ABL & 2) return;
                 const int r = 8 * (s16 & 1) + 2 * j;
                 float p0 = __builtin_fmaf(S_cur[qt][s16 >> 1][r], c, neg_msc[qt]);
                 float p1 = __builtin_fmaf(S_cur[qt][s16 >> 1][r + 1], c, neg_msc[qt]);
@@ -778,58 +878,71 @@ fa_fwd_kernel(const KernelArgs args) {
                     p0 = __builtin_amdgcn_exp2f(p0);
                     p1 = __builtin_amdgcn_exp2f(p1);
                 }
-                rs[qt][0] = vadd(rs[qt][0], p0);  // fp32 P, before rounding (softmax.cuh:66-83)
-                rs[qt][1] = vadd(rs[qt][1], p1);
+                // scalar f32 forms on purpose: v_pk_fma_f32 / v_pk_add_f32 here measured -6 % / -12 %
+                rs[qt][0] += p0;  // fp32 P, before rounding (softmax.cuh:66-83)
+                rs[qt][1] += p1;
                 Pw[qt][s16][j] = E::pack2(p0, p1);
             };
             auto max_unit = [&](int u) {  // u = 0..31: tile (nt = u>>4, qt = (u>>3)&1), elements 2(u&7), +1
                 const int nt = u >> 4, qt = (u >> 3) & 1, e = 2 * (u & 7);
+                if constexpr (ABL & 2) { vm[qt] = 0.0f; return; }
                 if ((u & 7) == 0 && nt == 0) vm[qt] = fmaxf(S_nxt[qt][nt][0], S_nxt[qt][nt][1]);
                 else vm[qt] = vmax3(vm[qt], S_nxt[qt][nt][e], S_nxt[qt][nt][e + 1]);
             };
-            vec8 ring[4];  // operand ring over the 32 operands of a visit (16 K, then 16 V)
-            auto operand = [&](int u) -> vec8 { return u < 16 ? k_frag(kt, u) : v_frag(vt, u - 16); };
-            ring[0] = operand(0);
-            ring[1] = operand(1);
-            __builtin_amdgcn_sched_barrier(0);
+            auto tail_step = [&](int k) {  // end-of-visit chain: row max -> candidate m -> rescale test
+                if (k == 1) vm[0] = pair_max(vm[0]);
+                if (k == 2) vm[1] = pair_max(vm[1]);
+                if (k == 3) { m_new[0] = fmaxf(m[0], vm[0]); m_new[1] = fmaxf(m[1], vm[1]); }
+                if (k == 4) { l[0] += rs[0][0] + rs[0][1]; l[1] += rs[1][0] + rs[1][1]; }
+                if (k == 5) { m_pend[0] = m_new[0]; resc[0] = __any((m_new[0] - m[0]) * c > TAU); }
+                if (k == 6) { m_pend[1] = m_new[1]; resc[1] = __any((m_new[1] - m[1]) * c > TAU); }
+            };
+            // operand u of the visit: 16 K fragments, 16 V fragments, then the first two K fragments
+            // of the NEXT visit (its tile was published by this visit's barrier), so that no LDS
+            // latency is exposed behind the next barrier
+            const char *kt_next = smem + ((R + 2) & 3) * TILE;
+            auto operand = [&](int u) -> vec8 {
+                if constexpr (ABL & 4) return __builtin_bit_cast(vec8, Pw[u & 1][(u >> 1) & 3]);
+                return u < 16 ? k_frag(kt, u) : (u < 32 ? v_frag(vt, u - 16) : k_frag(kt_next, u - 32));
+            };
             static_for<0, 64>([&](auto gap_tag) {
                 constexpr int g = decltype(gap_tag)::value;
                 constexpr int step = g >> 1, qt = g & 1;
-                if constexpr (qt == 0 && step + 2 < 32) ring[(step + 2) % 4] = operand(step + 2);
+                if constexpr (qt == 0 && (step & 1) == 0) {  // operands in pairs: one counted wait per two steps
+                    __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0): operands step, step+1 landed
+                    ring[(step + 2) % 4] = operand(step + 2);
+                    ring[(step + 3) % 4] = operand(step + 3);
+                }
                 if constexpr (g < 32) {
                     qk_mfma(S_nxt, step, qt, ring[step % 4]);
-                    constexpr int g8 = g & 7;
-                    if constexpr ((g & 3) == 0) {  // one 1-KiB DMA piece
-                        constexpr int j = g >> 3;
-                        if constexpr ((g & 4) == 0) glds16_sv(kb, k_off[j], kdst + NWAVES * j * 1024);
-                        else glds16_sv(vb, v_off[j], vdst + NWAVES * j * 1024);
-                    } else if constexpr (g8 != 6) {  // 5 units per 8 gaps: 20 in phase 1
-                        exp_unit(5 * (g >> 3) + (g8 < 4 ? g8 - 1 : (g8 == 5 ? 3 : 4)));
-                    }
                 } else {
-                    constexpr int h = g - 32, s2 = h >> 1, s16 = s2 >> 2, t = s2 & 3;
+                    constexpr int s2 = step - 16, s16 = s2 >> 2, t = s2 & 3;
                     E::mfma_acc_a_p(O[qt][t], ring[step % 4], Pw[qt][s16]);
-                    if constexpr (qt == 1 && h < 24) exp_unit(20 + (h >> 1));  // 12 units, done by gap 55
-                    if constexpr (h < 16) {
-                        if constexpr (qt == 0) { max_unit(h); max_unit(h + 1); }
-                    } else if constexpr (h < 24) {
-                        max_unit(16 + 2 * (h - 16)); max_unit(17 + 2 * (h - 16));
-                    }
                 }
+                if constexpr (plan.dma[g] >= 0 && !(ABL & 16)) {  // one 1-KiB DMA piece
+                    constexpr int j = plan.dma[g] >> 1;
+                    if constexpr ((plan.dma[g] & 1) == 0) glds16_sv_m0(kq, k_off[j], kdst + NWAVES * j * 1024);
+                    else glds16_sv_m0(vq, v_off[j], vdst + NWAVES * j * 1024);
+                }
+                static_for<0, plan.exp_n[g]>([&](auto i) { exp_unit(plan.exp_first[g] + decltype(i)::value); });
+                static_for<0, plan.max_n[g]>([&](auto i) { max_unit(plan.max_first[g] + decltype(i)::value); });
+                if constexpr (plan.tail[g] > 0) tail_step(plan.tail[g]);
                 __builtin_amdgcn_sched_barrier(0);
             });
-#pragma unroll
-            for (int qt = 0; qt < 2; ++qt) {
-                l[qt] += rs[qt][0] + rs[qt][1];
-                const float m_new = fmaxf(m[qt], pair_max(vm[qt]));
-                m_pend[qt] = m_new;
-                resc[qt] = __any((m_new - m[qt]) * c > TAU);
-            }
+            if (it + 5 < n_kv) kq -= tile_stride;
+            if (it + 4 < n_kv) vq -= tile_stride;
         };
-        // prologue: S(0) and its row max, which becomes the first reference max (O = l = 0)
-        wait_and_barrier();
-        issue_k(n_kv > 1 ? 1 : 0, 1);
+        // prologue: K(0), V(0) are in flight (common code); then K(1) | K(2), V(1) | K(3), V(2) in the
+        // order the counted waits assume
+        dma_k(1, 1);
+        dma_k(2, 2);
+        dma_v(1, 1);
+        dma_k(3, 3);
+        dma_v(2, 2);
+        if (!(ABL & 8)) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");  // K(0), V(0), K(1) landed
+        barrier();
         {
+            // S(0) and its row max, which becomes the first reference max (O = l = 0)
             const char *kt = smem;
             static_for<0, 16>([&](auto step_tag) {
                 constexpr int step = decltype(step_tag)::value;
@@ -849,11 +962,15 @@ fa_fwd_kernel(const KernelArgs args) {
                 neg_msc[qt] = -(m[qt] * c);
                 m_pend[qt] = m[qt];
             }
+            ring[0] = k_frag(smem + TILE, 0);  // first operands of visit 0: K(1)
+            ring[1] = k_frag(smem + TILE, 1);
         }
-        // seq_len is a multiple of B_r = 256, so n_kv = seq_len / 64 is even: visits come in pairs
-        for (int it = 0; it < n_kv; it += 2) {
-            visit(it, Sa, Sb);
-            visit(it + 1, Sb, Sa);
+        // seq_len is a multiple of B_r = 256, so n_kv = seq_len / 64 is a multiple of 4 = ring depth
+        for (int it = 0; it < n_kv; it += 4) {
+            visit(it, Sa, Sb, IntTag<0>{});
+            visit(it + 1, Sb, Sa, IntTag<1>{});
+            visit(it + 2, Sa, Sb, IntTag<2>{});
+            visit(it + 3, Sb, Sa, IntTag<3>{});
         }
         dma_wait();  // the re-fetched last tiles must land before the epilogue reuses the LDS
         asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // last P.V -> epilogue reads of O

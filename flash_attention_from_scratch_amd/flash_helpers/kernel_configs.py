@@ -460,12 +460,13 @@ def get_kernel_configs(kernels_key=""):
 
 
 def best_config(dtype=DType.BF16, seq_len=4096) -> FlashForwardKernelConfig:
-    """Autotune winner on MI355X (profiles/): at seq_len >= 4096 the plain loop
-    with 8 waves x 32 rows and 128-key tiles (fewest barriers per key); below that the
-    pipelined 4-wave / 64-key kernel, whose smaller workgroups fill the chip better."""
-    if seq_len >= 4096:
+    """Autotune winner on MI355X (profiles/): from seq_len 2048 up the hand-placed
+    64-rows-per-wave kernel (4 waves x 64 rows, 64-key tiles, one wave per SIMD: each LDS operand
+    feeds two MFMAs); below that the pipelined 4-wave x 32-row kernel, whose smaller workgroups
+    fill the chip better and whose prologue is shorter."""
+    if seq_len >= 2048 and seq_len % 256 == 0:
         return FlashForwardKernelConfig(
-            DType(dtype), 128, 256, 128, 8, True, True, True, 0, 0, 0, False, True
+            DType(dtype), 128, 256, 64, 4, True, True, True, 0, 0, 0, True, False
         )
     return FlashForwardKernelConfig(
         DType(dtype), 128, 128, 64, 4, True, True, True, 0, 0, 0, True, False

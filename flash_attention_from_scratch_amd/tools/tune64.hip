@@ -1,0 +1,84 @@
+// tune64.hip -- A/B timing of experiment knobs (ABL bits >= 256) of the 64-rows-per-wave pinned
+// schedule on the headline shape, random data (the chip is power-limited: constant data
+// clocks ~20 % higher and hides everything).
+#include "../csrc/fa_fwd_kernel.hpp"
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(e_), __LINE__); exit(2); } } while (0)
+
+static uint16_t *q, *k, *v, *o;
+static const int B = 16, H = 16, D = 128;
+static int S = 4096;
+static int only_abl = -1;  // argv: only=<abl>
+static int n_rep = 10;
+
+struct Variant { const char *name; int abl; void (*launch)(const fa::KernelArgs &); double sum_ms; int n; float best; };
+static std::vector<Variant> variants;
+static hipEvent_t e0, e1;
+
+template <int ABL> void launch(const fa::KernelArgs &a) {
+    auto kern = fa::fa_fwd_kernel<15, 2, 4, 64, true, true, true, true, true, false, 128, ABL>;
+    static bool init = false;
+    if (!init) { CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 131072)); init = true; }
+    hipLaunchKernelGGL(kern, dim3(a.n_bh * a.n_q_blocks), dim3(256), 131072, 0, a);
+}
+template <int ABL> void add(const char *name) {
+    if (only_abl >= 0 && ABL != only_abl) return;
+    variants.push_back({name, ABL, launch<ABL>, 0.0, 0, 1e9f});
+}
+// interleaved timing: the chip's clock drifts with temperature / power state by a few percent
+// over seconds, so every round runs every variant and the means are compared
+static void time_all() {
+    fa::KernelArgs a;
+    const int Bx = S > 4096 ? 4 : B;
+    a.q = q; a.k = k; a.v = v; a.o = o;
+    a.batch_stride = (int64_t)S * H * D; a.seq_stride = H * D; a.head_stride = D;
+    a.seq_len = S; a.n_heads = H; a.n_bh = Bx * H; a.n_q_blocks = S / 256; a.n_kv_blocks = S / 64; a.causal = 0;
+    for (auto &v : variants) { v.sum_ms = 0; v.n = 0; v.best = 1e9f; }
+    for (int round = -1; round < n_rep; ++round) {
+        for (auto &v : variants) {
+            for (int i = 0; i < 2; ++i) {
+                CHECK(hipEventRecord(e0));
+                v.launch(a);
+                CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+                float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+                if (round >= 0) { v.sum_ms += ms; v.n++; if (ms < v.best) v.best = ms; }
+            }
+        }
+    }
+    const double fl = 4.0 * Bx * H * (double)S * S * D;
+    for (auto &v : variants)
+        printf("%-40s abl=%5d S=%5d : mean %.4f ms  %7.1f TF   best %7.1f TF\n", v.name, v.abl, S, v.sum_ms / v.n,
+               fl / (v.sum_ms / v.n * 1e-3) / 1e12, fl / (v.best * 1e-3) / 1e12);
+}
+
+int main(int argc, char **argv) {
+    const size_t n = (size_t)B * 4096 * H * D;
+    std::vector<uint16_t> h(n);
+    CHECK(hipMalloc(&q, n * 2)); CHECK(hipMalloc(&k, n * 2)); CHECK(hipMalloc(&v, n * 2)); CHECK(hipMalloc(&o, n * 2));
+    srand(1);
+    bool zeros = false;
+    for (int i = 1; i < argc; ++i) {
+        if (!strcmp(argv[i], "zeros")) zeros = true;
+        if (!strncmp(argv[i], "only=", 5)) only_abl = atoi(argv[i] + 5);
+        if (!strncmp(argv[i], "reps=", 5)) n_rep = atoi(argv[i] + 5);
+    }
+    for (int t = 0; t < 3; ++t) {
+        for (size_t i = 0; i < n; ++i) {
+            float x = zeros ? 0.0f : ((rand() & 0xffff) / 65536.0f - 0.5f) * 3.4f;
+            uint32_t u; memcpy(&u, &x, 4); h[i] = (uint16_t)(u >> 16);
+        }
+        CHECK(hipMemcpy(t == 0 ? q : t == 1 ? k : v, h.data(), n * 2, hipMemcpyHostToDevice));
+    }
+    CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+#define X(abl, name) add<abl>(name);
+#include "tune64_list.inc"
+#undef X
+    for (int pass = 0; pass < 2; ++pass) {
+        S = pass ? 16384 : 4096;
+        time_all();
+    }
+    return 0;
+}

@@ -110,7 +110,8 @@ typedef struct {
 static void q_block_forward(const tensors_t *t, int64_t b, int64_t h, int64_t qb, int B_r,
                             int B_c, int round_p, int optimized_softmax, const float *kf,
                             const float *vf, float *S, float *O, float *m, float *l,
-                            float *qrow, float *m_trace, float *l_trace, int causal) {
+                            float *qrow, float *m_trace, float *l_trace, int causal,
+                            float lazy_tau) {
     const int64_t d = t->d;
     /* Scope wideners (not in the reference): seq need not be a multiple of the
      * tiles, and an optional causal mask.  Masked logits are -inf; a row whose keys were all
@@ -142,6 +143,52 @@ static void q_block_forward(const tensors_t *t, int64_t b, int64_t h, int64_t qb
                 S[r * B_c + cidx] = acc;
             }
         }
+        /* Lazy-rescale restatement (lazy_tau > 0; NOT the reference's arithmetic, which is the
+         * branch below): the MI355X 64-rows-per-wave kernel keeps O and l relative to a
+         * reference max m that moves only when, in a 32-row group (one wave's Q tile), some
+         * row's max rose by more than lazy_tau in the base-2 exponent; then every row of the
+         * group moves to its own running max.  Same real-valued result as softmax.cuh:36-49;
+         * P is bounded by 2^lazy_tau instead of 1. */
+        if (lazy_tau > 0.0f) {
+            for (int g0 = 0; g0 < rows; g0 += 32) {
+                const int g1 = g0 + 32 < rows ? g0 + 32 : (int)rows;
+                int need = 0;
+                for (int r = g0; r < g1; ++r) {
+                    float *s = S + r * B_c;
+                    float mx = s[0];
+                    for (int cidx = 1; cidx < B_c; ++cidx) mx = fmaxf(mx, s[cidx]);
+                    if (is_first) m[r] = mx;
+                    else {
+                        const float m_new = fmaxf(m[r], mx);
+                        if ((m_new - m[r]) * c > lazy_tau) need = 1;
+                    }
+                }
+                if (need) {
+                    for (int r = g0; r < g1; ++r) {
+                        float *s = S + r * B_c;
+                        float mx = s[0];
+                        for (int cidx = 1; cidx < B_c; ++cidx) mx = fmaxf(mx, s[cidx]);
+                        const float m_new = fmaxf(m[r], mx);
+                        const float scale = exp2f((m[r] - m_new) * c);
+                        m[r] = m_new;
+                        l[r] *= scale;
+                        float *orow = O + r * d;
+                        for (int64_t x = 0; x < d; ++x) orow[x] *= scale;
+                    }
+                }
+                for (int r = g0; r < g1; ++r) {
+                    float *s = S + r * B_c;
+                    const float max_scaled = m[r] * c;
+                    float rowsum = 0.0f;
+                    for (int cidx = 0; cidx < B_c; ++cidx) {
+                        const float p = exp2f(fmaf(s[cidx], c, -max_scaled));
+                        rowsum += p;
+                        s[cidx] = round_p ? round_b16(p, t->dtype) : p;
+                    }
+                    l[r] += rowsum;
+                }
+            }
+        } else
         /* local_softmax, softmax.cuh:85-105 */
         for (int r = 0; r < rows; ++r) {
             float *s = S + r * B_c;
@@ -198,7 +245,7 @@ static int blockwise_impl(const uint16_t *q, const uint16_t *k, const uint16_t *
                           int64_t heads, int64_t d_head, int64_t batch_stride,
                           int64_t seq_stride, int64_t head_stride, int B_r, int B_c,
                           int round_p, int optimized_softmax, float *m_trace,
-                          float *l_trace, int n_threads, int masked, int causal) {
+                          float *l_trace, int n_threads, int masked, int causal, float lazy_tau) {
     if (dtype != FA_ORACLE_FP16 && dtype != FA_ORACLE_BF16) return -1;
     if (B_r <= 0 || B_c <= 0 || seq <= 0) return -2;
     if (!masked && (seq % B_r != 0 || seq % B_c != 0)) return -2;
@@ -236,7 +283,8 @@ static int blockwise_impl(const uint16_t *q, const uint16_t *k, const uint16_t *
                 }
                 for (int64_t qb = 0; qb < n_q; ++qb)
                     q_block_forward(&t, b, h, qb, B_r, B_c, round_p, optimized_softmax, kf, vf,
-                                    S, O, ml, ml + B_r, ml + 2 * B_r, m_trace, l_trace, causal);
+                                    S, O, ml, ml + B_r, ml + 2 * B_r, m_trace, l_trace, causal,
+                                    lazy_tau);
             }
         }
         free(kf); free(vf); free(S); free(O); free(ml);
@@ -252,7 +300,17 @@ int fa_oracle_forward_blockwise(const uint16_t *q, const uint16_t *k, const uint
                                 float *l_trace, int n_threads) {
     return blockwise_impl(q, k, v, o, dtype, batch, seq, heads, d_head, batch_stride, seq_stride,
                           head_stride, B_r, B_c, round_p, optimized_softmax, m_trace, l_trace,
-                          n_threads, 0, 0);
+                          n_threads, 0, 0, 0.0f);
+}
+
+/* The lazy-rescale restatement (see q_block_forward): pins the 64-rows-per-wave device variant. */
+int fa_oracle_forward_blockwise_lazy(const uint16_t *q, const uint16_t *k, const uint16_t *v,
+                                     uint16_t *o, int dtype, int64_t batch, int64_t seq,
+                                     int64_t heads, int64_t d_head, int64_t batch_stride,
+                                     int64_t seq_stride, int64_t head_stride, int B_r, int B_c,
+                                     float tau, int n_threads) {
+    return blockwise_impl(q, k, v, o, dtype, batch, seq, heads, d_head, batch_stride, seq_stride,
+                          head_stride, B_r, B_c, 1, 0, NULL, NULL, n_threads, 0, 0, tau);
 }
 
 /* Widened modes (causal mask, any seq): same arithmetic, see q_block_forward. */
@@ -263,7 +321,7 @@ int fa_oracle_forward_blockwise_masked(const uint16_t *q, const uint16_t *k, con
                                        int optimized_softmax, int causal, int n_threads) {
     return blockwise_impl(q, k, v, o, dtype, batch, seq, heads, d_head, batch_stride, seq_stride,
                           head_stride, B_r, B_c, 1, optimized_softmax, NULL, NULL, n_threads, 1,
-                          causal);
+                          causal, 0.0f);
 }
 
 /*

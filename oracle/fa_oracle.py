@@ -63,6 +63,11 @@ def lib():
             u16p, u16p, u16p, u16p, ctypes.c_int, i64, i64, i64, i64, i64, i64, i64,
             ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
         ]
+        L.fa_oracle_forward_blockwise_lazy.restype = ctypes.c_int
+        L.fa_oracle_forward_blockwise_lazy.argtypes = [
+            u16p, u16p, u16p, u16p, ctypes.c_int, i64, i64, i64, i64, i64, i64, i64,
+            ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_int,
+        ]
         L.fa_oracle_forward_eager.restype = ctypes.c_int
         L.fa_oracle_forward_eager.argtypes = [
             u16p, u16p, u16p, u16p, ctypes.c_void_p, ctypes.c_int, i64, i64, i64, i64,
@@ -111,6 +116,22 @@ def blockwise_forward(q, k, v, B_r, B_c, round_p=True, optimized_softmax=False,
     if rc != 0:
         raise RuntimeError(f"fa_oracle_forward_blockwise failed: {rc}")
     return (o, m, l) if return_stats else o
+
+
+def blockwise_forward_lazy(q, k, v, B_r, B_c, tau=8.0, n_threads=0):
+    """Lazy-rescale restatement (NOT the reference's arithmetic: the MI355X 64-rows-per-wave
+    variant's): O and l stay relative to a reference max that moves only when a row's max rose by
+    more than `tau` in the base-2 exponent somewhere in its 32-row group."""
+    _check(q, k, v)
+    B, S, H, D = q.shape
+    o = torch.empty_like(q)
+    rc = lib().fa_oracle_forward_blockwise_lazy(
+        q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), _code(q.dtype),
+        B, S, H, D, q.stride(0), q.stride(1), q.stride(2), B_r, B_c, float(tau), n_threads,
+    )
+    if rc != 0:
+        raise RuntimeError(f"fa_oracle_forward_blockwise_lazy failed: {rc}")
+    return o
 
 
 def blockwise_forward_masked(q, k, v, B_r, B_c, causal=False, optimized_softmax=False, n_threads=0):

@@ -175,6 +175,29 @@ def test_online_softmax_rescale_is_exercised():
         assert (out.float() - ref.float()).abs().max().item() <= 2 * TOL[dtype]
 
 
+def test_64_row_variant_against_its_lazy_rescale_restatement():
+    """(B_r 256, B_c 64, 4 waves, buffer) keeps O and l relative to a reference max that moves
+    only past a threshold.  Checked against the CPU restatement of exactly that
+    arithmetic and against fp32 eager, on data whose row maxima keep rising along the visit order
+    (keys near the start of the sequence are visited last)."""
+    for dtype, name in ((torch.bfloat16, kc.DType.BF16), (torch.float16, kc.DType.FP16)):
+        cfg = kc.FlashForwardKernelConfig(name, 128, 256, 64, 4, True, True, True, 0, 0, 0, True, False)
+        qc = ut.QKVConfig(n_heads=2, d_head=128, batch_size=1, seq_len=1024, dtype=dtype,
+                          device=torch.device(DEV))
+        q, k, v = ut.generate_qkv(qc, seed=31)
+        stair = (k.float() * torch.linspace(8, 1, 1024, device=DEV).view(1, -1, 1, 1)).to(dtype)
+        spike = k.clone()
+        spike[0, 5, 0] = q[0, 700, 0] * 3.0
+        for kk in (k, stair, spike):
+            out = flash_attention.forward(cfg, q, kk, v)
+            ref = ut.py_flash_attention(q, kk, v, upcast=True).float()
+            oracle = fo.blockwise_forward_lazy(q.cpu(), kk.cpu(), v.cpu(), 256, 64).float()
+            assert torch.isfinite(out.float()).all()
+            tol = TOL[dtype] * (1 + ref.abs())
+            assert ((out.float() - ref).abs() <= tol).all()
+            assert ((out.float().cpu() - oracle).abs() <= tol.cpu()).all()
+
+
 def test_error_behaviour_matches_reference():
     cfg = kc.best_config(kc.DType.BF16)
     q = torch.zeros((1, 512, 2, 128), dtype=torch.bfloat16, device=DEV)

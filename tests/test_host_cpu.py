@@ -38,6 +38,8 @@ def test_every_enumerated_config_has_a_device_kernel():
         assert _capi.supported(cfg), cfg
         lds = _capi.lds_bytes(cfg)
         stages = 2 if cfg.eager_load_blocks else 1
+        if (cfg.d_head, cfg.B_r, cfg.B_c, cfg.n_warps, cfg.mma_double_buffer_loads) == (128, 256, 64, 4, True):
+            stages = 4  # the 64-rows-per-wave schedule rings K and V through 4 stages each
         # K/V stages, or the O tile staged through LDS in the epilogue, whichever is larger
         assert lds == max(2 * stages * cfg.B_c * cfg.d_head * 2, cfg.B_r * cfg.d_head * 2)
         assert lds <= 160 * 1024

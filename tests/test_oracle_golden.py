@@ -45,6 +45,40 @@ def test_c_blockwise_optimized_softmax_is_same_arithmetic(tag, case):
 
 
 @pytest.mark.parametrize("tag,case", CASES)
+def test_c_lazy_rescale_restatement_meets_the_reference_bars(tag, case):
+    """The 64-rows-per-wave device variant moves its reference max lazily.  Its
+    CPU restatement must meet the same bars as the reference's arithmetic on the reference's
+    fixtures; with a vanishing threshold it rescales whenever a max moves, which IS the
+    reference's arithmetic, bit for bit."""
+    g = load_eager_golden(tag, case)
+    S = g["q"].shape[1]
+    B_r = 256 if S % 256 == 0 else 64
+    out = fo.blockwise_forward_lazy(g["q"], g["k"], g["v"], B_r, 64, tau=8.0)
+    assert (out.float() - g["o_f32"].float()).abs().max().item() <= 2 * ULP[tag]
+    lhs, rhs = fo.tolerance_rule(out, g["o_b16"], g["o_f32"])
+    assert lhs <= rhs
+    # an (almost) zero threshold rescales whenever a max moves: the reference's arithmetic
+    eager_rescale = fo.blockwise_forward_lazy(g["q"], g["k"], g["v"], B_r, 64, tau=1e-30)
+    assert torch.equal(eager_rescale, fo.blockwise_forward(g["q"], g["k"], g["v"], B_r, 64))
+
+
+def test_c_lazy_rescale_staircase_logits():
+    """Row maxima that keep rising along the visit order (keys near the start of the sequence are
+    larger and are visited last) cross the threshold several times, in fp16 too (P <= 2^8)."""
+    torch.manual_seed(3)
+    for dtype, ulp in ((torch.bfloat16, 2.0 ** -9), (torch.float16, 2.0 ** -12)):
+        q, k, v = (torch.randn(1, 1024, 2, 128).to(dtype) for _ in range(3))
+        k = (k.float() * torch.linspace(8, 1, 1024).view(1, -1, 1, 1)).to(dtype)
+        ref = fo.eager_attention(q, k, v, upcast=True).float()
+        lazy = fo.blockwise_forward_lazy(q, k, v, 256, 64).float()
+        exact = fo.blockwise_forward(q, k, v, 256, 64).float()
+        assert torch.isfinite(lazy).all()
+        tol = 4 * ulp * (1 + ref.abs())
+        assert ((lazy - ref).abs() <= tol).all()
+        assert ((exact - ref).abs() <= tol).all()
+
+
+@pytest.mark.parametrize("tag,case", CASES)
 def test_c_eager_matches_reference_eager(tag, case):
     g = load_eager_golden(tag, case)
     e32 = fo.eager_forward_c(g["q"], g["k"], g["v"], upcast=True)
