@@ -459,12 +459,25 @@ def get_kernel_configs(kernels_key=""):
     raise ValueError(f"Invalid kernels env key: {kernels_key}")
 
 
-def best_config(dtype=DType.BF16, seq_len=4096) -> FlashForwardKernelConfig:
+def uses_lazy_rescale(cfg) -> bool:
+    """True for the config served by the 64-rows-per-wave device schedule, whose softmax moves
+    its reference max lazily (CPU restatement: oracle blockwise_forward_lazy)."""
+    return (cfg.d_head, cfg.B_r, cfg.B_c, cfg.n_warps, bool(cfg.mma_double_buffer_loads)) == (128, 256, 64, 4, True)
+
+
+def best_config(dtype=DType.BF16, seq_len=4096, masked=False) -> FlashForwardKernelConfig:
     """Autotune winner on MI355X (profiles/): from seq_len 2048 up the hand-placed
     64-rows-per-wave kernel (4 waves x 64 rows, 64-key tiles, one wave per SIMD: each LDS operand
     feeds two MFMAs); below that the pipelined 4-wave x 32-row kernel, whose smaller workgroups
-    fill the chip better and whose prologue is shorter."""
-    if seq_len >= 2048 and seq_len % 256 == 0:
+    fill the chip better and whose prologue is shorter.  masked=True: the best config that has a
+    causal / ragged-length variant (forward_ex): 8 waves x 32 rows with 128-key tiles from
+    seq_len 4096 up."""
+    if masked:
+        if seq_len >= 4096:
+            return FlashForwardKernelConfig(
+                DType(dtype), 128, 256, 128, 8, True, True, True, 0, 0, 0, False, True
+            )
+    elif seq_len >= 2048 and seq_len % 256 == 0:
         return FlashForwardKernelConfig(
             DType(dtype), 128, 256, 64, 4, True, True, True, 0, 0, 0, True, False
         )

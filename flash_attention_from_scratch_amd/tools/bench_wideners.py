@@ -26,7 +26,7 @@ def main():
     print("shape (B,S,H) | mode | kernel ms | TFLOP/s (useful) | torch SDPA ms | TFLOP/s")
     for dtype, name in ((torch.bfloat16, kc.DType.BF16),):
         for B, S, H in ((4, 4096, 16), (4, 4000, 16), (2, 16384, 16), (16, 1000, 16)):
-            cfg = kc.best_config(name, S)
+            cfg = kc.best_config(name, S, masked=True)
             qc = ut.QKVConfig(n_heads=H, d_head=128, batch_size=B, seq_len=S, dtype=dtype, device=torch.device("cuda:0"))
             q, k, v = ut.generate_qkv(qc, seed=0)
             o = torch.empty_like(q)

@@ -71,8 +71,11 @@ def test_golden_fixtures(cfg, case):
     assert err <= TOL[g["dtype"]], err
     lhs, rhs = fo.tolerance_rule(out, g["o_b16"], g["o_f32"])
     assert lhs <= rhs, (lhs, rhs)
-    ref = fo.blockwise_forward(g["q"], g["k"], g["v"], cfg.B_r, cfg.B_c,
-                               optimized_softmax=cfg.optimized_softmax)
+    if kc.uses_lazy_rescale(cfg):
+        ref = fo.blockwise_forward_lazy(g["q"], g["k"], g["v"], cfg.B_r, cfg.B_c)
+    else:
+        ref = fo.blockwise_forward(g["q"], g["k"], g["v"], cfg.B_r, cfg.B_c,
+                                   optimized_softmax=cfg.optimized_softmax)
     assert (out.float() - ref.float()).abs().max().item() <= TOL[g["dtype"]]
 
 
@@ -307,7 +310,7 @@ def test_masked_variant_equals_plain_kernel_when_nothing_is_masked():
 
 
 def test_reference_errors_unchanged_without_the_wideners():
-    cfg = kc.best_config(kc.DType.BF16)
+    cfg = kc.best_config(kc.DType.BF16, masked=True)
     q = torch.zeros((1, 320, 2, 128), dtype=torch.bfloat16, device=DEV)
     with pytest.raises(RuntimeError, match="multiples of B_r"):
         flash_attention.forward(cfg, q, q, q)
@@ -319,7 +322,7 @@ def test_reference_errors_unchanged_without_the_wideners():
 
 def test_causal_full_size_timing_sanity():
     """C1 shape, causal: about half the FLOPs -> clearly faster than the full mask."""
-    cfg = kc.best_config(kc.DType.BF16)
+    cfg = kc.best_config(kc.DType.BF16, masked=True)
     qc = ut.QKVConfig(n_heads=16, d_head=128, batch_size=4, seq_len=4096, dtype=torch.bfloat16,
                       device=torch.device(DEV))
     q, k, v = ut.generate_qkv(qc, seed=0)
