@@ -80,6 +80,7 @@ struct KernelArgs {
 #ifdef FA_TRACE
     unsigned long long *trace;  // tools/segment_timer.hip only: [wave][visit][8] s_memtime stamps
     int32_t trace_block;
+    int32_t trace_visit;        // tools/trace64.hip: the one visit whose gap stamps are recorded
 #endif
 };
 
@@ -198,6 +199,11 @@ static FA_DEV float vmax3(float a, float b, float c) {
     asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
     return d;
 }
+static FA_DEV float vmax2(float a, float b) {
+    float d;
+    asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
 static FA_DEV float vadd(float a, float b) {
     float d;
     asm("v_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
@@ -314,23 +320,28 @@ struct Plan64 {
     signed char max_first[64], max_n[64];  // row-max units over S(it+1), 32 per visit
     signed char dma[64];                   // DMA piece 0..7 (even = K, odd = V) or -1
     signed char tail[64];                  // end-of-visit chain step 1.. or 0
+    signed char barrier[64];               // 1: the visit's counted DMA wait + workgroup barrier
 };
-constexpr Plan64 make_plan64(bool dma_late, int n_phase1) {
+// variant bits (tools/tune64.hip): 1 barrier at the visit top instead of inside the MFMA stream,
+// 2 DMA pieces late in phase 2 instead of early in phase 1
+constexpr Plan64 make_plan64(int variant, int n_phase1) {
     Plan64 p{};
+    const bool bar_top = variant & 1, dma_late = variant & 2;
     int e = 0, m = 0, d = 0;
     for (int g = 0; g < 64; ++g) {
         const int h = g - 32;
         int ne = 0, nm = 0, dm = -1, tl = 0;
         if (g < 32) {
-            // gaps g % 4 == 0 carry the operand wait + two K reads (and a DMA piece in the early plan)
+            // gaps g % 4 == 0 carry the operand wait + two K reads; gap 2 the barrier; the DMA
+            // pieces follow it, one per four gaps
             if ((g & 3) == 0) {
-                if (!dma_late) dm = d++;
-            } else if (e < n_phase1) {
-                // spread n_phase1 units over the 24 gaps with g % 4 != 0
-                const int slot = (g >> 2) * 3 + (g & 3) - 1;          // 0..23
+                if (!dma_late && (bar_top || g >= 4)) dm = d++;
+            } else if (e < n_phase1 && (bar_top || g != 2)) {
+                const int slot = (g >> 2) * 3 + (g & 3) - 1;          // 0..23 over the gaps with g % 4 != 0
                 if ((slot + 1) * n_phase1 / 24 > slot * n_phase1 / 24) ne = 1;
             }
         } else {
+            if (!dma_late && d < 8 && h == 0) dm = d++;               // the eighth early piece
             if ((h & 1) && h <= 21 && e < 32) {                       // odd gaps up to 53: the rest of the units
                 const int gaps_left = (21 - h) / 2 + 1;
                 ne = (32 - e + gaps_left - 1) / gaps_left;            // 1, or 2 while behind
@@ -340,16 +351,17 @@ constexpr Plan64 make_plan64(bool dma_late, int n_phase1) {
                 else if (h >= 9) nm = 1;                              // late odd gaps: 1  -> 24 + 8 = 32
             }
             if (dma_late && h >= 24) dm = d++;
-            if (h >= 25 && h <= 30) tl = h - 24;                      // chain steps 1..6
+            if (h >= 24) tl = h - 23;                                 // chain steps 1..8
         }
         p.exp_first[g] = (signed char)e; p.exp_n[g] = (signed char)ne; e += ne;
         p.max_first[g] = (signed char)m; p.max_n[g] = (signed char)nm; m += nm;
         p.dma[g] = (signed char)dm; p.tail[g] = (signed char)tl;
+        p.barrier[g] = (!bar_top && g == 2) ? 1 : 0;
     }
     return p;
 }
 constexpr bool plan64_ok(const Plan64 &p) {
-    int e = 0, m = 0, d = 0;
+    int e = 0, m = 0, d = 0, bar = -1;
     for (int g = 0; g < 64; ++g) {
         // P of 16-key slice s16 is consumed from gap 32 + 8 s16 on: its units must be >= 2 gaps older
         for (int u = p.exp_first[g]; u < p.exp_first[g] + p.exp_n[g]; ++u)
@@ -357,9 +369,11 @@ constexpr bool plan64_ok(const Plan64 &p) {
         // S(it+1) tiles: nt = 0 last written at gap 29, nt = 1 at gap 31; read >= 2 MFMAs later
         for (int u = p.max_first[g]; u < p.max_first[g] + p.max_n[g]; ++u)
             if (g < ((u >> 4) ? 34 : 32)) return false;
-        if (p.tail[g] && m + p.max_n[g] < 32 && p.tail[g] == 1) return false;
-        e += p.exp_n[g]; m += p.max_n[g]; d += p.dma[g] >= 0;
         if (p.tail[g] == 1 && m < 32) return false;
+        if (p.barrier[g]) bar = g;
+        if (p.dma[g] >= 0 && bar >= 0 && g <= bar) return false;      // DMA overwrites what the barrier frees
+        if (p.barrier[g] && g >= 28) return false;                    // V(it+1) is first read at gap 30
+        e += p.exp_n[g]; m += p.max_n[g]; d += p.dma[g] >= 0;
     }
     return e == 32 && m == 32 && d == 8;
 }
@@ -797,13 +811,13 @@ fa_fwd_kernel(const KernelArgs args) {
         static_assert(DMA && !MASK && D == 128 && BC == 64 && NT == 2 && NWAVES == 4, "64-row pinned schedule");
         static_assert(TR::kStages == 4, "ring depth");
         constexpr float TAU = 8.0f;
-        constexpr Plan64 plan = make_plan64((ABL & 256) != 0, (ABL & 512) ? 24 : ((ABL & 1024) ? 20 : 22));
+        constexpr Plan64 plan = make_plan64((ABL >> 8) & 3, (ABL & 1024) ? 20 : 22);
         static_assert(plan64_ok(plan), "filler plan violates a wait-state distance");
         f32x16 Sa[2][NT], Sb[2][NT];
         u32x4 Pw[2][4];          // P[qt][16-key slice]: B operand of O^T += V^T P^T
         float neg_msc[2];        // -(m c)
         float m_pend[2];         // candidate reference max found during the previous visit
-        bool resc[2] = {false, false};
+        unsigned resc_any = 0;   // bit qt: Q tile qt moves its reference max at the next visit's top
         auto k_frag = [&](const char *kt, int step) -> vec8 {  // step = 2*ks + nt
             const int ks = step >> 1, nt = step & 1;
             return *(const vec8 *)(kt + nt * 32 * ROWB + ka_base + (((2 * ks + hi) ^ ka_swz) << 4));
@@ -844,16 +858,30 @@ fa_fwd_kernel(const KernelArgs args) {
         vec8 ring[4];  // operand ring: slot u % 4, rewritten two steps after the MFMAs that read it
         auto visit = [&](int it, auto &S_cur, auto &S_nxt, auto r_tag) {
             constexpr int R = decltype(r_tag)::value;  // it & 3
-            // K(it+2), V(it+1) landed (requested two visits ago; K(it+1), V(it) were published by
-            // the previous barrier); the 8 youngest pieces may fly on
-            if (!(ABL & 8)) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            barrier();
+#ifdef FA_TRACE
+            unsigned long long ts[20];
+            asm volatile("s_memtime %0" : "=s"(ts[0]));
+#endif
+            // the visit's synchronisation point: K(it+2), V(it+1) landed (requested two visits ago;
+            // K(it+1), V(it) were published by the previous barrier), the 8 youngest pieces may fly
+            // on; behind it every wave has finished visit it-1, whose K / V stages the DMA of this
+            // visit overwrites.  In the default plan it sits two MFMAs into the visit, after the
+            // gap-0 lgkmcnt(0) that retires this wave's last LDS reads of visit it-1.
+            auto sync_point = [&]() {
+                if (ABL & 8) return;
+                asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+            };
+            if constexpr (plan.barrier[2] == 0) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                sync_point();
+            }
             const unsigned kdst = smem_base + R * TILE + wave * 1024;                        // K(it+4) -> stage of K(it)
             const unsigned vdst = smem_base + V_BASE + ((R + 3) & 3) * TILE + wave * 1024;   // V(it+3) -> stage of V(it-1)
+            if (resc_any) {  // wave-uniform, rare: move the reference max of one or both Q tiles
+                asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");  // MFMA D (O) -> VALU read
 #pragma unroll
-            for (int qt = 0; qt < 2; ++qt) {
-                if (resc[qt]) {  // wave-uniform, rare
-                    asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");  // MFMA D (O) -> VALU read
+                for (int qt = 0; qt < 2; ++qt) {
+                    if (!(resc_any & (1u << qt))) continue;
                     const float alpha = __builtin_amdgcn_exp2f((m[qt] - m_pend[qt]) * c);
                     m[qt] = m_pend[qt];
                     neg_msc[qt] = -(m[qt] * c);
@@ -867,39 +895,73 @@ fa_fwd_kernel(const KernelArgs args) {
             const char *kt = smem + ((R + 1) & 3) * TILE;
             const char *vt = smem + V_BASE + R * TILE;
             float rs[2][2] = {{0.0f, 0.0f}, {0.0f, 0.0f}};
-            float vm[2], m_new[2];
+            float vm[2][2], m_new[2];
+            unsigned any01 = 0;
             auto exp_unit = [&](int u) {  // u = 8*s16 + 2*j + qt: in the order P.V consumes P
-                const int qt = u & 1, j = (u >> 1) & 3, s16 = u >> 3;
                 if constexpr (ABL & 2) return;
-                const int r = 8 * (s16 & 1) + 2 * j;
+                const int qt = u & 1, j = (u >> 1) & 3, s16 = u >> 3, r = 8 * (s16 & 1) + 2 * j;
+                // exp2(s c - m c), softmax.cuh:51-64.  Scalar f32 forms on purpose: v_pk_fma_f32 /
+                // v_pk_add_f32 here measured -6 % / -12 %; splitting the unit into stages over three
+                // gaps (no dependent pair inside a gap) measured -1.5 %.
                 float p0 = __builtin_fmaf(S_cur[qt][s16 >> 1][r], c, neg_msc[qt]);
                 float p1 = __builtin_fmaf(S_cur[qt][s16 >> 1][r + 1], c, neg_msc[qt]);
                 if (!(ABL & 1)) {
                     p0 = __builtin_amdgcn_exp2f(p0);
                     p1 = __builtin_amdgcn_exp2f(p1);
                 }
-                // scalar f32 forms on purpose: v_pk_fma_f32 / v_pk_add_f32 here measured -6 % / -12 %
                 rs[qt][0] += p0;  // fp32 P, before rounding (softmax.cuh:66-83)
                 rs[qt][1] += p1;
+                // pin the adds to this gap: hipcc otherwise sinks the whole row-sum chain (and keeps
+                // every p alive) to the first use of l, behind the next visit's barrier
+                asm volatile("" : "+v"(rs[qt][0]), "+v"(rs[qt][1]));
                 Pw[qt][s16][j] = E::pack2(p0, p1);
             };
             auto max_unit = [&](int u) {  // u = 0..31: tile (nt = u>>4, qt = (u>>3)&1), elements 2(u&7), +1
-                const int nt = u >> 4, qt = (u >> 3) & 1, e = 2 * (u & 7);
-                if constexpr (ABL & 2) { vm[qt] = 0.0f; return; }
-                if ((u & 7) == 0 && nt == 0) vm[qt] = fmaxf(S_nxt[qt][nt][0], S_nxt[qt][nt][1]);
-                else vm[qt] = vmax3(vm[qt], S_nxt[qt][nt][e], S_nxt[qt][nt][e + 1]);
+                const int nt = u >> 4, qt = (u >> 3) & 1, e = 2 * (u & 7), a = u & 1;  // two chains per Q tile
+                if constexpr (ABL & 2) { vm[qt][a] = 0.0f; return; }
+                // asm forms: fmaxf() on MFMA results makes hipcc canonicalise both inputs first
+                if ((u & 7) < 2 && nt == 0) vm[qt][a] = vmax2(S_nxt[qt][nt][e], S_nxt[qt][nt][e + 1]);
+                else vm[qt][a] = vmax3(vm[qt][a], S_nxt[qt][nt][e], S_nxt[qt][nt][e + 1]);
             };
-            auto tail_step = [&](int k) {  // end-of-visit chain: row max -> candidate m -> rescale test
-                if (k == 1) vm[0] = pair_max(vm[0]);
-                if (k == 2) vm[1] = pair_max(vm[1]);
-                if (k == 3) { m_new[0] = fmaxf(m[0], vm[0]); m_new[1] = fmaxf(m[1], vm[1]); }
-                if (k == 4) { l[0] += rs[0][0] + rs[0][1]; l[1] += rs[1][0] + rs[1][1]; }
-                if (k == 5) { m_pend[0] = m_new[0]; resc[0] = __any((m_new[0] - m[0]) * c > TAU); }
-                if (k == 6) { m_pend[1] = m_new[1]; resc[1] = __any((m_new[1] - m[1]) * c > TAU); }
+            auto lane_pair_max = [&](float x) {
+                auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+                return vmax2(__uint_as_float(r[0]), __uint_as_float(r[1]));
+            };
+            auto tail_step = [&](int k) {  // end-of-visit chain, one step per gap (pinned by volatile asm)
+                if (k == 1) {
+                    vm[0][0] = vmax2(vm[0][0], vm[0][1]);
+                    vm[1][0] = vmax2(vm[1][0], vm[1][1]);
+                    asm volatile("" : "+v"(vm[0][0]), "+v"(vm[1][0]));
+                }
+                if (k == 2) { vm[0][0] = lane_pair_max(vm[0][0]); asm volatile("" : "+v"(vm[0][0])); }
+                if (k == 3) { vm[1][0] = lane_pair_max(vm[1][0]); asm volatile("" : "+v"(vm[1][0])); }
+                if (k == 4) {  // candidate reference max
+                    m_new[0] = vmax2(m[0], vm[0][0]);
+                    m_new[1] = vmax2(m[1], vm[1][0]);
+                    asm volatile("" : "+v"(m_new[0]), "+v"(m_new[1]));
+                }
+                if (k == 5) {
+                    l[0] += rs[0][0] + rs[0][1];
+                    l[1] += rs[1][0] + rs[1][1];
+                    asm volatile("" : "+v"(l[0]), "+v"(l[1]));
+                }
+                if (k == 6 || k == 7) {  // did some row's max rise by more than TAU / c?
+                    const int qt = k - 6;
+                    m_pend[qt] = m_new[qt];
+                    float rise = (m_new[qt] - m[qt]) * c;
+                    asm volatile("" : "+v"(rise));  // (an "s" pin would make hipcc treat the flag as divergent)
+                    any01 |= (__ballot(rise > TAU) != 0 ? 1u : 0u) << qt;
+                }
+                if (k == 8) {  // next tiles to request (scalar ALU)
+                    resc_any = any01;
+                    if (it + 5 < n_kv) kq -= tile_stride;
+                    if (it + 4 < n_kv) vq -= tile_stride;
+
+                }
             };
             // operand u of the visit: 16 K fragments, 16 V fragments, then the first two K fragments
             // of the NEXT visit (its tile was published by this visit's barrier), so that no LDS
-            // latency is exposed behind the next barrier
+            // latency is exposed at the visit seam
             const char *kt_next = smem + ((R + 2) & 3) * TILE;
             auto operand = [&](int u) -> vec8 {
                 if constexpr (ABL & 4) return __builtin_bit_cast(vec8, Pw[u & 1][(u >> 1) & 3]);
@@ -910,6 +972,9 @@ fa_fwd_kernel(const KernelArgs args) {
                 constexpr int step = g >> 1, qt = g & 1;
                 if constexpr (qt == 0 && (step & 1) == 0) {  // operands in pairs: one counted wait per two steps
                     __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0): operands step, step+1 landed
+#ifdef FA_TRACE
+                    asm volatile("s_memtime %0" : "=s"(ts[2 + step / 2]));
+#endif
                     ring[(step + 2) % 4] = operand(step + 2);
                     ring[(step + 3) % 4] = operand(step + 3);
                 }
@@ -919,6 +984,7 @@ fa_fwd_kernel(const KernelArgs args) {
                     constexpr int s2 = step - 16, s16 = s2 >> 2, t = s2 & 3;
                     E::mfma_acc_a_p(O[qt][t], ring[step % 4], Pw[qt][s16]);
                 }
+                if constexpr (plan.barrier[g] != 0) sync_point();
                 if constexpr (plan.dma[g] >= 0 && !(ABL & 16)) {  // one 1-KiB DMA piece
                     constexpr int j = plan.dma[g] >> 1;
                     if constexpr ((plan.dma[g] & 1) == 0) glds16_sv_m0(kq, k_off[j], kdst + NWAVES * j * 1024);
@@ -929,8 +995,13 @@ fa_fwd_kernel(const KernelArgs args) {
                 if constexpr (plan.tail[g] > 0) tail_step(plan.tail[g]);
                 __builtin_amdgcn_sched_barrier(0);
             });
-            if (it + 5 < n_kv) kq -= tile_stride;
-            if (it + 4 < n_kv) vq -= tile_stride;
+#ifdef FA_TRACE
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts[18])::"memory");
+            if (blockIdx.x == (unsigned)args.trace_block && it == args.trace_visit && lane == 0) {
+#pragma unroll
+                for (int i = 0; i < 19; ++i) args.trace[wave * 24 + i] = ts[i];
+            }
+#endif
         };
         // prologue: K(0), V(0) are in flight (common code); then K(1) | K(2), V(1) | K(3), V(2) in the
         // order the counted waits assume

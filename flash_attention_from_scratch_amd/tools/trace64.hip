@@ -1,0 +1,53 @@
+// trace64.hip -- s_memtime stamps inside ONE visit of the 64-rows-per-wave schedule (debug build
+// with -DFA_TRACE; the shipped library carries no trace code).  Stamps: visit top, after the
+// barrier, then every 4 MFMA gaps (ideal: 4 x 32 = 128 cycles apiece), visit end.
+#define FA_TRACE 1
+#include "../csrc/fa_fwd_kernel.hpp"
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(e_), __LINE__); exit(2); } } while (0)
+
+int main(int argc, char **argv) {
+    const int B = 16, H = 16, D = 128, S = 4096;
+    const bool zeros = argc > 1 && !strcmp(argv[1], "zeros");
+    const size_t n = (size_t)B * S * H * D;
+    std::vector<uint16_t> h(n);
+    uint16_t *q, *k, *v, *o; unsigned long long *tr;
+    CHECK(hipMalloc(&q, n * 2)); CHECK(hipMalloc(&k, n * 2)); CHECK(hipMalloc(&v, n * 2)); CHECK(hipMalloc(&o, n * 2));
+    CHECK(hipMalloc(&tr, 4 * 24 * 8));
+    srand(1);
+    for (int t = 0; t < 3; ++t) {
+        for (size_t i = 0; i < n; ++i) {
+            float x = zeros ? 0.0f : ((rand() & 0xffff) / 65536.0f - 0.5f) * 3.4f;
+            uint32_t u; memcpy(&u, &x, 4); h[i] = (uint16_t)(u >> 16);
+        }
+        CHECK(hipMemcpy(t == 0 ? q : t == 1 ? k : v, h.data(), n * 2, hipMemcpyHostToDevice));
+    }
+    fa::KernelArgs a;
+    a.q = q; a.k = k; a.v = v; a.o = o;
+    a.batch_stride = (int64_t)S * H * D; a.seq_stride = H * D; a.head_stride = D;
+    a.seq_len = S; a.n_heads = H; a.n_bh = B * H; a.n_q_blocks = S / 256; a.n_kv_blocks = S / 64; a.causal = 0;
+    a.trace = tr;
+    auto kern = fa::fa_fwd_kernel<15, 2, 4, 64, true, true, true, true, true, false, 128, 0>;
+    CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+    const int blocks[2] = {100, 3000};
+    const int visits[4] = {20, 21, 22, 41};
+    for (int warm = 0; warm < 5; ++warm) hipLaunchKernelGGL(kern, dim3(a.n_bh * a.n_q_blocks), dim3(256), 131072, 0, a);
+    for (int bi = 0; bi < 2; ++bi) for (int vi = 0; vi < 4; ++vi) {
+        a.trace_block = blocks[bi]; a.trace_visit = visits[vi];
+        CHECK(hipMemset(tr, 0, 4 * 24 * 8));
+        hipLaunchKernelGGL(kern, dim3(a.n_bh * a.n_q_blocks), dim3(256), 131072, 0, a);
+        CHECK(hipDeviceSynchronize());
+        unsigned long long t[96];
+        CHECK(hipMemcpy(t, tr, sizeof(t), hipMemcpyDeviceToHost));
+        for (int w = 0; w < 4; ++w) {
+            const unsigned long long *r = t + w * 24;
+            printf("blk %4d visit %2d wave %d: total %5llu | top %4llu | groups", blocks[bi], visits[vi], w, r[18] - r[0], r[2] - r[0]);
+            for (int i = 2; i < 17; ++i) printf(" %3llu", r[i + 1] - r[i]);
+            printf(" | last %3llu\n", r[18] - r[17]);
+        }
+    }
+    return 0;
+}
