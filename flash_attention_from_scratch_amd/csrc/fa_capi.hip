@@ -89,6 +89,8 @@ std::once_flag g_init_once;
 int g_init_status = FA_OK;
 char g_init_err[256] = "";
 
+int g_num_cus = 256;  // persistent variants launch one workgroup per CU
+
 void do_init() {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) {
@@ -102,6 +104,7 @@ void do_init() {
         snprintf(g_init_err, sizeof(g_init_err), "hipGetDeviceProperties failed");
         return;
     }
+    g_num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
         g_init_status = FA_ERR_DEVICE;
         snprintf(g_init_err, sizeof(g_init_err),
@@ -171,7 +174,14 @@ int launch(const fa_fwd_args *a, const fa::KernelEntry *e, hipStream_t stream, i
     ka.causal = causal;
     // 1-D grid over (batch*head, Q block); the kernel un-maps it XCD-aware.
     // (reference: dim3(n_Q_blocks, n_heads, batch), flash_attention.cu:110-112)
-    const dim3 grid((unsigned)(ka.n_bh * ka.n_q_blocks));
+    // Persistent variants: one workgroup per CU (a multiple of 8, so an item keeps its XCD) that
+    // walks items blockIdx.x, + gridDim.x, ... itself.
+    unsigned n_wg = (unsigned)(ka.n_bh * ka.n_q_blocks);
+    if (e->persistent) {
+        const unsigned cap = (unsigned)(g_num_cus & ~7) ? (unsigned)(g_num_cus & ~7) : 8u;
+        if (n_wg > cap) n_wg = cap;
+    }
+    const dim3 grid(n_wg);
     const dim3 block((unsigned)e->threads);
     void *params[] = {&ka};
     hipError_t rc = hipLaunchKernel((const void *)e->fn, grid, block, params, (size_t)e->lds_bytes, stream);

@@ -309,7 +309,12 @@ struct FwdTraits {
     static constexpr int kStages = (QT == 2 && PIPE) ? 4 : (EAGER ? 2 : 1);
     static constexpr int kKvBytes = 2 * kStages * kTileBytes;   // K + V, all stages
     static constexpr int kOutBytes = kBr * 2 * D;               // O tile staged for the epilogue
-    static constexpr int kLdsBytes = kKvBytes > kOutBytes ? kKvBytes : kOutBytes;
+    // The 64-rows-per-wave schedule is a PERSISTENT kernel: one workgroup per CU walks the
+    // (batch*head, Q block) items and keeps the K/V tile stream running across item seams, so its
+    // O staging (8 KB per wave, one 32-row Q tile at a time) lives beside the rings, not in them.
+    static constexpr bool kPersistent = (QT == 2 && PIPE);
+    static constexpr int kLdsBytes = kPersistent ? kKvBytes + NWAVES * 32 * 2 * D
+                                                 : (kKvBytes > kOutBytes ? kKvBytes : kOutBytes);
 };
 
 // Filler plan of the 64-rows-per-wave schedule: what rides in the gap after MFMA g (g = 0..63 of a
@@ -425,18 +430,21 @@ fa_fwd_kernel(const KernelArgs args) {
 
     // ---- workgroup -> (batch*head, Q block); XCD-aware when n_bh % 8 == 0 --------
     const int nq = args.n_q_blocks;
-    int bh, qb;
-    {
-        const int bid = blockIdx.x;
+    // item -> (batch*head, Q block).  Workgroups are dealt round-robin over the 8 XCDs, so items
+    // congruent mod 8 share an L2: give each XCD whole heads (all Q blocks of a head read the same
+    // K / V).  The persistent variant walks items blockIdx.x, + gridDim.x, ... with gridDim.x % 8 == 0.
+    auto item_coords = [&](int bid, int &bh_out, int &qb_out) {
         if ((args.n_bh & 7) == 0) {
             const int xcd = bid & 7, local = bid >> 3;
-            bh = (local / nq) * 8 + xcd;
-            qb = local % nq;
+            bh_out = (local / nq) * 8 + xcd;
+            qb_out = local % nq;
         } else {
-            bh = bid / nq;
-            qb = bid % nq;
+            bh_out = bid / nq;
+            qb_out = bid % nq;
         }
-    }
+    };
+    int bh, qb;
+    item_coords(blockIdx.x, bh, qb);
     if (MASK && args.causal) qb = nq - 1 - qb;  // longest rows first
     const int b = bh / args.n_heads, h = bh % args.n_heads;
     const int64_t ss = args.seq_stride;
@@ -601,7 +609,12 @@ fa_fwd_kernel(const KernelArgs args) {
         if (MASK && row >= S_len) row = S_len - 1;  // rows past the end are computed, never stored
         const uint16_t *qp = Qg + row * ss + hi * 8;
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) Qr[qt][ks] = *(const vec8 *)(qp + ks * 16);
+        for (int ks = 0; ks < KS; ++ks) {
+            if constexpr (TR::kPersistent)  // straight into the accumulator file; waited for by hand below
+                asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=a"(Qr[qt][ks]) : "v"(qp), "i"(ks * 32) : "memory");
+            else
+                Qr[qt][ks] = *(const vec8 *)(qp + ks * 16);
+        }
     }
 
     // forward_kernel.cuh:150-151 (fp32 product of rsqrt(d) and log2 e)
@@ -814,7 +827,7 @@ fa_fwd_kernel(const KernelArgs args) {
         constexpr Plan64 plan = make_plan64((ABL >> 8) & 3, (ABL & 1024) ? 20 : 22);
         static_assert(plan64_ok(plan), "filler plan violates a wait-state distance");
         f32x16 Sa[2][NT], Sb[2][NT];
-        u32x4 Pw[2][4];          // P[qt][16-key slice]: B operand of O^T += V^T P^T
+        u32x4 Pw[2][4] = {};     // P[qt][16-key slice]: B operand of O^T += V^T P^T
         float neg_msc[2];        // -(m c)
         float m_pend[2];         // candidate reference max found during the previous visit
         unsigned resc_any = 0;   // bit qt: Q tile qt moves its reference max at the next visit's top
@@ -835,27 +848,54 @@ fa_fwd_kernel(const KernelArgs args) {
             if (ks == 0) E::mfma_acc_v_q0(S[qt][nt], a, Qr[qt][ks]);
             else E::mfma_acc_v_q(S[qt][nt], a, Qr[qt][ks]);
         };
-        // tile j (visit index) -> global pointer; past the end the last tile is fetched again into
-        // a stage nobody reads, so the instruction stream has no branch and the DMA count per
-        // visit is constant (the counted wait depends on it)
-        auto tile_ptr = [&](const uint16_t *T, int j) {
-            j = j < n_kv ? j : n_kv - 1;
-            return T + (int64_t)(n_kv - 1 - j) * tile_stride;
+        // ---- persistent walk over items; the K / V tile stream runs on across item seams --------
+        // This workgroup serves items blockIdx.x, + gridDim.x, ...  Tiles are numbered along the
+        // walk: visit index j of the current item for j < n_kv, visit index j - n_kv of the NEXT item
+        // beyond (n_kv % 4 == 0, so a tile's ring stage is j & 3 either way).  The last visits of an
+        // item therefore request the next item's first tiles, its last visit forms the next item's
+        // S(0) with the next item's Q (loaded straight into the Q AGPRs one visit earlier), and a
+        // seam costs the O epilogue only.  After the last item the "next" item is the item itself:
+        // the re-fetched tiles land in stages nobody reads.
+        const int n_items = args.n_bh * nq;
+        int item = blockIdx.x;
+        const uint16_t *Kc = Kg, *Vc = Vg;   // current item
+        uint16_t *Oc = Og;
+        int qb_c = qb;
+        const uint16_t *Kn = Kg, *Vn = Vg, *Qn = Qg;  // next item (set per item below)
+        uint16_t *On = Og;
+        int qb_n = qb;
+        bool has_next = false;
+        auto tile_g = [&](const uint16_t *cur, const uint16_t *nxt, int j) {
+            return j < n_kv ? cur + (int64_t)(n_kv - 1 - j) * tile_stride
+                            : nxt + (int64_t)(2 * n_kv - 1 - j) * tile_stride;
         };
-        auto dma_k = [&](int tile, int stage) {
-            const uint16_t *src = tile_ptr(Kg, tile);
+        // One lane offset per tensor: piece j of a wave starts 16 rows below piece j-1 (K: rows
+        // 4 wave + 16 j; V: the 16-key group pair j), a wave-uniform stride that rides in the
+        // scalar base instead of costing three more VGPRs per tensor.
+        const int64_t piece_stride = 16 * ss;
+        auto dma_k = [&](const uint16_t *src, int stage) {
 #pragma unroll
             for (int j = 0; j < DMA_PER_WAVE; ++j)
-                glds16_sv_m0(src, k_off[j], smem_base + stage * TILE + (wave + NWAVES * j) * 1024);
+                glds16_sv_m0(src + j * piece_stride, k_off[0], smem_base + stage * TILE + (wave + NWAVES * j) * 1024);
         };
-        auto dma_v = [&](int tile, int stage) {
-            const uint16_t *src = tile_ptr(Vg, tile);
+        auto dma_v = [&](const uint16_t *src, int stage) {
 #pragma unroll
             for (int j = 0; j < DMA_PER_WAVE; ++j)
-                glds16_sv_m0(src, v_off[j], smem_base + V_BASE + stage * TILE + (wave + NWAVES * j) * 1024);
+                glds16_sv_m0(src + j * piece_stride, v_off[0], smem_base + V_BASE + stage * TILE + (wave + NWAVES * j) * 1024);
         };
-        const uint16_t *kq = tile_ptr(Kg, 4), *vq = tile_ptr(Vg, 3);  // next tiles to request
+        const uint16_t *kq = nullptr, *vq = nullptr;  // next K / V tile to request (set per item below)
         vec8 ring[4];  // operand ring: slot u % 4, rewritten two steps after the MFMAs that read it
+        vec8 Qr2[2][KS];  // the next item's Q (AGPRs), requested during the item's first visit
+        float mraw[2];   // row max of the S tile formed by the last visit (the next item's S(0))
+        bool seam = false;  // the first two visits after a seam: the epilogue's stores are in flight
+        // next item's Q rows -> the Q AGPRs.  Plain asm loads: hipcc does not count them; the wait
+        // is the vmcnt(0) at the top of the item's last visit.
+        auto load_q_next = [&](auto piece_tag, vec8 &dst) {  // piece = 8*qt + ks, dst = Qr[qt][ks]
+            constexpr int piece = decltype(piece_tag)::value, qt = piece >> 3, ks = piece & 7;
+            const int64_t row = (int64_t)qb_n * TR::kBr + wave * TR::kRowsPerWave + qt * 32 + r31;
+            const uint16_t *qp = Qn + row * ss + hi * 8;
+            asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=a"(dst) : "v"(qp), "i"(ks * 32) : "memory");
+        };
         auto visit = [&](int it, auto &S_cur, auto &S_nxt, auto r_tag) {
             constexpr int R = decltype(r_tag)::value;  // it & 3
 #ifdef FA_TRACE
@@ -869,8 +909,31 @@ fa_fwd_kernel(const KernelArgs args) {
             // gap-0 lgkmcnt(0) that retires this wave's last LDS reads of visit it-1.
             auto sync_point = [&]() {
                 if (ABL & 8) return;
-                asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+                // what may still be in flight behind the pieces this barrier publishes: this visit's
+                // predecessor's 8 pieces, plus -- early in an item -- the 16 stores of the previous
+                // item's epilogue and the 16 loads of the next item's Q
+                int allow = 8;
+                if constexpr (R == 0) allow = (it == 0 && seam) ? 24 : 8;
+                if constexpr (R == 1) allow = (it == 1) ? 8 + (seam ? 16 : 0) + (has_next ? 16 : 0) : 8;
+                if constexpr (R == 2) allow = (it == 2 && has_next) ? 24 : 8;
+                if (allow == 8) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+                else if (allow == 24) asm volatile("s_waitcnt vmcnt(24)\n\ts_barrier" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(40)\n\ts_barrier" ::: "memory");
             };
+            if constexpr (R == 3) {
+                // last visit of an item forms the next item's S(0): swap the next item's Q in
+                if (it + 1 == n_kv && has_next) {
+                    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");  // the Q loads (visit 0) are older than 16 pieces
+#pragma unroll
+                    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+                        for (int ks = 0; ks < KS; ++ks) {
+                            asm volatile("" : "+a"(Qr2[qt][ks]));  // value defined by the asm loads
+                            Qr[qt][ks] = Qr2[qt][ks];
+                        }
+                    asm volatile("s_nop 3" ::: "memory");  // accvgpr write -> MFMA operand
+                }
+            }
             if constexpr (plan.barrier[2] == 0) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 sync_point();
@@ -914,7 +977,11 @@ fa_fwd_kernel(const KernelArgs args) {
                 // pin the adds to this gap: hipcc otherwise sinks the whole row-sum chain (and keeps
                 // every p alive) to the first use of l, behind the next visit's barrier
                 asm volatile("" : "+v"(rs[qt][0]), "+v"(rs[qt][1]));
-                Pw[qt][s16][j] = E::pack2(p0, p1);
+                unsigned pk = E::pack2(p0, p1);
+                // ... and the pack: sunk below a branch of the stream it would sit right in front of the
+                // MFMA that reads it, which hipcc does not pad (the MFMAs are opaque asm)
+                asm volatile("" : "+v"(pk));
+                Pw[qt][s16][j] = pk;
             };
             auto max_unit = [&](int u) {  // u = 0..31: tile (nt = u>>4, qt = (u>>3)&1), elements 2(u&7), +1
                 const int nt = u >> 4, qt = (u >> 3) & 1, e = 2 * (u & 7), a = u & 1;  // two chains per Q tile
@@ -922,6 +989,7 @@ fa_fwd_kernel(const KernelArgs args) {
                 // asm forms: fmaxf() on MFMA results makes hipcc canonicalise both inputs first
                 if ((u & 7) < 2 && nt == 0) vm[qt][a] = vmax2(S_nxt[qt][nt][e], S_nxt[qt][nt][e + 1]);
                 else vm[qt][a] = vmax3(vm[qt][a], S_nxt[qt][nt][e], S_nxt[qt][nt][e + 1]);
+                asm volatile("" : "+v"(vm[qt][a]));  // pinned to its gap (S_nxt is rewritten next visit)
             };
             auto lane_pair_max = [&](float x) {
                 auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
@@ -936,6 +1004,8 @@ fa_fwd_kernel(const KernelArgs args) {
                 if (k == 2) { vm[0][0] = lane_pair_max(vm[0][0]); asm volatile("" : "+v"(vm[0][0])); }
                 if (k == 3) { vm[1][0] = lane_pair_max(vm[1][0]); asm volatile("" : "+v"(vm[1][0])); }
                 if (k == 4) {  // candidate reference max
+                    mraw[0] = vm[0][0];
+                    mraw[1] = vm[1][0];
                     m_new[0] = vmax2(m[0], vm[0][0]);
                     m_new[1] = vmax2(m[1], vm[1][0]);
                     asm volatile("" : "+v"(m_new[0]), "+v"(m_new[1]));
@@ -954,8 +1024,10 @@ fa_fwd_kernel(const KernelArgs args) {
                 }
                 if (k == 8) {  // next tiles to request (scalar ALU)
                     resc_any = any01;
-                    if (it + 5 < n_kv) kq -= tile_stride;
-                    if (it + 4 < n_kv) vq -= tile_stride;
+                    // visit it+1 requests K(it+5), V(it+4); the stream wraps into the next item
+                    kq = (it + 5 == n_kv) ? Kn + (int64_t)(n_kv - 1) * tile_stride : kq - tile_stride;
+                    vq = (it + 4 == n_kv) ? Vn + (int64_t)(n_kv - 1) * tile_stride : vq - tile_stride;
+                    if constexpr (R == 1) seam = false;
 
                 }
             };
@@ -970,6 +1042,13 @@ fa_fwd_kernel(const KernelArgs args) {
             static_for<0, 64>([&](auto gap_tag) {
                 constexpr int g = decltype(gap_tag)::value;
                 constexpr int step = g >> 1, qt = g & 1;
+                // An MFMA reads its A / B registers for a few cycles after it issues, and hipcc -- to
+                // which the MFMAs are opaque asm -- is free to hand a register that just died to the very
+                // next VALU instruction (seen: the pair-max temporary landing in the A operand of the
+                // MFMA in front of it; one-ulp run-to-run differences that an s_nop 7 behind every MFMA
+                // removed).  So every operand is kept alive until the NEXT MFMA has issued: an empty asm
+                // that names it, placed behind that MFMA (volatile asm statements keep their order).
+                vec8 prev_a = ring[(step + 3) % 4];  // A operand of the previous step (its slot is reloaded below)
                 if constexpr (qt == 0 && (step & 1) == 0) {  // operands in pairs: one counted wait per two steps
                     __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0): operands step, step+1 landed
 #ifdef FA_TRACE
@@ -984,11 +1063,28 @@ fa_fwd_kernel(const KernelArgs args) {
                     constexpr int s2 = step - 16, s16 = s2 >> 2, t = s2 & 3;
                     E::mfma_acc_a_p(O[qt][t], ring[step % 4], Pw[qt][s16]);
                 }
+                if constexpr (qt == 0) asm volatile("" ::"v"(prev_a));
+                if constexpr (g >= 33) {
+                    constexpr int pg = g - 1, ps2 = (pg >> 1) - 16;
+                    asm volatile("" ::"v"(Pw[pg & 1][ps2 >> 2]));  // B operand of the previous P.V MFMA
+                }
+                if constexpr (g == 0) asm volatile("" ::"v"(Pw[1][3]));  // ... of the previous visit's last one
                 if constexpr (plan.barrier[g] != 0) sync_point();
+                if constexpr (R == 0 && g == 33 && !(ABL & 2048)) {
+                    // first visit of an item: request the NEXT item's Q rows into the spare Q set
+                    // (64 of the AGPRs are otherwise unused); they are swapped in at the top of
+                    // this item's last visit, several visits after they have landed
+                    if (it == 0 && has_next) {
+                        static_for<0, 16>([&](auto i) {
+                            constexpr int pc = decltype(i)::value;
+                            load_q_next(IntTag<pc>{}, Qr2[pc >> 3][pc & 7]);
+                        });
+                    }
+                }
                 if constexpr (plan.dma[g] >= 0 && !(ABL & 16)) {  // one 1-KiB DMA piece
                     constexpr int j = plan.dma[g] >> 1;
-                    if constexpr ((plan.dma[g] & 1) == 0) glds16_sv_m0(kq, k_off[j], kdst + NWAVES * j * 1024);
-                    else glds16_sv_m0(vq, v_off[j], vdst + NWAVES * j * 1024);
+                    if constexpr ((plan.dma[g] & 1) == 0) glds16_sv_m0(kq + j * piece_stride, k_off[0], kdst + NWAVES * j * 1024);
+                    else glds16_sv_m0(vq + j * piece_stride, v_off[0], vdst + NWAVES * j * 1024);
                 }
                 static_for<0, plan.exp_n[g]>([&](auto i) { exp_unit(plan.exp_first[g] + decltype(i)::value); });
                 static_for<0, plan.max_n[g]>([&](auto i) { max_unit(plan.max_first[g] + decltype(i)::value); });
@@ -997,31 +1093,51 @@ fa_fwd_kernel(const KernelArgs args) {
             });
 #ifdef FA_TRACE
             asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts[18])::"memory");
-            if (blockIdx.x == (unsigned)args.trace_block && it == args.trace_visit && lane == 0) {
+            if (item == args.trace_block && it == args.trace_visit && lane == 0) {
 #pragma unroll
                 for (int i = 0; i < 19; ++i) args.trace[wave * 24 + i] = ts[i];
             }
 #endif
         };
-        // prologue: K(0), V(0) are in flight (common code); then K(1) | K(2), V(1) | K(3), V(2) in the
-        // order the counted waits assume
-        dma_k(1, 1);
-        dma_k(2, 2);
-        dma_v(1, 1);
-        dma_k(3, 3);
-        dma_v(2, 2);
+        // ---- first item: prologue -------------------------------------------------------------
+        auto set_next = [&]() {  // coordinates of the item after `item` (or `item` again)
+            const int nitem = item + (int)gridDim.x;
+            has_next = nitem < n_items;
+            int bh_n;
+            item_coords(has_next ? nitem : item, bh_n, qb_n);
+            const int b_n = bh_n / args.n_heads, h_n = bh_n % args.n_heads;
+            const int64_t off_n = (int64_t)b_n * args.batch_stride + (int64_t)h_n * args.head_stride;
+            Qn = (const uint16_t *)args.q + off_n;
+            Kn = (const uint16_t *)args.k + off_n;
+            Vn = (const uint16_t *)args.v + off_n;
+            On = (uint16_t *)args.o + off_n;
+        };
+        set_next();
+        // K(0), V(0) are in flight (common code); then K(1) | K(2), V(1) | K(3), V(2) in the order the
+        // counted waits assume
+        dma_k(tile_g(Kc, Kn, 1), 1);
+        dma_k(tile_g(Kc, Kn, 2), 2);
+        dma_v(tile_g(Vc, Vn, 1), 1);
+        dma_k(tile_g(Kc, Kn, 3), 3);
+        dma_v(tile_g(Vc, Vn, 2), 2);
+        kq = tile_g(Kc, Kn, 4);
+        vq = tile_g(Vc, Vn, 3);
         if (!(ABL & 8)) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");  // K(0), V(0), K(1) landed
         barrier();
         {
             // S(0) and its row max, which becomes the first reference max (O = l = 0)
             const char *kt = smem;
+            vec8 a_all[16];  // every operand stays allocated until the last MFMA has issued (see visit())
+#pragma unroll
+            for (int step = 0; step < 16; ++step) a_all[step] = k_frag(kt, step);
             static_for<0, 16>([&](auto step_tag) {
                 constexpr int step = decltype(step_tag)::value;
-                const vec8 a = k_frag(kt, step);
-                qk_mfma(Sa, step, 0, a);
-                qk_mfma(Sa, step, 1, a);
+                qk_mfma(Sa, step, 0, a_all[step]);
+                qk_mfma(Sa, step, 1, a_all[step]);
             });
             asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // MFMA D -> VALU read
+#pragma unroll
+            for (int step = 0; step < 16; ++step) asm volatile("" ::"v"(a_all[step]));
 #pragma unroll
             for (int qt = 0; qt < 2; ++qt) {
                 float v = Sa[qt][0][0];
@@ -1036,15 +1152,96 @@ fa_fwd_kernel(const KernelArgs args) {
             ring[0] = k_frag(smem + TILE, 0);  // first operands of visit 0: K(1)
             ring[1] = k_frag(smem + TILE, 1);
         }
+        // O of one item: finish l, normalise, RNE to 16 bit (final_softmax_normalization
+        // softmax.cuh:107-128; forward_kernel.cuh:186-203), through this wave's 8-KB LDS staging
+        // area one 32-row Q tile at a time so that the global stores are whole 256-B rows (16 B per
+        // lane, 4 rows per wave-instruction).  Wave-private: no barrier.  The 16-B chunk index is
+        // XORed with (row & 15) so the 8-B writes and the 16-B reads are bank-conflict free.
+        auto store_item = [&]() {
+            asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // last P.V -> VALU reads of O
+            char *stage_o = smem + 2 * TR::kStages * TILE + wave * (32 * ROWB);
+            // lane-derived indices recomputed here from a volatile v_mbcnt: values derived from
+            // threadIdx at kernel entry would stay live (and get spilled) across the whole item loop
+            int lane;
+            asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
+            const int r31 = lane & 31, hi = lane >> 5;
+            const int rsub = lane / CPR, chunk = lane & (CPR - 1);
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+                const float inv = 1.0f / pair_sum(l[qt]);
+                char *wp = stage_o + r31 * ROWB + hi * 8;
+#pragma unroll
+                for (int t = 0; t < DTILES; ++t) {
+                    float o[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[r] = O[qt][t][r] * inv;
+                    // regs 4rq..4rq+3 : d = 32t + 8rq + 4hi + 0..3  -> chunk 4t + rq, half hi
+                    const s16x8 lo_s = __builtin_bit_cast(s16x8, E::pack8(o));
+                    const s16x8 up_s = __builtin_bit_cast(s16x8, E::pack8(o + 8));
+                    *(s16x4 *)(wp + (((4 * t + 0) ^ swz_of(r31)) << 4)) = lo_s.lo;
+                    *(s16x4 *)(wp + (((4 * t + 1) ^ swz_of(r31)) << 4)) = lo_s.hi;
+                    *(s16x4 *)(wp + (((4 * t + 2) ^ swz_of(r31)) << 4)) = up_s.lo;
+                    *(s16x4 *)(wp + (((4 * t + 3) ^ swz_of(r31)) << 4)) = up_s.hi;
+                    __builtin_amdgcn_sched_barrier(0);  // one d tile at a time: S(0) of the next item is live
+                }
+                const int64_t row0 = (int64_t)qb_c * TR::kBr + wave * TR::kRowsPerWave + qt * 32;
+#pragma unroll
+                for (int i = 0; i < 32 / RPP; ++i) {
+                    const int row = RPP * i + rsub;
+                    const s16x8 v = *(const s16x8 *)(stage_o + row * ROWB + ((chunk ^ swz_of(row)) << 4));
+                    if (!(ABL & 4096)) *(s16x8 *)(Oc + (row0 + row) * ss + chunk * 8) = v;
+                    else asm volatile("" :: "v"(v));
+                }
+            }
+        };
         // seq_len is a multiple of B_r = 256, so n_kv = seq_len / 64 is a multiple of 4 = ring depth
-        for (int it = 0; it < n_kv; it += 4) {
-            visit(it, Sa, Sb, IntTag<0>{});
-            visit(it + 1, Sb, Sa, IntTag<1>{});
-            visit(it + 2, Sa, Sb, IntTag<2>{});
-            visit(it + 3, Sb, Sa, IntTag<3>{});
+        for (;;) {
+            for (int it = 0; it < n_kv; it += 4) {
+                visit(it, Sa, Sb, IntTag<0>{});
+                visit(it + 1, Sb, Sa, IntTag<1>{});
+                visit(it + 2, Sa, Sb, IntTag<2>{});
+                visit(it + 3, Sb, Sa, IntTag<3>{});
+            }
+#ifdef FA_TRACE
+            unsigned long long te0, te1, te2;
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(te0)::"memory");
+#endif
+            store_item();
+#ifdef FA_TRACE
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(te1)::"memory");
+#endif
+            if (!has_next) break;
+            // ---- seam: the last visit left the next item's S(0) in Sa and its row max in mraw; its
+            // first tiles are landed or in flight, its first operands sit in the ring
+            item += (int)gridDim.x;
+            Kc = Kn; Vc = Vn; Oc = On; qb_c = qb_n;
+            set_next();
+            kq = tile_g(Kc, Kn, 4);  // visit 0 requests K(4), V(3) (for n_kv == 4 that is already the item after)
+            vq = tile_g(Vc, Vn, 3);
+            seam = true;
+            resc_any = 0;
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+                m[qt] = mraw[qt];
+                neg_msc[qt] = -(m[qt] * c);
+                m_pend[qt] = m[qt];
+                l[qt] = 0.0f;
+#pragma unroll
+                for (int t = 0; t < DTILES; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) O[qt][t][r] = 0.0f;
+            }
+#ifdef FA_TRACE
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(te2)::"memory");
+            if (item - (int)gridDim.x == args.trace_block && lane == 0) {
+                args.trace[wave * 24 + 21] = te0;
+                args.trace[wave * 24 + 22] = te1;
+                args.trace[wave * 24 + 23] = te2;
+            }
+#endif
         }
-        dma_wait();  // the re-fetched last tiles must land before the epilogue reuses the LDS
-        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // last P.V -> epilogue reads of O
+        dma_wait();  // nothing may still be landing in the LDS when the workgroup retires
+        return;
     } else if (PIPE) {
         // In-wave software pipeline with two S accumulators.  While the matrix pipe forms
         // S(it+1) = K(it+1) Q^T and then O += V(it) P(it), the VALU turns the finished S(it)

@@ -25,6 +25,7 @@ struct KernelEntry {
     int d_head;         // 128 (reference scope) or 64
     int threads;
     int lds_bytes;
+    int persistent;     // 1: launch one workgroup per CU; the kernel walks the items itself
     kernel_fn fn;
 };
 
@@ -33,7 +34,7 @@ template <int DT, int QT, int NWAVES, int BC, bool SWZ, bool EAGER, bool OPT, bo
 constexpr KernelEntry make_entry() {
     using TR = FwdTraits<DT, QT, NWAVES, BC, SWZ, EAGER, OPT, PIPE, DMA, MASK, D>;
     return KernelEntry{DT, 32 * QT, NWAVES, BC, SWZ, EAGER, OPT, PIPE, DMA, MASK, D, TR::kThreads,
-                       TR::kLdsBytes,
+                       TR::kLdsBytes, TR::kPersistent,
                        (kernel_fn)&fa_fwd_kernel<DT, QT, NWAVES, BC, SWZ, EAGER, OPT, PIPE, DMA, MASK, D>};
 }
 

@@ -1,0 +1,76 @@
+"""isa_lint64.py -- hazard lint for the hand-placed 64-rows-per-wave kernel.
+
+hipcc treats the inline-asm MFMAs as opaque single-cycle instructions, so it neither pads the
+hazards around them nor keeps their operand registers allocated while the matrix pipe is still
+reading them.  This script disassembles nothing: it reads the `-S` output and reports
+
+  WAR   an instruction within `--window` instructions AFTER an MFMA writes a VGPR that the MFMA
+        reads as A or B operand (seen on hardware as rare one-ulp run-to-run differences);
+  RAW   an MFMA reads as A / B a VGPR written by a VALU instruction fewer than `--raw` instructions
+        earlier (v_cvt_pk -> MFMA needs wait states hipcc does not insert for asm);
+  AGPR  compiler-generated v_accvgpr_* inside the main loop (accumulators must stay put).
+
+Usage: python isa_lint64.py kernel.s [--window 3] [--raw 2]
+"""
+import argparse
+import re
+import sys
+
+
+def regs(tok):
+    tok = tok.strip(",")
+    m = re.match(r"v\[(\d+):(\d+)\]$", tok)
+    if m:
+        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    m = re.match(r"v(\d+)$", tok)
+    return {int(m.group(1))} if m else set()
+
+
+def lint(path, window=3, raw=2):
+    lines = [l.strip() for l in open(path).read().split("\n")]
+    findings = []
+    kernels = []
+    cur = []
+    for l in lines:
+        if not l or l.startswith(";") or l.startswith("."):
+            if l.startswith(".Lfunc_end"):
+                kernels.append(cur)
+                cur = []
+            continue
+        cur.append(l)
+    if cur:
+        kernels.append(cur)
+    for kidx, code in enumerate(kernels):
+        for i, l in enumerate(code):
+            if not l.startswith("v_mfma"):
+                continue
+            ops = l.split()[1:]
+            rd = regs(ops[1]) | regs(ops[2])
+            for k in range(1, window + 1):
+                if i + k >= len(code) or code[i + k].startswith("v_mfma"):
+                    break
+                n = code[i + k]
+                if n.startswith("v_") or n.startswith("ds_read") or n.startswith("global_load") or n.startswith("scratch_load"):
+                    if regs(n.split()[1]) & rd:
+                        findings.append(("WAR", kidx, i, l, n))
+            for k in range(1, raw + 1):
+                if i - k < 0 or code[i - k].startswith("v_mfma"):
+                    break
+                p = code[i - k]
+                if p.startswith("v_") and not p.startswith("v_cmp"):
+                    if regs(p.split()[1]) & rd:
+                        findings.append(("RAW", kidx, i, l, p))
+    return findings
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("asm")
+    ap.add_argument("--window", type=int, default=3)
+    ap.add_argument("--raw", type=int, default=2)
+    a = ap.parse_args()
+    f = lint(a.asm, a.window, a.raw)
+    for kind, k, i, m, o in f:
+        print(f"{kind} kernel#{k} @{i}: {m}   <->   {o}")
+    print(f"{len(f)} finding(s)")
+    sys.exit(1 if f else 0)

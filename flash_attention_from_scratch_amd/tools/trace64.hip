@@ -31,22 +31,26 @@ int main(int argc, char **argv) {
     a.seq_len = S; a.n_heads = H; a.n_bh = B * H; a.n_q_blocks = S / 256; a.n_kv_blocks = S / 64; a.causal = 0;
     a.trace = tr;
     auto kern = fa::fa_fwd_kernel<15, 2, 4, 64, true, true, true, true, true, false, 128, 0>;
-    CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
-    const int blocks[2] = {100, 3000};
-    const int visits[4] = {20, 21, 22, 41};
-    for (int warm = 0; warm < 5; ++warm) hipLaunchKernelGGL(kern, dim3(a.n_bh * a.n_q_blocks), dim3(256), 131072, 0, a);
-    for (int bi = 0; bi < 2; ++bi) for (int vi = 0; vi < 4; ++vi) {
-        a.trace_block = blocks[bi]; a.trace_visit = visits[vi];
+    CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
+    // persistent kernel: workgroup w serves items w, w + 256, ...; trace the second item of two workgroups
+    const int items[2] = {256 + 100, 256 + 203};
+    const int visits[6] = {0, 1, 20, 61, 62, 63};
+    const int grid = 256;
+    for (int warm = 0; warm < 5; ++warm) hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 163840, 0, a);
+    for (int bi = 0; bi < 2; ++bi) for (int vi = 0; vi < 6; ++vi) {
+        a.trace_block = items[bi]; a.trace_visit = visits[vi];
         CHECK(hipMemset(tr, 0, 4 * 24 * 8));
-        hipLaunchKernelGGL(kern, dim3(a.n_bh * a.n_q_blocks), dim3(256), 131072, 0, a);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 163840, 0, a);
         CHECK(hipDeviceSynchronize());
         unsigned long long t[96];
         CHECK(hipMemcpy(t, tr, sizeof(t), hipMemcpyDeviceToHost));
         for (int w = 0; w < 4; ++w) {
             const unsigned long long *r = t + w * 24;
-            printf("blk %4d visit %2d wave %d: total %5llu | top %4llu | groups", blocks[bi], visits[vi], w, r[18] - r[0], r[2] - r[0]);
+            printf("item %4d visit %2d wave %d: total %5llu | top %4llu | groups", items[bi], visits[vi], w, r[18] - r[0], r[2] - r[0]);
             for (int i = 2; i < 17; ++i) printf(" %3llu", r[i + 1] - r[i]);
-            printf(" | last %3llu\n", r[18] - r[17]);
+            printf(" | last %3llu", r[18] - r[17]);
+            if (vi == 5) printf(" | end-of-visit->epilogue %llu epilogue %llu reset %llu", r[21] - r[18], r[22] - r[21], r[23] - r[22]);
+            printf("\n");
         }
     }
     return 0;

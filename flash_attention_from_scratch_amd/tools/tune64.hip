@@ -21,8 +21,8 @@ static hipEvent_t e0, e1;
 template <int ABL> void launch(const fa::KernelArgs &a) {
     auto kern = fa::fa_fwd_kernel<15, 2, 4, 64, true, true, true, true, true, false, 128, ABL>;
     static bool init = false;
-    if (!init) { CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 131072)); init = true; }
-    hipLaunchKernelGGL(kern, dim3(a.n_bh * a.n_q_blocks), dim3(256), 131072, 0, a);
+    if (!init) { CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 163840)); init = true; }
+    hipLaunchKernelGGL(kern, dim3(a.n_bh * a.n_q_blocks < 256 ? a.n_bh * a.n_q_blocks : 256), dim3(256), 163840, 0, a);
 }
 template <int ABL> void add(const char *name) {
     if (only_abl >= 0 && ABL != only_abl) return;
@@ -76,8 +76,9 @@ int main(int argc, char **argv) {
 #define X(abl, name) add<abl>(name);
 #include "tune64_list.inc"
 #undef X
-    for (int pass = 0; pass < 2; ++pass) {
-        S = pass ? 16384 : 4096;
+    const int seqs[4] = {512, 1024, 4096, 16384};
+    for (int pass = 0; pass < 4; ++pass) {
+        S = seqs[pass];
         time_all();
     }
     return 0;
