@@ -466,18 +466,18 @@ def uses_lazy_rescale(cfg) -> bool:
 
 
 def best_config(dtype=DType.BF16, seq_len=4096, masked=False) -> FlashForwardKernelConfig:
-    """Autotune winner on MI355X (profiles/): from seq_len 2048 up the hand-placed
+    """Autotune winner on MI355X (profiles/): the persistent hand-placed
     64-rows-per-wave kernel (4 waves x 64 rows, 64-key tiles, one wave per SIMD: each LDS operand
-    feeds two MFMAs); below that the pipelined 4-wave x 32-row kernel, whose smaller workgroups
-    fill the chip better and whose prologue is shorter.  masked=True: the best config that has a
-    causal / ragged-length variant (forward_ex): 8 waves x 32 rows with 128-key tiles from
-    seq_len 4096 up."""
+    feeds two MFMAs; one workgroup per CU walks the (batch*head, Q block) items) whenever seq_len is a
+    multiple of its 256-row Q block; otherwise the pipelined 4-wave x 32-row kernel.
+    masked=True: the best config that has a causal / ragged-length variant (forward_ex): 8 waves x
+    32 rows with 128-key tiles from seq_len 4096 up, else 4 waves x 32 rows."""
     if masked:
         if seq_len >= 4096:
             return FlashForwardKernelConfig(
                 DType(dtype), 128, 256, 128, 8, True, True, True, 0, 0, 0, False, True
             )
-    elif seq_len >= 2048 and seq_len % 256 == 0:
+    elif seq_len % 256 == 0:
         return FlashForwardKernelConfig(
             DType(dtype), 128, 256, 64, 4, True, True, True, 0, 0, 0, True, False
         )

@@ -201,6 +201,32 @@ def test_64_row_variant_against_its_lazy_rescale_restatement():
             assert ((out.float().cpu() - oracle).abs() <= tol.cpu()).all()
 
 
+@pytest.mark.parametrize("shape", [(8, 16, 1024), (32, 16, 256), (40, 16, 256), (5, 7, 512), (3, 16, 2048)],
+                         ids=lambda s: "B%d_H%d_S%d" % s)
+def test_persistent_walk_seams(shape):
+    """The 64-rows-per-wave kernel is persistent: 256 workgroups walk B*H*S/256 items, keep the K/V
+    tile stream running across item seams and form the next item's S(0) in the last visit of the
+    current one.  More items than workgroups (uneven last round included), the 4-tile minimum
+    (S = 256: every request already belongs to the next item), batch*heads not a multiple of 8 (no
+    XCD-aware mapping): compare with the 32-rows-per-wave kernel and with fp32 eager on a slice, and
+    require bitwise run-to-run determinism (a cold first run included: the operand-register hazard
+    the schedule guards against showed up exactly there)."""
+    B, H, S = shape
+    for dtype, name in ((torch.bfloat16, kc.DType.BF16), (torch.float16, kc.DType.FP16)):
+        cfg = kc.FlashForwardKernelConfig(name, 128, 256, 64, 4, True, True, True, 0, 0, 0, True, False)
+        other = kc.FlashForwardKernelConfig(name, 128, 128, 64, 4, True, True, True, 0, 0, 0, True, False)
+        qc = ut.QKVConfig(n_heads=H, d_head=128, batch_size=B, seq_len=S, dtype=dtype, device=torch.device(DEV))
+        q, k, v = ut.generate_qkv(qc, seed=B + S)
+        torch.cuda.synchronize()
+        runs = [flash_attention.forward(cfg, q, k, v) for _ in range(4)]
+        assert all(torch.equal(runs[0], r) for r in runs[1:]), (str(cfg), shape)
+        ref = flash_attention.forward(other, q, k, v)
+        assert (runs[0].float() - ref.float()).abs().max().item() <= 2 * TOL[dtype]
+        sl = slice(B - 1, B)  # the items served last
+        eager = ut.py_flash_attention(q[sl], k[sl], v[sl], upcast=True)
+        assert (runs[0][sl].float() - eager.float()).abs().max().item() <= TOL[dtype]
+
+
 def test_error_behaviour_matches_reference():
     cfg = kc.best_config(kc.DType.BF16)
     q = torch.zeros((1, 512, 2, 128), dtype=torch.bfloat16, device=DEV)

@@ -2,7 +2,7 @@
 import os
 import textwrap
 
-from flash_attention_from_scratch_amd.tools import isa_stats, kernel_resources, rocprof_bench
+from flash_attention_from_scratch_amd.tools import isa_lint64, isa_stats, kernel_resources, rocprof_bench
 from flash_helpers import kernel_configs as kc
 
 SAMPLE_ASM = textwrap.dedent("""\
@@ -98,3 +98,49 @@ def test_generated_variant_list_is_current_and_covers_every_config():
     wanted = {gen.variant_of(cfg) for cfg in kc.get_all_supported_configs()}
     assert wanted == built
     assert masked == {v for v in wanted if gen.has_masked_variant(v)} and masked
+
+
+LINT_SAMPLE = textwrap.dedent("""\
+    \tv_cvt_pk_bf16_f32 v20, v1, v2
+    \tv_mfma_f32_32x32x16_bf16 a[0:15], v[16:19], v[20:23], a[0:15]
+    \tv_mov_b32_e32 v17, v40
+    \tv_add_f32_e32 v50, v51, v52
+    \tv_mfma_f32_32x32x16_bf16 a[16:31], v[24:27], v[28:31], a[16:31]
+    \tv_add_f32_e32 v60, v61, v62
+    \tds_read_b128 v[24:27], v99
+    \ts_endpgm
+    """)
+
+
+def test_isa_lint_flags_operand_war_and_raw(tmp_path):
+    f = tmp_path / "k.s"
+    f.write_text(LINT_SAMPLE)
+    kinds = sorted(k for k, *_ in isa_lint64.lint(str(f), window=3, raw=2))
+    # v_cvt_pk right in front of the MFMA that reads v20 (RAW); v_mov into v17 and the ds_read into
+    # v[24:27] right behind the MFMAs that read them (WAR)
+    assert kinds == ["RAW", "WAR", "WAR"]
+
+
+def test_isa_lint_on_the_built_64_row_kernels(tmp_path):
+    """Compile the two hand-placed kernels to ISA (as the library build does) and require that no
+    instruction near an inline-asm MFMA touches its operand registers: hipcc cannot see these
+    hazards, the schedule has to avoid them by construction."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        import pytest
+        pytest.skip("hipcc not available")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, "flash_attention_from_scratch_amd", "csrc")
+    src = tmp_path / "probe.hip"
+    src.write_text('#include "fa_registry.hpp"\nnamespace fa { const KernelEntry kE[] = {'
+                   " make_entry<15, 2, 4, 64, true, true, false, true, true>(),"
+                   " make_entry<5, 2, 4, 64, true, true, false, true, true>() }; }\n")
+    out = tmp_path / "probe.s"
+    subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fno-slp-vectorize", "-S",
+                    "--cuda-device-only", "-I", csrc, str(src), "-o", str(out)], check=True, timeout=600)
+    text = out.read_text()
+    assert text.count("v_mfma_f32_32x32x16") >= 2 * (32 + 4 * 64)
+    assert "scratch_" not in text
+    assert isa_lint64.lint(str(out), window=4, raw=3) == []
