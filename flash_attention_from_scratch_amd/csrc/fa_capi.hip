@@ -141,6 +141,9 @@ int validate(const fa_fwd_args *a, const fa::KernelEntry **out, bool masked = fa
                     (long long)a->d_head, a->cfg.d_head);
     if (a->batch <= 0 || a->seq_len <= 0 || a->n_heads <= 0)
         return fail(FA_ERR_SHAPE, "batch, seq_len and n_heads must be positive");
+    if (masked && e->masked == 2 && (a->seq_len % a->cfg.B_r != 0 || a->seq_len % a->cfg.B_c != 0))
+        return fail(FA_ERR_SHAPE, "the masked variant of this configuration handles the causal mask only: "
+                                  "seq_len must be a multiple of B_r and B_c");
     if (!masked && a->seq_len % a->cfg.B_r != 0)
         return fail(FA_ERR_SHAPE, "Only multiples of B_r are supported for seq_len Q currently");
     if (!masked && a->seq_len % a->cfg.B_c != 0)

@@ -331,7 +331,10 @@ struct Plan64 {
 // 2 DMA pieces late in phase 2 instead of early in phase 1
 constexpr Plan64 make_plan64(int variant, int n_phase1) {
     Plan64 p{};
-    const bool bar_top = variant & 1, dma_late = variant & 2;
+    const bool bar_top = variant & 1, dma_late = variant & 2, masked = variant & 4;
+    // masked: gaps 32..35 of a diagonal visit rewrite S(it+1) (causal mask) before its row max is
+    // taken, so the 32 row-max units start 4 gaps later and the end-of-visit chain runs in 5 steps
+    const int m0 = masked ? 4 : 0, odd0 = masked ? 11 : 9, mend = masked ? 27 : 24;
     int e = 0, m = 0, d = 0;
     for (int g = 0; g < 64; ++g) {
         const int h = g - 32;
@@ -351,12 +354,13 @@ constexpr Plan64 make_plan64(int variant, int n_phase1) {
                 const int gaps_left = (21 - h) / 2 + 1;
                 ne = (32 - e + gaps_left - 1) / gaps_left;            // 1, or 2 while behind
             }
-            if (h < 24) {
+            if (h >= m0 && h < mend) {
                 if (!(h & 1)) nm = 2;                                 // even gaps (with the V reads): 2
-                else if (h >= 9) nm = 1;                              // late odd gaps: 1  -> 24 + 8 = 32
+                else if (h >= odd0) nm = 1;                           // late odd gaps: 1  -> 24 + 8 = 32
             }
             if (dma_late && h >= 24) dm = d++;
-            if (h >= 24) tl = h - 23;                                 // chain steps 1..8
+            if (masked) { if (h >= 27) tl = 10 + (h - 27); }          // merged chain steps 10..14
+            else if (h >= 24) tl = h - 23;                            // chain steps 1..8
         }
         p.exp_first[g] = (signed char)e; p.exp_n[g] = (signed char)ne; e += ne;
         p.max_first[g] = (signed char)m; p.max_n[g] = (signed char)nm; m += nm;
@@ -374,7 +378,7 @@ constexpr bool plan64_ok(const Plan64 &p) {
         // S(it+1) tiles: nt = 0 last written at gap 29, nt = 1 at gap 31; read >= 2 MFMAs later
         for (int u = p.max_first[g]; u < p.max_first[g] + p.max_n[g]; ++u)
             if (g < ((u >> 4) ? 34 : 32)) return false;
-        if (p.tail[g] == 1 && m < 32) return false;
+        if ((p.tail[g] == 1 || p.tail[g] == 10) && m < 32) return false;
         if (p.barrier[g]) bar = g;
         if (p.dma[g] >= 0 && bar >= 0 && g <= bar) return false;      // DMA overwrites what the barrier frees
         if (p.barrier[g] && g >= 28) return false;                    // V(it+1) is first read at gap 30
@@ -445,7 +449,7 @@ fa_fwd_kernel(const KernelArgs args) {
     };
     int bh, qb;
     item_coords(blockIdx.x, bh, qb);
-    if (MASK && args.causal) qb = nq - 1 - qb;  // longest rows first
+    if (MASK && args.causal && !TR::kPersistent) qb = nq - 1 - qb;  // longest rows first
     const int b = bh / args.n_heads, h = bh % args.n_heads;
     const int64_t ss = args.seq_stride;
     const int64_t head_off = (int64_t)b * args.batch_stride + (int64_t)h * args.head_stride;
@@ -821,10 +825,10 @@ fa_fwd_kernel(const KernelArgs args) {
         // reference's eager rescale (softmax.cuh:36-49); only the rounding point of P differs,
         // with the same relative error.  With O in the accumulator file a rescale costs ~200
         // issue slots per Q tile, and for random data some row of 32 finds a new max in most tiles.
-        static_assert(DMA && !MASK && D == 128 && BC == 64 && NT == 2 && NWAVES == 4, "64-row pinned schedule");
+        static_assert(DMA && D == 128 && BC == 64 && NT == 2 && NWAVES == 4, "64-row pinned schedule");
         static_assert(TR::kStages == 4, "ring depth");
         constexpr float TAU = 8.0f;
-        constexpr Plan64 plan = make_plan64((ABL >> 8) & 3, (ABL & 1024) ? 20 : 22);
+        constexpr Plan64 plan = make_plan64(((ABL >> 8) & 3) | (MASK ? 4 : 0), (ABL & 1024) ? 20 : 22);
         static_assert(plan64_ok(plan), "filler plan violates a wait-state distance");
         f32x16 Sa[2][NT], Sb[2][NT];
         u32x4 Pw[2][4] = {};     // P[qt][16-key slice]: B operand of O^T += V^T P^T
@@ -865,19 +869,44 @@ fa_fwd_kernel(const KernelArgs args) {
         uint16_t *On = Og;
         int qb_n = qb;
         bool has_next = false;
+        // causal (MASK variants): an item visits the tiles up to its diagonal only, 4 (qb + 1) of them
+        // -- still a multiple of the ring depth, so the stage arithmetic along the walk holds
+        const bool causal = MASK && args.causal;
+        int nkc = n_kv, nkn = n_kv;  // tiles of the current / next item
         auto tile_g = [&](const uint16_t *cur, const uint16_t *nxt, int j) {
-            return j < n_kv ? cur + (int64_t)(n_kv - 1 - j) * tile_stride
-                            : nxt + (int64_t)(2 * n_kv - 1 - j) * tile_stride;
+            return j < nkc ? cur + (int64_t)(nkc - 1 - j) * tile_stride
+                           : nxt + (int64_t)(nkn - 1 - (j - nkc)) * tile_stride;
+        };
+        // MASK: logits above the causal diagonal become -inf.  `tile` counts from the start of the
+        // sequence, `qb_rows` is the Q block whose rows the S tile belongs to.  A wave's 64 rows meet
+        // the diagonal in exactly one 64-key tile; tiles beyond it are masked whole.
+        auto mask_tile = [&](auto &S, int tile, int qb_rows) {
+            if constexpr (MASK) {
+                const int d = tile - (4 * qb_rows + wave);
+                if (causal && d >= 0) {  // wave-uniform
+#pragma unroll
+                    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                const int key = 32 * nt + (r & 3) + 8 * (r >> 2) + 4 * hi, row = 32 * qt + r31;
+                                S[qt][nt][r] = (d > 0 || key > row) ? -__builtin_inff() : S[qt][nt][r];
+                            }
+                }
+            }
         };
         auto dma_k = [&](const uint16_t *src, int stage) {
 #pragma unroll
             for (int j = 0; j < DMA_PER_WAVE; ++j)
-                glds16_sv_m0(src, k_off[j], smem_base + stage * TILE + (wave + NWAVES * j) * 1024);
+                glds16_sv_m0(MASK ? src + j * (16 * ss) : src, k_off[MASK ? 0 : j],
+                             smem_base + stage * TILE + (wave + NWAVES * j) * 1024);
         };
         auto dma_v = [&](const uint16_t *src, int stage) {
 #pragma unroll
             for (int j = 0; j < DMA_PER_WAVE; ++j)
-                glds16_sv_m0(src, v_off[j], smem_base + V_BASE + stage * TILE + (wave + NWAVES * j) * 1024);
+                glds16_sv_m0(MASK ? src + j * (16 * ss) : src, v_off[MASK ? 0 : j],
+                             smem_base + V_BASE + stage * TILE + (wave + NWAVES * j) * 1024);
         };
         const uint16_t *kq = nullptr, *vq = nullptr;  // next K / V tile to request (set per item below)
         vec8 ring[4];  // operand ring: slot u % 4, rewritten two steps after the MFMAs that read it
@@ -918,7 +947,7 @@ fa_fwd_kernel(const KernelArgs args) {
             };
             if constexpr (R == 3) {
                 // last visit of an item forms the next item's S(0): swap the next item's Q in
-                if (it + 1 == n_kv && has_next) {
+                if (it + 1 == nkc && has_next) {
                     asm volatile("s_waitcnt vmcnt(16)" ::: "memory");  // the Q loads (visit 0) are older than 16 pieces
 #pragma unroll
                     for (int qt = 0; qt < 2; ++qt)
@@ -943,7 +972,7 @@ fa_fwd_kernel(const KernelArgs args) {
                     if (!(resc_any & (1u << qt))) continue;
                     const float alpha = __builtin_amdgcn_exp2f((m[qt] - m_pend[qt]) * c);
                     m[qt] = m_pend[qt];
-                    neg_msc[qt] = -(m[qt] * c);
+                    neg_msc[qt] = -(finite_or_zero(m[qt]) * c);
                     l[qt] *= alpha;
 #pragma unroll
                     for (int t = 0; t < DTILES; ++t)
@@ -991,7 +1020,7 @@ fa_fwd_kernel(const KernelArgs args) {
                 auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
                 return vmax2(__uint_as_float(r[0]), __uint_as_float(r[1]));
             };
-            auto tail_step = [&](int k) {  // end-of-visit chain, one step per gap (pinned by volatile asm)
+            auto tail_unit = [&](int k) {  // end-of-visit chain, one step per gap (pinned by volatile asm)
                 if (k == 1) {
                     vm[0][0] = vmax2(vm[0][0], vm[0][1]);
                     vm[1][0] = vmax2(vm[1][0], vm[1][1]);
@@ -1021,11 +1050,19 @@ fa_fwd_kernel(const KernelArgs args) {
                 if (k == 8) {  // next tiles to request (scalar ALU)
                     resc_any = any01;
                     // visit it+1 requests K(it+5), V(it+4); the stream wraps into the next item
-                    kq = (it + 5 == n_kv) ? Kn + (int64_t)(n_kv - 1) * tile_stride : kq - tile_stride;
-                    vq = (it + 4 == n_kv) ? Vn + (int64_t)(n_kv - 1) * tile_stride : vq - tile_stride;
+                    kq = (it + 5 == nkc) ? Kn + (int64_t)(nkn - 1) * tile_stride : kq - tile_stride;
+                    vq = (it + 4 == nkc) ? Vn + (int64_t)(nkn - 1) * tile_stride : vq - tile_stride;
                     if constexpr (R == 1) seam = false;
 
                 }
+            };
+            auto tail_step = [&](int k) {  // plan step: 1..8 one unit each; 10..14 the masked plan's merged steps
+                if (k < 10) tail_unit(k);
+                if (k == 10) tail_unit(1);
+                if (k == 11) { tail_unit(2); tail_unit(3); }
+                if (k == 12) { tail_unit(4); tail_unit(5); }
+                if (k == 13) { tail_unit(6); tail_unit(7); }
+                if (k == 14) tail_unit(8);
             };
             // operand u of the visit: 16 K fragments, 16 V fragments, then the first two K fragments
             // of the NEXT visit (its tile was published by this visit's barrier), so that no LDS
@@ -1066,6 +1103,12 @@ fa_fwd_kernel(const KernelArgs args) {
                 }
                 if constexpr (g == 0) asm volatile("" ::"v"(Pw[1][3]));  // ... of the previous visit's last one
                 if constexpr (plan.barrier[g] != 0) sync_point();
+                if constexpr (MASK && g == 34) {
+                    // S(it+1) is complete (last written at gap 31): causal mask, before its row max.
+                    // The last visit's S tile is the NEXT item's S(0).
+                    if (it + 1 < nkc) mask_tile(S_nxt, nkc - 2 - it, qb_c);
+                    else mask_tile(S_nxt, nkn - 1, qb_n);
+                }
                 if constexpr (R == 0 && g == 33) {
                     // first visit of an item: request the NEXT item's Q rows into the spare Q set
                     // (64 of the AGPRs are otherwise unused); they are swapped in at the top of
@@ -1079,10 +1122,17 @@ fa_fwd_kernel(const KernelArgs args) {
                 }
                 if constexpr (plan.dma[g] >= 0 && !(ABL & 16)) {  // one 1-KiB DMA piece
                     constexpr int j = plan.dma[g] >> 1;
-                    // per-piece lane offsets: 6 more VGPRs than one offset + a scalar piece stride, but
-                    // 16 fewer SALU instructions per visit (+0.5 %)
-                    if constexpr ((plan.dma[g] & 1) == 0) glds16_sv_m0(kq, k_off[j], kdst + NWAVES * j * 1024);
-                    else glds16_sv_m0(vq, v_off[j], vdst + NWAVES * j * 1024);
+                    // per-piece lane offsets: 6 more VGPRs than one offset + a scalar piece stride (piece j
+                    // of a wave starts 16 rows below piece j-1), but 16 fewer SALU instructions per
+                    // visit (+0.5 %).  The masked variant has no VGPRs to spare and takes the stride.
+                    if constexpr (MASK) {
+                        const int64_t piece_stride = 16 * ss;
+                        if constexpr ((plan.dma[g] & 1) == 0) glds16_sv_m0(kq + j * piece_stride, k_off[0], kdst + NWAVES * j * 1024);
+                        else glds16_sv_m0(vq + j * piece_stride, v_off[0], vdst + NWAVES * j * 1024);
+                    } else {
+                        if constexpr ((plan.dma[g] & 1) == 0) glds16_sv_m0(kq, k_off[j], kdst + NWAVES * j * 1024);
+                        else glds16_sv_m0(vq, v_off[j], vdst + NWAVES * j * 1024);
+                    }
                 }
                 static_for<0, plan.exp_n[g]>([&](auto i) { exp_unit(plan.exp_first[g] + decltype(i)::value); });
                 static_for<0, plan.max_n[g]>([&](auto i) { max_unit(plan.max_first[g] + decltype(i)::value); });
@@ -1098,11 +1148,29 @@ fa_fwd_kernel(const KernelArgs args) {
 #endif
         };
         // ---- first item: prologue -------------------------------------------------------------
+        // causal: an item costs ~(qb + 1), and along the walk a workgroup would meet the same Q-block
+        // position of a head again and again (round r: slot w + G r of the XCD's item list).  So
+        // odd rounds run their G-slot window of a head (or their whole heads, if a head is shorter than
+        // the window) in reverse: still every Q block of every head exactly once, and two consecutive
+        // rounds sum to the same work for every workgroup.  Needs windows and rounds to line up
+        // (Q blocks per head and workgroups per XCD both powers of two, as a rule); otherwise the walk
+        // stays in order -- correct, just less balanced.
+        auto walk_qb = [&](int it_, int pos) {
+            const int G = (args.n_bh & 7) == 0 ? (int)gridDim.x >> 3 : (int)gridDim.x;
+            const int W = nq < G ? nq : G;
+            if (W <= 0 || G % W != 0 || nq % W != 0) return pos;
+            const int in_w = pos % W;
+            return (pos / W) * W + (((it_ / (int)gridDim.x) & 1) ? W - 1 - in_w : in_w);
+        };
         auto set_next = [&]() {  // coordinates of the item after `item` (or `item` again)
             const int nitem = item + (int)gridDim.x;
             has_next = nitem < n_items;
             int bh_n;
             item_coords(has_next ? nitem : item, bh_n, qb_n);
+            if (causal) {
+                qb_n = walk_qb(has_next ? nitem : item, qb_n);
+                nkn = 4 * (qb_n + 1);
+            }
             const int b_n = bh_n / args.n_heads, h_n = bh_n % args.n_heads;
             const int64_t off_n = (int64_t)b_n * args.batch_stride + (int64_t)h_n * args.head_stride;
             Qn = (const uint16_t *)args.q + off_n;
@@ -1136,6 +1204,7 @@ fa_fwd_kernel(const KernelArgs args) {
             asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // MFMA D -> VALU read
 #pragma unroll
             for (int step = 0; step < 16; ++step) asm volatile("" ::"v"(a_all[step]));
+            mask_tile(Sa, nkc - 1, qb_c);
 #pragma unroll
             for (int qt = 0; qt < 2; ++qt) {
                 float v = Sa[qt][0][0];
@@ -1144,7 +1213,7 @@ fa_fwd_kernel(const KernelArgs args) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) v = fmaxf(v, Sa[qt][nt][r]);
                 m[qt] = pair_max(v);
-                neg_msc[qt] = -(m[qt] * c);
+                neg_msc[qt] = -(finite_or_zero(m[qt]) * c);
                 m_pend[qt] = m[qt];
             }
             ring[0] = k_frag(smem + TILE, 0);  // first operands of visit 0: K(1)
@@ -1195,7 +1264,7 @@ fa_fwd_kernel(const KernelArgs args) {
         };
         // seq_len is a multiple of B_r = 256, so n_kv = seq_len / 64 is a multiple of 4 = ring depth
         for (;;) {
-            for (int it = 0; it < n_kv; it += 4) {
+            for (int it = 0; it < nkc; it += 4) {
                 visit(it, Sa, Sb, IntTag<0>{});
                 visit(it + 1, Sb, Sa, IntTag<1>{});
                 visit(it + 2, Sa, Sb, IntTag<2>{});
@@ -1214,6 +1283,7 @@ fa_fwd_kernel(const KernelArgs args) {
             // first tiles are landed or in flight, its first operands sit in the ring
             item += (int)gridDim.x;
             Kc = Kn; Vc = Vn; Oc = On; qb_c = qb_n;
+            nkc = nkn;
             set_next();
             kq = tile_g(Kc, Kn, 4);  // visit 0 requests K(4), V(3) (for n_kv == 4 that is already the item after)
             vq = tile_g(Vc, Vn, 3);
@@ -1222,7 +1292,7 @@ fa_fwd_kernel(const KernelArgs args) {
 #pragma unroll
             for (int qt = 0; qt < 2; ++qt) {
                 m[qt] = mraw[qt];
-                neg_msc[qt] = -(m[qt] * c);
+                neg_msc[qt] = -(finite_or_zero(m[qt]) * c);
                 m_pend[qt] = m[qt];
                 l[qt] = 0.0f;
 #pragma unroll

@@ -21,7 +21,7 @@ struct KernelEntry {
     int opt_softmax;
     int pipelined;      // cfg.mma_double_buffer_loads
     int async_copy;     // 1: LDS-DMA transport, 0: register-staged
-    int masked;         // 1: handles ragged seq_len and the causal mask
+    int masked;         // 1: handles ragged seq_len and the causal mask; 2: causal mask only (seq_len % B_r == 0)
     int d_head;         // 128 (reference scope) or 64
     int threads;
     int lds_bytes;
@@ -33,7 +33,7 @@ template <int DT, int QT, int NWAVES, int BC, bool SWZ, bool EAGER, bool OPT, bo
           bool MASK = false, int D = 128>
 constexpr KernelEntry make_entry() {
     using TR = FwdTraits<DT, QT, NWAVES, BC, SWZ, EAGER, OPT, PIPE, DMA, MASK, D>;
-    return KernelEntry{DT, 32 * QT, NWAVES, BC, SWZ, EAGER, OPT, PIPE, DMA, MASK, D, TR::kThreads,
+    return KernelEntry{DT, 32 * QT, NWAVES, BC, SWZ, EAGER, OPT, PIPE, DMA, MASK ? (TR::kPersistent ? 2 : 1) : 0, D, TR::kThreads,
                        TR::kLdsBytes, TR::kPersistent,
                        (kernel_fn)&fa_fwd_kernel<DT, QT, NWAVES, BC, SWZ, EAGER, OPT, PIPE, DMA, MASK, D>};
 }

@@ -470,9 +470,10 @@ def best_config(dtype=DType.BF16, seq_len=4096, masked=False) -> FlashForwardKer
     64-rows-per-wave kernel (4 waves x 64 rows, 64-key tiles, one wave per SIMD: each LDS operand
     feeds two MFMAs; one workgroup per CU walks the (batch*head, Q block) items) whenever seq_len is a
     multiple of its 256-row Q block; otherwise the pipelined 4-wave x 32-row kernel.
-    masked=True: the best config that has a causal / ragged-length variant (forward_ex): 8 waves x
-    32 rows with 128-key tiles from seq_len 4096 up, else 4 waves x 32 rows."""
-    if masked:
+    masked=True: the best config that has a causal / ragged-length variant (forward_ex): the same
+    persistent kernel when seq_len is a multiple of 256 (its masked form does the causal mask only),
+    otherwise 8 waves x 32 rows with 128-key tiles from seq_len 4096 up, else 4 waves x 32 rows."""
+    if masked and seq_len % 256 != 0:
         if seq_len >= 4096:
             return FlashForwardKernelConfig(
                 DType(dtype), 128, 256, 128, 8, True, True, True, 0, 0, 0, False, True

@@ -302,7 +302,7 @@ def _rel_ok(out, ref, dtype):
 
 
 @pytest.mark.parametrize("causal", [False, True], ids=["full", "causal"])
-@pytest.mark.parametrize("S", [1, 100, 257, 1000, 2048, 2500])
+@pytest.mark.parametrize("S", [1, 100, 256, 257, 1000, 2048, 2500, 2560])
 def test_masked_variants_against_eager_sdpa_and_oracle(S, causal):
     assert len(MASKED) >= 10
     for dtype in (torch.bfloat16, torch.float16):
@@ -314,6 +314,11 @@ def test_masked_variants_against_eager_sdpa_and_oracle(S, causal):
         oracle = None
         for cfg in MASKED:
             if cfg.dtype.to_torch_dtype() != dtype:
+                continue
+            if kc.uses_lazy_rescale(cfg) and S % cfg.B_r:
+                # the persistent kernel's masked form does the causal mask only (fa_kernel_info.masked == 2)
+                with pytest.raises(RuntimeError, match="causal mask only"):
+                    flash_attention.forward_ex(cfg, q, k, v, causal=causal)
                 continue
             out = flash_attention.forward_ex(cfg, q, k, v, causal=causal)
             assert torch.isfinite(out.float()).all(), (str(cfg), S, causal)
@@ -335,8 +340,32 @@ def test_masked_variant_equals_plain_kernel_when_nothing_is_masked():
         assert torch.equal(flash_attention.forward_ex(cfg, q, k, v), flash_attention.forward(cfg, q, k, v)), str(cfg)
 
 
+@pytest.mark.parametrize("shape", [(8, 16, 1024), (40, 16, 256), (5, 7, 512), (3, 16, 2048), (2, 16, 4096),
+                                   (1, 8, 16384), (2, 4, 6144)], ids=lambda s: "B%d_H%d_S%d" % s)
+def test_persistent_walk_causal(shape):
+    """Causal mask on the persistent 64-rows-per-wave kernel: items of different length (4 (qb + 1)
+    tiles) along one walk, the mask applied to the S tile a visit forms for the NEXT item, waves whose
+    first tiles are masked whole (m = -inf until their diagonal tile).  Against fp32 eager with the
+    mask, the masked 32-rows-per-wave kernel, and itself (bitwise)."""
+    B, H, S = shape
+    for dtype, name in ((torch.bfloat16, kc.DType.BF16), (torch.float16, kc.DType.FP16)):
+        cfg = kc.FlashForwardKernelConfig(name, 128, 256, 64, 4, True, True, True, 0, 0, 0, True, False)
+        other = kc.FlashForwardKernelConfig(name, 128, 128, 64, 4, True, True, True, 0, 0, 0, True, False)
+        qc = ut.QKVConfig(n_heads=H, d_head=128, batch_size=B, seq_len=S, dtype=dtype, device=torch.device(DEV))
+        q, k, v = ut.generate_qkv(qc, seed=B + S + 1)
+        runs = [flash_attention.forward_ex(cfg, q, k, v, causal=True) for _ in range(3)]
+        assert torch.isfinite(runs[0].float()).all()
+        assert all(torch.equal(runs[0], r) for r in runs[1:]), (str(cfg), shape)
+        ref = flash_attention.forward_ex(other, q, k, v, causal=True)
+        assert _rel_ok(runs[0], ref, dtype) or (runs[0].float() - ref.float()).abs().max().item() <= 2 * TOL[dtype]
+        for b, h in ((0, 0), (B - 1, H - 1)):  # one head each: the fp32 score matrix is S x S
+            qs, ks, vs = (t[b:b + 1, :, h:h + 1].contiguous() for t in (q, k, v))
+            eager = fo.eager_attention_masked(qs, ks, vs, True)
+            assert _rel_ok(runs[0][b:b + 1, :, h:h + 1], eager, dtype), (str(cfg), shape)
+
+
 def test_reference_errors_unchanged_without_the_wideners():
-    cfg = kc.best_config(kc.DType.BF16, masked=True)
+    cfg = kc.best_config(kc.DType.BF16, seq_len=320, masked=True)
     q = torch.zeros((1, 320, 2, 128), dtype=torch.bfloat16, device=DEV)
     with pytest.raises(RuntimeError, match="multiples of B_r"):
         flash_attention.forward(cfg, q, q, q)
