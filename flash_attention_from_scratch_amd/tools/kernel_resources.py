@@ -57,11 +57,16 @@ def collect():
         cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", f"-DFA_INST_DT={dt}",
                f"-DFA_INST_QT={qt}", "-Rpass-analysis=kernel-resource-usage", "-I", CSRC, "-c",
                os.path.join(CSRC, src), "-o", os.devnull]
+        if qt == 2:
+            cmd.insert(1, "-fno-slp-vectorize")  # as csrc/Makefile builds the 64-rows-per-wave slice (QT2FLAGS)
         rows += parse_remarks(subprocess.run(cmd, capture_output=True, text=True).stderr)
     for r in rows:
         r["B_r"] = r.get("rows_per_wave", 0) * r.get("n_waves", 0)
         stages = 2 if r.get("eager") else 1
         r["lds_bytes"] = max(2 * stages * r.get("B_c", 0), r["B_r"]) * 2 * r.get("d_head", 128)
+        if r.get("rows_per_wave") == 64 and r.get("pipelined"):
+            # the persistent schedule: 4-stage K and V rings + 8 KiB of O staging per wave
+            r["lds_bytes"] = (2 * 4 * r.get("B_c", 0) + 32 * r.get("n_waves", 0)) * 2 * r.get("d_head", 128)
     return rows
 
 
