@@ -599,7 +599,7 @@ fa_fwd_kernel(const KernelArgs args) {
     // ---- prologue: first tiles in flight, then Q -> VGPRs --------------------------
     if (EAGER && DMA) {
         issue_k(0, 0);
-        issue_v(0, 0);
+        if (!TR::kPersistent) issue_v(0, 0);  // the persistent kernel asks for Q before V(0): see its prologue
     }
     if (!DMA) {
         load_k(0);
@@ -1179,16 +1179,18 @@ fa_fwd_kernel(const KernelArgs args) {
             On = (uint16_t *)args.o + off_n;
         };
         set_next();
-        // K(0), V(0) are in flight (common code); then K(1) | K(2), V(1) | K(3), V(2) in the order the
-        // counted waits assume
+        // Every CU starts at once and the first requests (176 KB per workgroup) return at ~11 B/cycle
+        // per CU, in issue order: K(0) and Q -- all S(0) needs -- were asked for first (common code);
+        // then K(1), V(0) | K(2), V(1) | K(3), V(2) in the order the counted waits assume.
         dma_k(tile_g(Kc, Kn, 1), 1);
+        dma_v(tile_g(Vc, Vn, 0), 0);
         dma_k(tile_g(Kc, Kn, 2), 2);
         dma_v(tile_g(Vc, Vn, 1), 1);
         dma_k(tile_g(Kc, Kn, 3), 3);
         dma_v(tile_g(Vc, Vn, 2), 2);
         kq = tile_g(Kc, Kn, 4);
         vq = tile_g(Vc, Vn, 3);
-        if (!(ABL & 8)) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");  // K(0), V(0), K(1) landed
+        if (!(ABL & 8)) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");  // K(0), Q landed
         barrier();
         {
             // S(0) and its row max, which becomes the first reference max (O = l = 0)
@@ -1216,6 +1218,8 @@ fa_fwd_kernel(const KernelArgs args) {
                 neg_msc[qt] = -(finite_or_zero(m[qt]) * c);
                 m_pend[qt] = m[qt];
             }
+            if (!(ABL & 8)) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");  // K(1) landed (under S(0))
+            barrier();
             ring[0] = k_frag(smem + TILE, 0);  // first operands of visit 0: K(1)
             ring[1] = k_frag(smem + TILE, 1);
         }

@@ -364,6 +364,32 @@ def test_persistent_walk_causal(shape):
             assert _rel_ok(runs[0][b:b + 1, :, h:h + 1], eager, dtype), (str(cfg), shape)
 
 
+def test_persistent_walk_random_shapes():
+    """Seeded fuzz over (batch, heads, seq_len multiple of 256), both dtypes, full and causal: the
+    persistent kernel against the 32-rows-per-wave kernels (different tile shape, eager rescale),
+    bitwise repeatable.  Item counts from 1 to a few thousand, heads not a multiple of 8, uneven
+    last rounds of the walk."""
+    import random
+    rng = random.Random(20260927)
+    for trial in range(24):
+        B, H = rng.choice([1, 2, 3, 5, 9, 17]), rng.choice([1, 2, 3, 4, 8, 12, 16])
+        S = 256 * rng.choice([1, 2, 3, 4, 5, 8, 12, 16])
+        if B * H * S > 17 * 16 * 2048:
+            S = 256 * rng.choice([1, 2, 4])
+        causal = bool(trial & 1)
+        dtype, name = ((torch.bfloat16, kc.DType.BF16), (torch.float16, kc.DType.FP16))[(trial >> 1) & 1]
+        cfg = kc.FlashForwardKernelConfig(name, 128, 256, 64, 4, True, True, True, 0, 0, 0, True, False)
+        other = kc.FlashForwardKernelConfig(name, 128, 128, 64, 4, True, True, True, 0, 0, 0, True, False)
+        gen = torch.Generator(device=DEV).manual_seed(trial)
+        q, k, v = (torch.randn((B, S, H, 128), dtype=dtype, device=DEV, generator=gen) for _ in range(3))
+        a = flash_attention.forward_ex(cfg, q, k, v, causal=causal) if causal else flash_attention.forward(cfg, q, k, v)
+        b = flash_attention.forward_ex(cfg, q, k, v, causal=causal) if causal else flash_attention.forward(cfg, q, k, v)
+        ref = flash_attention.forward_ex(other, q, k, v, causal=causal)
+        assert torch.equal(a, b), (trial, B, H, S, causal)
+        assert torch.isfinite(a.float()).all(), (trial, B, H, S, causal)
+        assert _rel_ok(a, ref, dtype) or (a.float() - ref.float()).abs().max().item() <= 2 * TOL[dtype], (trial, B, H, S, causal)
+
+
 def test_reference_errors_unchanged_without_the_wideners():
     cfg = kc.best_config(kc.DType.BF16, seq_len=320, masked=True)
     q = torch.zeros((1, 320, 2, 128), dtype=torch.bfloat16, device=DEV)
