@@ -51,7 +51,10 @@ def lint(path, window=3, raw=2):
                     break
                 n = code[i + k]
                 if n.startswith("v_") or n.startswith("ds_read") or n.startswith("global_load") or n.startswith("scratch_load"):
-                    if regs(n.split()[1]) & rd:
+                    written = regs(n.split()[1])
+                    if n.startswith("v_permlane32_swap") or n.startswith("v_swap"):
+                        written |= regs(n.split()[2])  # these exchange: both operands are written
+                    if written & rd:
                         findings.append(("WAR", kidx, i, l, n))
             for k in range(1, raw + 1):
                 if i - k < 0 or code[i - k].startswith("v_mfma"):
