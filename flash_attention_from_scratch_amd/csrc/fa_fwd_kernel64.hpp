@@ -1,0 +1,739 @@
+// fa_fwd_kernel64.hpp -- the persistent, hand-placed 64-rows-per-wave Flash-Attention-2 forward
+// (DESIGN.md 3.5): config (B_r 256, B_c 64, 4 waves) + mma_double_buffer_loads, d_head 128.
+// One wave per SIMD owns the whole 512-register file; one workgroup per CU walks the
+// (batch*head, Q block) items.  Same arithmetic contract as fa_fwd_kernel.hpp (reference:
+// src/include/forward_kernel.cuh:85-204, softmax.cuh) except for the lazy rescale documented
+// below; shares that file's element traits, DMA helpers and LDS images.
+#pragma once
+#include "fa_fwd_kernel.hpp"
+
+namespace fa {
+
+// Filler plan of the 64-rows-per-wave schedule: what rides in the gap after MFMA g (g = 0..63 of a
+// visit; 0..31 = QK^T of tile it+1, 32..63 = P.V of tile it).  Built at compile time so that
+// placements can be compared by changing one function (tools/tune64.hip).
+struct Plan64 {
+    signed char exp_first[64], exp_n[64];  // softmax units (2 elements each), 32 per visit, in P.V order
+    signed char max_first[64], max_n[64];  // row-max units over S(it+1), 32 per visit
+    signed char dma[64];                   // DMA piece 0..7 (even = K, odd = V) or -1
+    signed char tail[64];                  // end-of-visit chain step 1.. or 0
+    signed char barrier[64];               // 1: the visit's counted DMA wait + workgroup barrier
+};
+// variant bits (tools/tune64.hip): 1 barrier at the visit top instead of inside the MFMA stream,
+// 2 DMA pieces late in phase 2 instead of early in phase 1
+constexpr Plan64 make_plan64(int variant, int n_phase1) {
+    Plan64 p{};
+    const bool bar_top = variant & 1, dma_late = variant & 2, masked = variant & 4;
+    // masked: gaps 32..35 of a diagonal visit rewrite S(it+1) (causal mask) before its row max is
+    // taken, so the 32 row-max units start 4 gaps later and the end-of-visit chain runs in 5 steps
+    const int m0 = masked ? 4 : 0, odd0 = masked ? 11 : 9, mend = masked ? 27 : 24;
+    int e = 0, m = 0, d = 0;
+    for (int g = 0; g < 64; ++g) {
+        const int h = g - 32;
+        int ne = 0, nm = 0, dm = -1, tl = 0;
+        if (g < 32) {
+            // gaps g % 4 == 0 carry the operand wait + two K reads; gap 2 the barrier; the DMA
+            // pieces follow it, one per four gaps
+            if ((g & 3) == 0) {
+                if (!dma_late && (bar_top || g >= 4)) dm = d++;
+            } else if (e < n_phase1 && (bar_top || g != 2)) {
+                const int slot = (g >> 2) * 3 + (g & 3) - 1;          // 0..23 over the gaps with g % 4 != 0
+                if ((slot + 1) * n_phase1 / 24 > slot * n_phase1 / 24) ne = 1;
+            }
+        } else {
+            if (!dma_late && d < 8 && h == 0) dm = d++;               // the eighth early piece
+            if ((h & 1) && h <= 21 && e < 32) {                       // odd gaps up to 53: the rest of the units
+                const int gaps_left = (21 - h) / 2 + 1;
+                ne = (32 - e + gaps_left - 1) / gaps_left;            // 1, or 2 while behind
+            }
+            if (h >= m0 && h < mend) {
+                if (!(h & 1)) nm = 2;                                 // even gaps (with the V reads): 2
+                else if (h >= odd0) nm = 1;                           // late odd gaps: 1  -> 24 + 8 = 32
+            }
+            if (dma_late && h >= 24) dm = d++;
+            if (masked) { if (h >= 27) tl = 10 + (h - 27); }          // merged chain steps 10..14
+            else if (h >= 24) tl = h - 23;                            // chain steps 1..8
+        }
+        p.exp_first[g] = (signed char)e; p.exp_n[g] = (signed char)ne; e += ne;
+        p.max_first[g] = (signed char)m; p.max_n[g] = (signed char)nm; m += nm;
+        p.dma[g] = (signed char)dm; p.tail[g] = (signed char)tl;
+        p.barrier[g] = (!bar_top && g == 2) ? 1 : 0;
+    }
+    return p;
+}
+constexpr bool plan64_ok(const Plan64 &p) {
+    int e = 0, m = 0, d = 0, bar = -1;
+    for (int g = 0; g < 64; ++g) {
+        // P of 16-key slice s16 is consumed from gap 32 + 8 s16 on: its units must be >= 2 gaps older
+        for (int u = p.exp_first[g]; u < p.exp_first[g] + p.exp_n[g]; ++u)
+            if (g + 2 > 32 + 8 * (u >> 3)) return false;
+        // S(it+1) tiles: nt = 0 last written at gap 29, nt = 1 at gap 31; read >= 2 MFMAs later
+        for (int u = p.max_first[g]; u < p.max_first[g] + p.max_n[g]; ++u)
+            if (g < ((u >> 4) ? 34 : 32)) return false;
+        if ((p.tail[g] == 1 || p.tail[g] == 10) && m < 32) return false;
+        if (p.barrier[g]) bar = g;
+        if (p.dma[g] >= 0 && bar >= 0 && g <= bar) return false;      // DMA overwrites what the barrier frees
+        if (p.barrier[g] && g >= 28) return false;                    // V(it+1) is first read at gap 30
+        e += p.exp_n[g]; m += p.max_n[g]; d += p.dma[g] >= 0;
+    }
+    return e == 32 && m == 32 && d == 8;
+}
+
+template <int DT, bool OPT, bool MASK = false, int ABL = 0>
+__global__ void
+__launch_bounds__(256, 1)
+fa_fwd_kernel64(const KernelArgs args) {
+    constexpr int QT = 2, NWAVES = 4, BC = 64, D = 128;
+    constexpr bool SWZ = true, EAGER = true, PIPE = true, DMA = true;
+
+    using E = Elem<DT>;
+    using vec8 = typename E::vec8;
+    using TR = FwdTraits<DT, QT, NWAVES, BC, SWZ, EAGER, OPT, PIPE, DMA, MASK, D>;
+    constexpr int ROWB = 2 * D;              // bytes per K / V / O row (256, or 128 at d_head 64)
+    constexpr int CPR = D / 8;               // 16-B chunks per row (16 / 8)
+    constexpr int RPP = 64 / CPR;            // tile rows per 1-KiB DMA piece (4 / 8)
+    constexpr int DSUB = D / 32;             // 32-wide d subtiles per key group of the V image
+    // row -> XOR mask of the 16-B chunk index: 16 consecutive rows must land on 16 distinct
+    // 16-B slots of the 256-B LDS bank row (d_head 64: two rows share a bank row)
+    auto swz_of = [](int row) { return D == 128 ? (row & 15) : ((row >> 1) & 7); };
+    constexpr int NT = BC / 32;              // 32-key tiles per LDS tile
+    constexpr int KS = D / 16;               // k steps of the QK^T contraction
+    constexpr int DTILES = D / 32;           // 32-wide d tiles of O^T
+    constexpr int TILE = TR::kTileBytes;
+    constexpr int N_DMA = BC / RPP;          // 1-KiB DMA pieces per K (or V) tile
+    static_assert(N_DMA % NWAVES == 0, "tile/wave split");
+    constexpr int DMA_PER_WAVE = N_DMA / NWAVES;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // LDS carve: K stages 0..3 | V stages 0..3 | O staging (8 KiB per wave)
+    constexpr int V_BASE = TR::kStages * TILE;
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r31 = lane & 31;
+    const int hi = lane >> 5;
+
+    // ---- workgroup -> (batch*head, Q block); XCD-aware when n_bh % 8 == 0 --------
+    const int nq = args.n_q_blocks;
+    // item -> (batch*head, Q block).  Workgroups are dealt round-robin over the 8 XCDs, so items
+    // congruent mod 8 share an L2: give each XCD whole heads (all Q blocks of a head read the same
+    // K / V).  The walk is items blockIdx.x, + gridDim.x, ... with gridDim.x % 8 == 0.
+    auto item_coords = [&](int bid, int &bh_out, int &qb_out) {
+        if ((args.n_bh & 7) == 0) {
+            const int xcd = bid & 7, local = bid >> 3;
+            bh_out = (local / nq) * 8 + xcd;
+            qb_out = local % nq;
+        } else {
+            bh_out = bid / nq;
+            qb_out = bid % nq;
+        }
+    };
+    int bh, qb;
+    item_coords(blockIdx.x, bh, qb);
+    const int b = bh / args.n_heads, h = bh % args.n_heads;
+    const int64_t ss = args.seq_stride;
+    const int64_t head_off = (int64_t)b * args.batch_stride + (int64_t)h * args.head_stride;
+    const uint16_t *Qg = (const uint16_t *)args.q + head_off;
+    const uint16_t *Kg = (const uint16_t *)args.k + head_off;
+    const uint16_t *Vg = (const uint16_t *)args.v + head_off;
+    uint16_t *Og = (uint16_t *)args.o + head_off;
+
+    // ---- per-lane DMA source offsets (elements), invariant over tiles ------------
+    // piece i (wave-uniform) covers LDS chunks [64 i, 64 i + 64) of a tile.
+    //   K: chunk p -> key p>>4, 16-B chunk (p&15) ^ (key&15)
+    //   V: chunk p -> subtile p>>5 = (key>>3)*4 + (d>>5); inside: key&7 = (p&31)>>2,
+    //      d&31 = (p&3)*8
+    const int k_row_in_piece = lane / CPR;                                 // 0..RPP-1
+    // swizzle of tile row RPP*i + k_row_in_piece; i = wave + NWAVES*j and RPP*NWAVES % 16 == 0
+    const int k_swz = SWZ ? swz_of(RPP * wave + k_row_in_piece) : 0;
+    const int64_t k_lane_off = (int64_t)k_row_in_piece * ss + (((lane & (CPR - 1)) ^ k_swz) << 3);
+    const int v_sub_in_piece = lane >> 5;                                  // 0..1
+    const int v_w = lane & 31;
+    const int64_t v_lane_row = (v_w >> 2);                                 // key & 7
+    const int v_lane_d = (v_w & 3) * 8;
+
+    // KV blocks are visited last-to-first (forward_kernel.cuh:142,175-184): visit index `it` is
+    // sequence block n_kv-1-it.  Causal: only the 4 (qb + 1) tiles up to the item's diagonal.
+    const int n_kv = (MASK && args.causal) ? 4 * (qb + 1) : args.n_kv_blocks;
+    const unsigned smem_base = __builtin_amdgcn_readfirstlane(lds_addr(smem));
+    // DMA addressing: SGPR base = head base + tile offset (scalar ALU), VGPR = 32-bit
+    // per-lane byte offset of this wave's piece inside a tile (invariant over tiles).
+    unsigned k_off[DMA_PER_WAVE], v_off[DMA_PER_WAVE];
+#pragma unroll
+    for (int j = 0; j < DMA_PER_WAVE; ++j) {
+        const int i = wave + NWAVES * j;  // piece index, wave-uniform; keys 4i .. 4i+3
+        k_off[j] = (unsigned)(((int64_t)(RPP * i) * ss + k_lane_off) * 2);
+        const int sub = 2 * i + v_sub_in_piece;  // subtiles 2i, 2i+1
+        v_off[j] = (unsigned)(((8 * (sub / DSUB) + v_lane_row) * ss + (sub % DSUB) * 32 + v_lane_d) * 2);
+    }
+    const int64_t tile_stride = (int64_t)BC * ss;  // elements between consecutive KV blocks
+    auto dma_wait = [&]() { if (DMA && !(ABL & 8)) dma_wait_all(); };
+    auto barrier = [&]() { if (!(ABL & 8)) wg_barrier(); };
+    // ---- first requests of the walk: K(0), then Q (all S(0) needs); the rest follows in the prologue
+    if (!(ABL & 16)) {
+#pragma unroll
+        for (int j = 0; j < DMA_PER_WAVE; ++j)
+            glds16_sv(Kg + (int64_t)(n_kv - 1) * tile_stride, k_off[j], smem_base + (wave + NWAVES * j) * 1024);
+    }
+
+    vec8 Qr[QT][KS];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        const int64_t row = (int64_t)qb * TR::kBr + wave * TR::kRowsPerWave + qt * 32 + r31;
+        const uint16_t *qp = Qg + row * ss + hi * 8;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)  // straight into the accumulator file; waited for by hand below
+            asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=a"(Qr[qt][ks]) : "v"(qp), "i"(ks * 32) : "memory");
+    }
+
+    // forward_kernel.cuh:150-151 (fp32 product of rsqrt(d) and log2 e)
+    const float c = (float)((double)(1.0f / __builtin_sqrtf((float)D)) * 1.4426950408889634074);
+
+    f32x16 O[QT][DTILES];
+    float m[QT], l[QT];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        m[qt] = -__builtin_inff();
+        l[qt] = 0.0f;
+#pragma unroll
+        for (int t = 0; t < DTILES; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) O[qt][t][r] = 0.0f;
+    }
+
+    // per-lane LDS read offsets
+    //   K A-operand: row 32*nt + r31, chunk (2*ks + hi) ^ (r31 & 15)
+    const int ka_swz = SWZ ? swz_of(r31) : 0;
+    const int ka_base = r31 * ROWB;
+    //   V^T A-operand (transpose read): see header comment
+    const int li = lane & 15, lg = lane >> 4;
+    const int va_base = (4 * (lg >> 1) + (li >> 2)) * 64 + (lg & 1) * 32 + (li & 3) * 8;
+
+    // a row whose keys were all masked so far has m = -inf: exponentiate against 0 instead
+    auto finite_or_zero = [&](float mval) { return (MASK && mval == -__builtin_inff()) ? 0.0f : mval; };
+
+    {
+        // ---- 64 rows per wave, one wave per SIMD, hand-placed registers and order ----------
+        // Each K / V operand read from LDS feeds TWO MFMAs (the wave's two 32-row Q tiles), which
+        // halves LDS traffic, DMA issue and barriers per MFMA.  512 registers per lane, by file:
+        //   AGPR  O (128) | Q (64)
+        //   VGPR  two S tiles (128) | P (32) | operand ring (16) | softmax temporaries
+        // All MFMAs are inline asm so that O and Q never leave the accumulator file; hipcc does
+        // not schedule or hazard-pad them, so the stream is pinned gap by gap (one MFMA + its
+        // fillers, then sched_barrier(0)) and the wait states are kept by distance:
+        //   * S(it+1) is accumulated in phase 1 and first read (row max) >= 2 MFMAs later;
+        //   * a packed P operand is consumed >= 2 gaps after its v_cvt_pk;
+        //   * O is read by VALU only in the rare rescale and in the epilogue, behind s_nop pads.
+        // One wave per SIMD hides about five single-issue instructions per 32-cycle MFMA
+        // (MI355X_MICROARCH.md, per-instruction constants), so the softmax of tile `it` is cut
+        // into 32 two-element units {2 fma, 2 exp2, 2 add, 1 pack} and dealt over the gaps by
+        // a compile-time plan (Plan64):
+        //   phase 1 (32 MFMAs, S(it+1) = K(it+1) Q^T): K operand reads, most of the units
+        //   phase 2 (32 MFMAs, O += V(it) P(it)):      V operand reads, the other units, the row max
+        //            of S(it+1), the 8 DMA pieces of the tiles three visits ahead, the m / rescale test
+        // K and V each ring through 4 LDS stages (128 KB; the 512-register waves allow one
+        // workgroup per CU anyway).  A tile is requested three visits before it is read and must have
+        // landed two visits after the request: the wait in front of the per-visit barrier is
+        // COUNTED (vmcnt(8): the youngest visit's pieces stay in flight), so an HBM-latency fetch
+        // does not stall the matrix pipe, and the barrier publishes a tile one visit early, which
+        // lets the last gaps of a visit prefetch the next visit's first operands.
+        //
+        // Rescaling is lazy: O and l stay relative to a reference max m that is only moved (and
+        // O, l multiplied by 2^((m_old - m_new) c)) when some row's max rose by more than
+        // TAU / c logit units, so P <= 2^TAU.  The result is the same real number as the
+        // reference's eager rescale (softmax.cuh:36-49); only the rounding point of P differs,
+        // with the same relative error.  With O in the accumulator file a rescale costs ~200
+        // issue slots per Q tile, and for random data some row of 32 finds a new max in most tiles.
+        static_assert(DMA && D == 128 && BC == 64 && NT == 2 && NWAVES == 4, "64-row pinned schedule");
+        static_assert(TR::kStages == 4, "ring depth");
+        constexpr float TAU = 8.0f;
+        constexpr Plan64 plan = make_plan64(((ABL >> 8) & 3) | (MASK ? 4 : 0), (ABL & 1024) ? 20 : 22);
+        static_assert(plan64_ok(plan), "filler plan violates a wait-state distance");
+        f32x16 Sa[2][NT], Sb[2][NT];
+        u32x4 Pw[2][4] = {};     // P[qt][16-key slice]: B operand of O^T += V^T P^T
+        float neg_msc[2];        // -(m c)
+        float m_pend[2];         // candidate reference max found during the previous visit
+        unsigned resc_any = 0;   // bit qt: Q tile qt moves its reference max at the next visit's top
+        auto k_frag = [&](const char *kt, int step) -> vec8 {  // step = 2*ks + nt
+            const int ks = step >> 1, nt = step & 1;
+            return *(const vec8 *)(kt + nt * 32 * ROWB + ka_base + (((2 * ks + hi) ^ ka_swz) << 4));
+        };
+        auto v_frag = [&](const char *vt, int step) -> vec8 {  // step = 4*s16 + t
+            const int s16 = step >> 2, t = step & 3;
+            const char *vp = vt + va_base + s16 * (DSUB * 1024) + t * 512;
+            s16x8 av;
+            av.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((FA_LDS(s16x4) *)(vp));
+            av.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((FA_LDS(s16x4) *)(vp + DSUB * 512));
+            return __builtin_bit_cast(vec8, av);
+        };
+        auto qk_mfma = [&](auto &S, int step, int qt, vec8 a) {
+            const int ks = step >> 1, nt = step & 1;
+            if (ks == 0) E::mfma_acc_v_q0(S[qt][nt], a, Qr[qt][ks]);
+            else E::mfma_acc_v_q(S[qt][nt], a, Qr[qt][ks]);
+        };
+        // ---- persistent walk over items; the K / V tile stream runs on across item seams --------
+        // This workgroup serves items blockIdx.x, + gridDim.x, ...  Tiles are numbered along the
+        // walk: visit index j of the current item for j < n_kv, visit index j - n_kv of the NEXT item
+        // beyond (n_kv % 4 == 0, so a tile's ring stage is j & 3 either way).  The last visits of an
+        // item therefore request the next item's first tiles, its last visit forms the next item's
+        // S(0) with the next item's Q (loaded straight into the Q AGPRs one visit earlier), and a
+        // seam costs the O epilogue only.  After the last item the "next" item is the item itself:
+        // the re-fetched tiles land in stages nobody reads.
+        const int n_items = args.n_bh * nq;
+        int item = blockIdx.x;
+        const uint16_t *Kc = Kg, *Vc = Vg;   // current item
+        uint16_t *Oc = Og;
+        int qb_c = qb;
+        const uint16_t *Kn = Kg, *Vn = Vg, *Qn = Qg;  // next item (set per item below)
+        uint16_t *On = Og;
+        int qb_n = qb;
+        bool has_next = false;
+        // causal (MASK variants): an item visits the tiles up to its diagonal only, 4 (qb + 1) of them
+        // -- still a multiple of the ring depth, so the stage arithmetic along the walk holds
+        const bool causal = MASK && args.causal;
+        int nkc = n_kv, nkn = n_kv;  // tiles of the current / next item
+        auto tile_g = [&](const uint16_t *cur, const uint16_t *nxt, int j) {
+            return j < nkc ? cur + (int64_t)(nkc - 1 - j) * tile_stride
+                           : nxt + (int64_t)(nkn - 1 - (j - nkc)) * tile_stride;
+        };
+        // MASK: logits above the causal diagonal become -inf.  `tile` counts from the start of the
+        // sequence, `qb_rows` is the Q block whose rows the S tile belongs to.  A wave's 64 rows meet
+        // the diagonal in exactly one 64-key tile; tiles beyond it are masked whole.
+        auto mask_tile = [&](auto &S, int tile, int qb_rows) {
+            if constexpr (MASK) {
+                const int d = tile - (4 * qb_rows + wave);
+                if (causal && d >= 0) {  // wave-uniform
+#pragma unroll
+                    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                const int key = 32 * nt + (r & 3) + 8 * (r >> 2) + 4 * hi, row = 32 * qt + r31;
+                                S[qt][nt][r] = (d > 0 || key > row) ? -__builtin_inff() : S[qt][nt][r];
+                            }
+                }
+            }
+        };
+        auto dma_k = [&](const uint16_t *src, int stage) {
+#pragma unroll
+            for (int j = 0; j < DMA_PER_WAVE; ++j)
+                glds16_sv_m0(MASK ? src + j * (16 * ss) : src, k_off[MASK ? 0 : j],
+                             smem_base + stage * TILE + (wave + NWAVES * j) * 1024);
+        };
+        auto dma_v = [&](const uint16_t *src, int stage) {
+#pragma unroll
+            for (int j = 0; j < DMA_PER_WAVE; ++j)
+                glds16_sv_m0(MASK ? src + j * (16 * ss) : src, v_off[MASK ? 0 : j],
+                             smem_base + V_BASE + stage * TILE + (wave + NWAVES * j) * 1024);
+        };
+        const uint16_t *kq = nullptr, *vq = nullptr;  // next K / V tile to request (set per item below)
+        vec8 ring[4];  // operand ring: slot u % 4, rewritten two steps after the MFMAs that read it
+        vec8 Qr2[2][KS];  // the next item's Q (AGPRs), requested during the item's first visit
+        float mraw[2];   // row max of the S tile formed by the last visit (the next item's S(0))
+        bool seam = false;  // the first two visits after a seam: the epilogue's stores are in flight
+        // next item's Q rows -> the Q AGPRs.  Plain asm loads: hipcc does not count them; the wait
+        // is the vmcnt(0) at the top of the item's last visit.
+        auto load_q_next = [&](auto piece_tag, vec8 &dst) {  // piece = 8*qt + ks, dst = Qr[qt][ks]
+            constexpr int piece = decltype(piece_tag)::value, qt = piece >> 3, ks = piece & 7;
+            const int64_t row = (int64_t)qb_n * TR::kBr + wave * TR::kRowsPerWave + qt * 32 + r31;
+            const uint16_t *qp = Qn + row * ss + hi * 8;
+            asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=a"(dst) : "v"(qp), "i"(ks * 32) : "memory");
+        };
+        auto visit = [&](int it, auto &S_cur, auto &S_nxt, auto r_tag) {
+            constexpr int R = decltype(r_tag)::value;  // it & 3
+#ifdef FA_TRACE
+            unsigned long long ts[20];
+            asm volatile("s_memtime %0" : "=s"(ts[0]));
+#endif
+            // the visit's synchronisation point: K(it+2), V(it+1) landed (requested two visits ago;
+            // K(it+1), V(it) were published by the previous barrier), the 8 youngest pieces may fly
+            // on; behind it every wave has finished visit it-1, whose K / V stages the DMA of this
+            // visit overwrites.  In the default plan it sits two MFMAs into the visit, after the
+            // gap-0 lgkmcnt(0) that retires this wave's last LDS reads of visit it-1.
+            auto sync_point = [&]() {
+                if (ABL & 8) return;
+                // what may still be in flight behind the pieces this barrier publishes: this visit's
+                // predecessor's 8 pieces, plus -- early in an item -- the 16 stores of the previous
+                // item's epilogue and the 16 loads of the next item's Q
+                int allow = 8;
+                if constexpr (R == 0) allow = (it == 0 && seam) ? 24 : 8;
+                if constexpr (R == 1) allow = (it == 1) ? 8 + (seam ? 16 : 0) + (has_next ? 16 : 0) : 8;
+                if constexpr (R == 2) allow = (it == 2 && has_next) ? 24 : 8;
+                if (allow == 8) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+                else if (allow == 24) asm volatile("s_waitcnt vmcnt(24)\n\ts_barrier" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(40)\n\ts_barrier" ::: "memory");
+            };
+            if constexpr (R == 3) {
+                // last visit of an item forms the next item's S(0): swap the next item's Q in
+                if (it + 1 == nkc && has_next) {
+                    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");  // the Q loads (visit 0) are older than 16 pieces
+#pragma unroll
+                    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+                        for (int ks = 0; ks < KS; ++ks) {
+                            asm volatile("" : "+a"(Qr2[qt][ks]));  // value defined by the asm loads
+                            Qr[qt][ks] = Qr2[qt][ks];
+                        }
+                    asm volatile("s_nop 3" ::: "memory");  // accvgpr write -> MFMA operand
+                }
+            }
+            if constexpr (plan.barrier[2] == 0) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                sync_point();
+            }
+            const unsigned kdst = smem_base + R * TILE + wave * 1024;                        // K(it+4) -> stage of K(it)
+            const unsigned vdst = smem_base + V_BASE + ((R + 3) & 3) * TILE + wave * 1024;   // V(it+3) -> stage of V(it-1)
+            if (resc_any) {  // wave-uniform, rare: move the reference max of one or both Q tiles
+                asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");  // MFMA D (O) -> VALU read
+#pragma unroll
+                for (int qt = 0; qt < 2; ++qt) {
+                    if (!(resc_any & (1u << qt))) continue;
+                    const float alpha = __builtin_amdgcn_exp2f((m[qt] - m_pend[qt]) * c);
+                    m[qt] = m_pend[qt];
+                    neg_msc[qt] = -(finite_or_zero(m[qt]) * c);
+                    l[qt] *= alpha;
+#pragma unroll
+                    for (int t = 0; t < DTILES; ++t)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) O[qt][t][r] *= alpha;
+                }
+            }
+            const char *kt = smem + ((R + 1) & 3) * TILE;
+            const char *vt = smem + V_BASE + R * TILE;
+            float rs[2][2] = {{0.0f, 0.0f}, {0.0f, 0.0f}};
+            float vm[2][2], m_new[2];
+            unsigned any01 = 0;
+            auto exp_unit = [&](int u) {  // u = 8*s16 + 2*j + qt: in the order P.V consumes P
+                if constexpr (ABL & 2) return;
+                const int qt = u & 1, j = (u >> 1) & 3, s16 = u >> 3, r = 8 * (s16 & 1) + 2 * j;
+                // exp2(s c - m c), softmax.cuh:51-64.  Scalar f32 forms on purpose: v_pk_fma_f32 /
+                // v_pk_add_f32 here measured -6 % / -12 %; splitting the unit into stages over three
+                // gaps (no dependent pair inside a gap) measured -1.5 %.
+                float p0 = __builtin_fmaf(S_cur[qt][s16 >> 1][r], c, neg_msc[qt]);
+                float p1 = __builtin_fmaf(S_cur[qt][s16 >> 1][r + 1], c, neg_msc[qt]);
+                if (!(ABL & 1)) {
+                    p0 = __builtin_amdgcn_exp2f(p0);
+                    p1 = __builtin_amdgcn_exp2f(p1);
+                }
+                rs[qt][0] += p0;  // fp32 P, before rounding (softmax.cuh:66-83)
+                rs[qt][1] += p1;
+                // pin the adds to this gap: hipcc otherwise sinks the whole row-sum chain (and keeps
+                // every p alive) to the first use of l, behind the next visit's barrier
+                asm volatile("" : "+v"(rs[qt][0]), "+v"(rs[qt][1]));
+                unsigned pk = E::pack2(p0, p1);
+                // ... and the pack: sunk below a branch of the stream it would sit right in front of the
+                // MFMA that reads it, which hipcc does not pad (the MFMAs are opaque asm)
+                asm volatile("" : "+v"(pk));
+                Pw[qt][s16][j] = pk;
+            };
+            auto max_unit = [&](int u) {  // u = 0..31: tile (nt = u>>4, qt = (u>>3)&1), elements 2(u&7), +1
+                const int nt = u >> 4, qt = (u >> 3) & 1, e = 2 * (u & 7), a = u & 1;  // two chains per Q tile
+                if constexpr (ABL & 2) { vm[qt][a] = 0.0f; return; }
+                // asm forms: fmaxf() on MFMA results makes hipcc canonicalise both inputs first
+                if ((u & 7) < 2 && nt == 0) vm[qt][a] = vmax2(S_nxt[qt][nt][e], S_nxt[qt][nt][e + 1]);
+                else vm[qt][a] = vmax3(vm[qt][a], S_nxt[qt][nt][e], S_nxt[qt][nt][e + 1]);
+                asm volatile("" : "+v"(vm[qt][a]));  // pinned to its gap (S_nxt is rewritten next visit)
+            };
+            auto lane_pair_max = [&](float x) {
+                auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+                return vmax2(__uint_as_float(r[0]), __uint_as_float(r[1]));
+            };
+            auto tail_unit = [&](int k) {  // end-of-visit chain, one step per gap (pinned by volatile asm)
+                if (k == 1) {
+                    vm[0][0] = vmax2(vm[0][0], vm[0][1]);
+                    vm[1][0] = vmax2(vm[1][0], vm[1][1]);
+                    asm volatile("" : "+v"(vm[0][0]), "+v"(vm[1][0]));
+                }
+                if (k == 2) { vm[0][0] = lane_pair_max(vm[0][0]); asm volatile("" : "+v"(vm[0][0])); }
+                if (k == 3) { vm[1][0] = lane_pair_max(vm[1][0]); asm volatile("" : "+v"(vm[1][0])); }
+                if (k == 4) {  // candidate reference max
+                    mraw[0] = vm[0][0];
+                    mraw[1] = vm[1][0];
+                    m_new[0] = vmax2(m[0], vm[0][0]);
+                    m_new[1] = vmax2(m[1], vm[1][0]);
+                    asm volatile("" : "+v"(m_new[0]), "+v"(m_new[1]));
+                }
+                if (k == 5) {
+                    l[0] += rs[0][0] + rs[0][1];
+                    l[1] += rs[1][0] + rs[1][1];
+                    asm volatile("" : "+v"(l[0]), "+v"(l[1]));
+                }
+                if (k == 6 || k == 7) {  // did some row's max rise by more than TAU / c?
+                    const int qt = k - 6;
+                    m_pend[qt] = m_new[qt];
+                    float rise = (m_new[qt] - m[qt]) * c;
+                    asm volatile("" : "+v"(rise));  // (an "s" pin would make hipcc treat the flag as divergent)
+                    any01 |= (__ballot(rise > TAU) != 0 ? 1u : 0u) << qt;
+                }
+                if (k == 8) {  // next tiles to request (scalar ALU)
+                    resc_any = any01;
+                    // visit it+1 requests K(it+5), V(it+4); the stream wraps into the next item
+                    kq = (it + 5 == nkc) ? Kn + (int64_t)(nkn - 1) * tile_stride : kq - tile_stride;
+                    vq = (it + 4 == nkc) ? Vn + (int64_t)(nkn - 1) * tile_stride : vq - tile_stride;
+                    if constexpr (R == 1) seam = false;
+
+                }
+            };
+            auto tail_step = [&](int k) {  // plan step: 1..8 one unit each; 10..14 the masked plan's merged steps
+                if (k < 10) tail_unit(k);
+                if (k == 10) tail_unit(1);
+                if (k == 11) { tail_unit(2); tail_unit(3); }
+                if (k == 12) { tail_unit(4); tail_unit(5); }
+                if (k == 13) { tail_unit(6); tail_unit(7); }
+                if (k == 14) tail_unit(8);
+            };
+            // operand u of the visit: 16 K fragments, 16 V fragments, then the first two K fragments
+            // of the NEXT visit (its tile was published by this visit's barrier), so that no LDS
+            // latency is exposed at the visit seam
+            const char *kt_next = smem + ((R + 2) & 3) * TILE;
+            auto operand = [&](int u) -> vec8 {
+                if constexpr (ABL & 4) return __builtin_bit_cast(vec8, Pw[u & 1][(u >> 1) & 3]);
+                return u < 16 ? k_frag(kt, u) : (u < 32 ? v_frag(vt, u - 16) : k_frag(kt_next, u - 32));
+            };
+            static_for<0, 64>([&](auto gap_tag) {
+                constexpr int g = decltype(gap_tag)::value;
+                constexpr int step = g >> 1, qt = g & 1;
+                // An MFMA reads its A / B registers for a few cycles after it issues, and hipcc -- to
+                // which the MFMAs are opaque asm -- is free to hand a register that just died to the very
+                // next VALU instruction (seen: the pair-max temporary landing in the A operand of the
+                // MFMA in front of it; one-ulp run-to-run differences that an s_nop 7 behind every MFMA
+                // removed).  So every operand is kept alive until the NEXT MFMA has issued: an empty asm
+                // that names it, placed behind that MFMA (volatile asm statements keep their order).
+                vec8 prev_a = ring[(step + 3) % 4];  // A operand of the previous step (its slot is reloaded below)
+                if constexpr (qt == 0 && (step & 1) == 0) {  // operands in pairs: one counted wait per two steps
+                    __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0): operands step, step+1 landed
+#ifdef FA_TRACE
+                    asm volatile("s_memtime %0" : "=s"(ts[2 + step / 2]));
+#endif
+                    ring[(step + 2) % 4] = operand(step + 2);
+                    ring[(step + 3) % 4] = operand(step + 3);
+                }
+                if constexpr (g < 32) {
+                    qk_mfma(S_nxt, step, qt, ring[step % 4]);
+                } else {
+                    constexpr int s2 = step - 16, s16 = s2 >> 2, t = s2 & 3;
+                    E::mfma_acc_a_p(O[qt][t], ring[step % 4], Pw[qt][s16]);
+                }
+                if constexpr (qt == 0) asm volatile("" ::"v"(prev_a));
+                if constexpr (g >= 33) {
+                    constexpr int pg = g - 1, ps2 = (pg >> 1) - 16;
+                    asm volatile("" ::"v"(Pw[pg & 1][ps2 >> 2]));  // B operand of the previous P.V MFMA
+                }
+                if constexpr (g == 0) asm volatile("" ::"v"(Pw[1][3]));  // ... of the previous visit's last one
+                if constexpr (plan.barrier[g] != 0) sync_point();
+                if constexpr (MASK && g == 34) {
+                    // S(it+1) is complete (last written at gap 31): causal mask, before its row max.
+                    // The last visit's S tile is the NEXT item's S(0).
+                    if (it + 1 < nkc) mask_tile(S_nxt, nkc - 2 - it, qb_c);
+                    else mask_tile(S_nxt, nkn - 1, qb_n);
+                }
+                if constexpr (R == 0 && g == 33) {
+                    // first visit of an item: request the NEXT item's Q rows into the spare Q set
+                    // (64 of the AGPRs are otherwise unused); they are swapped in at the top of
+                    // this item's last visit, several visits after they have landed
+                    if (it == 0 && has_next) {
+                        static_for<0, 16>([&](auto i) {
+                            constexpr int pc = decltype(i)::value;
+                            load_q_next(IntTag<pc>{}, Qr2[pc >> 3][pc & 7]);
+                        });
+                    }
+                }
+                if constexpr (plan.dma[g] >= 0 && !(ABL & 16)) {  // one 1-KiB DMA piece
+                    constexpr int j = plan.dma[g] >> 1;
+                    // per-piece lane offsets: 6 more VGPRs than one offset + a scalar piece stride (piece j
+                    // of a wave starts 16 rows below piece j-1), but 16 fewer SALU instructions per
+                    // visit (+0.5 %).  The masked variant has no VGPRs to spare and takes the stride.
+                    if constexpr (MASK) {
+                        const int64_t piece_stride = 16 * ss;
+                        if constexpr ((plan.dma[g] & 1) == 0) glds16_sv_m0(kq + j * piece_stride, k_off[0], kdst + NWAVES * j * 1024);
+                        else glds16_sv_m0(vq + j * piece_stride, v_off[0], vdst + NWAVES * j * 1024);
+                    } else {
+                        if constexpr ((plan.dma[g] & 1) == 0) glds16_sv_m0(kq, k_off[j], kdst + NWAVES * j * 1024);
+                        else glds16_sv_m0(vq, v_off[j], vdst + NWAVES * j * 1024);
+                    }
+                }
+                static_for<0, plan.exp_n[g]>([&](auto i) { exp_unit(plan.exp_first[g] + decltype(i)::value); });
+                static_for<0, plan.max_n[g]>([&](auto i) { max_unit(plan.max_first[g] + decltype(i)::value); });
+                if constexpr (plan.tail[g] > 0) tail_step(plan.tail[g]);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+#ifdef FA_TRACE
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts[18])::"memory");
+            if (item == args.trace_block && it == args.trace_visit && lane == 0) {
+#pragma unroll
+                for (int i = 0; i < 19; ++i) args.trace[wave * 24 + i] = ts[i];
+            }
+#endif
+        };
+        // ---- first item: prologue -------------------------------------------------------------
+        // causal: an item costs ~(qb + 1), and along the walk a workgroup would meet the same Q-block
+        // position of a head again and again (round r: slot w + G r of the XCD's item list).  So
+        // odd rounds run their G-slot window of a head (or their whole heads, if a head is shorter than
+        // the window) in reverse: still every Q block of every head exactly once, and two consecutive
+        // rounds sum to the same work for every workgroup.  Needs windows and rounds to line up
+        // (Q blocks per head and workgroups per XCD both powers of two, as a rule); otherwise the walk
+        // stays in order -- correct, just less balanced.
+        auto walk_qb = [&](int it_, int pos) {
+            const int G = (args.n_bh & 7) == 0 ? (int)gridDim.x >> 3 : (int)gridDim.x;
+            const int W = nq < G ? nq : G;
+            if (W <= 0 || G % W != 0 || nq % W != 0) return pos;
+            const int in_w = pos % W;
+            return (pos / W) * W + (((it_ / (int)gridDim.x) & 1) ? W - 1 - in_w : in_w);
+        };
+        auto set_next = [&]() {  // coordinates of the item after `item` (or `item` again)
+            const int nitem = item + (int)gridDim.x;
+            has_next = nitem < n_items;
+            int bh_n;
+            item_coords(has_next ? nitem : item, bh_n, qb_n);
+            if (causal) {
+                qb_n = walk_qb(has_next ? nitem : item, qb_n);
+                nkn = 4 * (qb_n + 1);
+            }
+            const int b_n = bh_n / args.n_heads, h_n = bh_n % args.n_heads;
+            const int64_t off_n = (int64_t)b_n * args.batch_stride + (int64_t)h_n * args.head_stride;
+            Qn = (const uint16_t *)args.q + off_n;
+            Kn = (const uint16_t *)args.k + off_n;
+            Vn = (const uint16_t *)args.v + off_n;
+            On = (uint16_t *)args.o + off_n;
+        };
+        set_next();
+        // Every CU starts at once and the first requests (176 KB per workgroup) return at ~11 B/cycle
+        // per CU, in issue order: K(0) and Q -- all S(0) needs -- were asked for first (common code);
+        // then K(1), V(0) | K(2), V(1) | K(3), V(2) in the order the counted waits assume.
+        dma_k(tile_g(Kc, Kn, 1), 1);
+        dma_v(tile_g(Vc, Vn, 0), 0);
+        dma_k(tile_g(Kc, Kn, 2), 2);
+        dma_v(tile_g(Vc, Vn, 1), 1);
+        dma_k(tile_g(Kc, Kn, 3), 3);
+        dma_v(tile_g(Vc, Vn, 2), 2);
+        kq = tile_g(Kc, Kn, 4);
+        vq = tile_g(Vc, Vn, 3);
+        if (!(ABL & 8)) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");  // K(0), Q landed
+        barrier();
+        {
+            // S(0) and its row max, which becomes the first reference max (O = l = 0)
+            const char *kt = smem;
+            vec8 a_all[16];  // every operand stays allocated until the last MFMA has issued (see visit())
+#pragma unroll
+            for (int step = 0; step < 16; ++step) a_all[step] = k_frag(kt, step);
+            static_for<0, 16>([&](auto step_tag) {
+                constexpr int step = decltype(step_tag)::value;
+                qk_mfma(Sa, step, 0, a_all[step]);
+                qk_mfma(Sa, step, 1, a_all[step]);
+            });
+            asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // MFMA D -> VALU read
+#pragma unroll
+            for (int step = 0; step < 16; ++step) asm volatile("" ::"v"(a_all[step]));
+            mask_tile(Sa, nkc - 1, qb_c);
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+                float v = Sa[qt][0][0];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) v = fmaxf(v, Sa[qt][nt][r]);
+                m[qt] = pair_max(v);
+                neg_msc[qt] = -(finite_or_zero(m[qt]) * c);
+                m_pend[qt] = m[qt];
+            }
+            if (!(ABL & 8)) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");  // K(1) landed (under S(0))
+            barrier();
+            ring[0] = k_frag(smem + TILE, 0);  // first operands of visit 0: K(1)
+            ring[1] = k_frag(smem + TILE, 1);
+        }
+        // O of one item: finish l, normalise, RNE to 16 bit (final_softmax_normalization
+        // softmax.cuh:107-128; forward_kernel.cuh:186-203), through this wave's 8-KB LDS staging
+        // area one 32-row Q tile at a time so that the global stores are whole 256-B rows (16 B per
+        // lane, 4 rows per wave-instruction).  Wave-private: no barrier.  The 16-B chunk index is
+        // XORed with (row & 15) so the 8-B writes and the 16-B reads are bank-conflict free.
+        auto store_item = [&]() {
+            asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // last P.V -> VALU reads of O
+            char *stage_o = smem + 2 * TR::kStages * TILE + wave * (32 * ROWB);
+            // lane-derived indices recomputed here from a volatile v_mbcnt: values derived from
+            // threadIdx at kernel entry would stay live (and get spilled) across the whole item loop
+            int lane;
+            asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
+            const int r31 = lane & 31, hi = lane >> 5;
+            const int rsub = lane / CPR, chunk = lane & (CPR - 1);
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+                const float inv = 1.0f / pair_sum(l[qt]);
+                char *wp = stage_o + r31 * ROWB + hi * 8;
+#pragma unroll
+                for (int t = 0; t < DTILES; ++t) {
+                    float o[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[r] = O[qt][t][r] * inv;
+                    // regs 4rq..4rq+3 : d = 32t + 8rq + 4hi + 0..3  -> chunk 4t + rq, half hi
+                    const s16x8 lo_s = __builtin_bit_cast(s16x8, E::pack8(o));
+                    const s16x8 up_s = __builtin_bit_cast(s16x8, E::pack8(o + 8));
+                    *(s16x4 *)(wp + (((4 * t + 0) ^ swz_of(r31)) << 4)) = lo_s.lo;
+                    *(s16x4 *)(wp + (((4 * t + 1) ^ swz_of(r31)) << 4)) = lo_s.hi;
+                    *(s16x4 *)(wp + (((4 * t + 2) ^ swz_of(r31)) << 4)) = up_s.lo;
+                    *(s16x4 *)(wp + (((4 * t + 3) ^ swz_of(r31)) << 4)) = up_s.hi;
+                    __builtin_amdgcn_sched_barrier(0);  // one d tile at a time: S(0) of the next item is live
+                }
+                const int64_t row0 = (int64_t)qb_c * TR::kBr + wave * TR::kRowsPerWave + qt * 32;
+#pragma unroll
+                for (int i = 0; i < 32 / RPP; ++i) {
+                    const int row = RPP * i + rsub;
+                    const s16x8 v = *(const s16x8 *)(stage_o + row * ROWB + ((chunk ^ swz_of(row)) << 4));
+                    // non-temporal: O is written once and not read again by this kernel (+1.3...2.8 % at
+                    // seq_len <= 1024, where the store-issue-bound epilogue is a visible share)
+                    __builtin_nontemporal_store(v, (s16x8 *)(Oc + (row0 + row) * ss + chunk * 8));
+                }
+            }
+        };
+        // seq_len is a multiple of B_r = 256, so n_kv = seq_len / 64 is a multiple of 4 = ring depth
+        for (;;) {
+            for (int it = 0; it < nkc; it += 4) {
+                visit(it, Sa, Sb, IntTag<0>{});
+                visit(it + 1, Sb, Sa, IntTag<1>{});
+                visit(it + 2, Sa, Sb, IntTag<2>{});
+                visit(it + 3, Sb, Sa, IntTag<3>{});
+            }
+#ifdef FA_TRACE
+            unsigned long long te0, te1, te2;
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(te0)::"memory");
+#endif
+            store_item();
+#ifdef FA_TRACE
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(te1)::"memory");
+#endif
+            if (!has_next) break;
+            // ---- seam: the last visit left the next item's S(0) in Sa and its row max in mraw; its
+            // first tiles are landed or in flight, its first operands sit in the ring
+            item += (int)gridDim.x;
+            Kc = Kn; Vc = Vn; Oc = On; qb_c = qb_n;
+            nkc = nkn;
+            set_next();
+            kq = tile_g(Kc, Kn, 4);  // visit 0 requests K(4), V(3) (for n_kv == 4 that is already the item after)
+            vq = tile_g(Vc, Vn, 3);
+            seam = true;
+            resc_any = 0;
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+                m[qt] = mraw[qt];
+                neg_msc[qt] = -(finite_or_zero(m[qt]) * c);
+                m_pend[qt] = m[qt];
+                l[qt] = 0.0f;
+#pragma unroll
+                for (int t = 0; t < DTILES; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) O[qt][t][r] = 0.0f;
+            }
+#ifdef FA_TRACE
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(te2)::"memory");
+            if (item - (int)gridDim.x == args.trace_block && lane == 0) {
+                args.trace[wave * 24 + 21] = te0;
+                args.trace[wave * 24 + 22] = te1;
+                args.trace[wave * 24 + 23] = te2;
+            }
+#endif
+        }
+        dma_wait();  // nothing may still be landing in the LDS when the workgroup retires
+        return;
+    }
+}
+
+}  // namespace fa

@@ -6,6 +6,7 @@
 #pragma once
 #include <stdint.h>
 #include "fa_fwd_kernel.hpp"
+#include "fa_fwd_kernel64.hpp"
 
 namespace fa {
 
@@ -33,9 +34,15 @@ template <int DT, int QT, int NWAVES, int BC, bool SWZ, bool EAGER, bool OPT, bo
           bool MASK = false, int D = 128>
 constexpr KernelEntry make_entry() {
     using TR = FwdTraits<DT, QT, NWAVES, BC, SWZ, EAGER, OPT, PIPE, DMA, MASK, D>;
-    return KernelEntry{DT, 32 * QT, NWAVES, BC, SWZ, EAGER, OPT, PIPE, DMA, MASK ? (TR::kPersistent ? 2 : 1) : 0, D, TR::kThreads,
-                       TR::kLdsBytes, TR::kPersistent,
-                       (kernel_fn)&fa_fwd_kernel<DT, QT, NWAVES, BC, SWZ, EAGER, OPT, PIPE, DMA, MASK, D>};
+    if constexpr (TR::kPersistent) {  // (B_r 256, B_c 64, 4 waves) + buffer: fa_fwd_kernel64.hpp
+        static_assert(NWAVES == 4 && BC == 64 && SWZ && EAGER && DMA && D == 128, "64-row pinned schedule");
+        return KernelEntry{DT, 64, 4, 64, 1, 1, OPT, 1, 1, MASK ? 2 : 0, 128, TR::kThreads, TR::kLdsBytes, 1,
+                           (kernel_fn)&fa_fwd_kernel64<DT, OPT, MASK>};
+    } else {
+        return KernelEntry{DT, 32 * QT, NWAVES, BC, SWZ, EAGER, OPT, PIPE, DMA, MASK ? 1 : 0, D, TR::kThreads,
+                           TR::kLdsBytes, 0,
+                           (kernel_fn)&fa_fwd_kernel<DT, QT, NWAVES, BC, SWZ, EAGER, OPT, PIPE, DMA, MASK, D>};
+    }
 }
 
 struct KernelTable {

@@ -43,11 +43,13 @@ PMC_GROUPS = [["GRBM_GUI_ACTIVE", "TCC_HIT_sum", "TCC_MISS_sum"]]
 def symbol_to_config(symbol):
     """'void fa::fa_fwd_kernel<15, 1, 8, 64, true, true, false, true, true, false, 128, 0>(fa::KernelArgs)' ->
     FlashForwardKernelConfig of that device variant (None for other kernels)."""
-    m = re.search(r"fa::fa_fwd_kernel(16)?<([^>]*)>", symbol)
+    m = re.search(r"fa::fa_fwd_kernel(16|64)?<([^>]*)>", symbol)
     if not m:
         return None
     vals = [{"true": 1, "false": 0}.get(t.strip(), t.strip()) for t in m.group(2).split(",")]
     vals = [int(v) for v in vals]
+    if m.group(1) == "64":  # fa_fwd_kernel64<DT, OPT, MASK, ABL>: the persistent (256, 64, 4) + buffer kernel
+        return FlashForwardKernelConfig(DType(vals[0]), 128, 256, 64, 4, True, True, True, 0, 0, 0, True, bool(vals[1]))
     if m.group(1):
         dt, nw, bc, swz, eager, opt = vals[:6]
         rows, pipe = 16, 0

@@ -2,7 +2,7 @@
 // with -DFA_TRACE; the shipped library carries no trace code).  Stamps: visit top, after the
 // barrier, then every 4 MFMA gaps (ideal: 4 x 32 = 128 cycles apiece), visit end.
 #define FA_TRACE 1
-#include "../csrc/fa_fwd_kernel.hpp"
+#include "../csrc/fa_fwd_kernel64.hpp"
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -30,7 +30,7 @@ int main(int argc, char **argv) {
     a.batch_stride = (int64_t)S * H * D; a.seq_stride = H * D; a.head_stride = D;
     a.seq_len = S; a.n_heads = H; a.n_bh = B * H; a.n_q_blocks = S / 256; a.n_kv_blocks = S / 64; a.causal = 0;
     a.trace = tr;
-    auto kern = fa::fa_fwd_kernel<15, 2, 4, 64, true, true, true, true, true, false, 128, 0>;
+    auto kern = fa::fa_fwd_kernel64<15, true, false, 0>;
     CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
     // persistent kernel: workgroup w serves items w, w + 256, ...; trace the second item of two workgroups
     const int items[2] = {256 + 100, 256 + 203};

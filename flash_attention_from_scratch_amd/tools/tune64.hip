@@ -1,7 +1,7 @@
 // tune64.hip -- A/B timing of experiment knobs (ABL bits >= 256) of the 64-rows-per-wave pinned
 // schedule on the headline shape, random data (the chip is power-limited: constant data
 // clocks ~20 % higher and hides everything).
-#include "../csrc/fa_fwd_kernel.hpp"
+#include "../csrc/fa_fwd_kernel64.hpp"
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -19,7 +19,7 @@ static std::vector<Variant> variants;
 static hipEvent_t e0, e1;
 
 template <int ABL> void launch(const fa::KernelArgs &a) {
-    auto kern = fa::fa_fwd_kernel<15, 2, 4, 64, true, true, true, true, true, false, 128, ABL>;
+    auto kern = fa::fa_fwd_kernel64<15, true, false, ABL>;
     static bool init = false;
     if (!init) { CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 163840)); init = true; }
     hipLaunchKernelGGL(kern, dim3(a.n_bh * a.n_q_blocks < 256 ? a.n_bh * a.n_q_blocks : 256), dim3(256), 163840, 0, a);
