@@ -353,8 +353,14 @@ fa_fwd_kernel64(const KernelArgs args) {
             auto sync_point = [&]() {
                 if (ABL & 8) return;
                 // what may still be in flight behind the pieces this barrier publishes: this visit's
-                // predecessor's 8 pieces, plus -- early in an item -- the 16 stores of the previous
-                // item's epilogue and the 16 loads of the next item's Q
+                // predecessor's 8 pieces, plus -- in the first three visits of an item -- the 16 stores of
+                // the previous item's epilogue and the 16 loads of the next item's Q.  One compare and
+                // one branch on the common path (the selection below costs ~20 scalar instructions in
+                // the one gap where the matrix pipe has nothing else to hide behind).
+                if (it >= 3) {
+                    asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+                    return;
+                }
                 int allow = 8;
                 if constexpr (R == 0) allow = (it == 0 && seam) ? 24 : 8;
                 if constexpr (R == 1) allow = (it == 1) ? 8 + (seam ? 16 : 0) + (has_next ? 16 : 0) : 8;
@@ -502,7 +508,7 @@ fa_fwd_kernel64(const KernelArgs args) {
                 vec8 prev_a = ring[(step + 3) % 4];  // A operand of the previous step (its slot is reloaded below)
                 if constexpr (qt == 0 && (step & 1) == 0) {  // operands in pairs: one counted wait per two steps
                     __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0): operands step, step+1 landed
-#ifdef FA_TRACE
+#if defined(FA_TRACE) && FA_TRACE == 1
                     asm volatile("s_memtime %0" : "=s"(ts[2 + step / 2]));
 #endif
                     ring[(step + 2) % 4] = operand(step + 2);
@@ -514,6 +520,9 @@ fa_fwd_kernel64(const KernelArgs args) {
                     constexpr int s2 = step - 16, s16 = s2 >> 2, t = s2 & 3;
                     E::mfma_acc_a_p(O[qt][t], ring[step % 4], Pw[qt][s16]);
                 }
+#if defined(FA_TRACE) && FA_TRACE == 2
+                if constexpr (g >= 48) asm volatile("s_memtime %0" : "=s"(ts[2 + g - 48]));  // fine trace of the visit's last 16 gaps
+#endif
                 if constexpr (qt == 0) asm volatile("" ::"v"(prev_a));
                 if constexpr (g >= 33) {
                     constexpr int pg = g - 1, ps2 = (pg >> 1) - 16;

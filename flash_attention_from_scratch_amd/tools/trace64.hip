@@ -1,7 +1,9 @@
 // trace64.hip -- s_memtime stamps inside ONE visit of the 64-rows-per-wave schedule (debug build
 // with -DFA_TRACE; the shipped library carries no trace code).  Stamps: visit top, after the
 // barrier, then every 4 MFMA gaps (ideal: 4 x 32 = 128 cycles apiece), visit end.
+#ifndef FA_TRACE
 #define FA_TRACE 1
+#endif
 #include "../csrc/fa_fwd_kernel64.hpp"
 #include <stdio.h>
 #include <stdlib.h>
@@ -46,9 +48,15 @@ int main(int argc, char **argv) {
         CHECK(hipMemcpy(t, tr, sizeof(t), hipMemcpyDeviceToHost));
         for (int w = 0; w < 4; ++w) {
             const unsigned long long *r = t + w * 24;
+#if FA_TRACE == 2
+            printf("item %4d visit %2d wave %d: total %5llu | gaps 48..63:", items[bi], visits[vi], w, r[18] - r[0]);
+            for (int i = 2; i < 17; ++i) printf(" %3llu", r[i + 1] - r[i]);
+            printf(" | 63->end %3llu", r[18] - r[17]);
+#else
             printf("item %4d visit %2d wave %d: total %5llu | top %4llu | groups", items[bi], visits[vi], w, r[18] - r[0], r[2] - r[0]);
             for (int i = 2; i < 17; ++i) printf(" %3llu", r[i + 1] - r[i]);
             printf(" | last %3llu", r[18] - r[17]);
+#endif
             if (vi == 5) printf(" | end-of-visit->epilogue %llu epilogue %llu reset %llu", r[21] - r[18], r[22] - r[21], r[23] - r[22]);
             printf("\n");
         }
