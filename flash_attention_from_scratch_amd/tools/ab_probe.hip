@@ -36,6 +36,16 @@ __device__ __forceinline__ void role_a(int iters, float *out, unsigned seed) {
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[u & 3]) : "v"(a[u & 1]), "v"(b[(u >> 1) & 1]));
+            if (NA == 6) {  // variant: row sum by v_dot2 on the packed pair (1 instruction instead of 2 adds)
+                float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[2 * u], 0.1275f, -1.0f));
+                float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[2 * u + 1], 0.1275f, -1.0f));
+                typedef __bf16 pair_t __attribute__((ext_vector_type(2)));
+                pair_t pr; pr[0] = (__bf16)p0; pr[1] = (__bf16)p1;
+                unsigned pu = __builtin_bit_cast(unsigned, pr);
+                asm volatile("v_dot2_f32_bf16 %0, %1, %2, %0" : "+v"(rs0) : "v"(pu), "v"(0x3f803f80u));
+                pk ^= pu;
+                asm volatile("" : "+v"(rs0), "+v"(pk));
+            }
             if (NA >= 7) {  // one softmax unit: 2 fma, 2 exp2, 2 add, 1 pack
                 float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[2 * u], 0.1275f, -1.0f));
                 float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[2 * u + 1], 0.1275f, -1.0f));
@@ -76,13 +86,14 @@ __device__ __forceinline__ void role_b(int iters, float *out, unsigned seed, cha
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
     const char *p = lds + (threadIdx.x & 63) * 16;
+    bf16x8 ring[2] = {a[0], a[1]};
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[u]) : "v"(a[u & 1]), "v"(b[(u >> 1) & 1]));
-            if (NB >= 1) {
-                bf16x8 t = *(const bf16x8 *)(p + u * 1024);   // the next operand (here: discarded into a)
-                asm volatile("" ::"v"(t));
+            if (NB >= 1) {  // operand read two steps ahead of its (pretended) use, as the kernel does
+                asm volatile("" ::"v"(ring[u & 1]));
+                ring[u & 1] = *(const bf16x8 *)(p + u * 1024);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -129,6 +140,7 @@ int main() {
     run<1, 0, 0>("B: bare MFMAs, one wave per SIMD");
     run<1, 0, 1>("B: MFMA + 1 ds_read_b128");
     run<0, 7, 0>("A: MFMA + softmax unit (7 VALU)");
+    run<0, 6, 0>("A: MFMA + softmax unit with v_dot2 row sum (6 VALU)");
     run<0, 9, 0>("A: MFMA + softmax unit + 2 max3 (9 VALU)");
     run<2, 7, 1>("A (7 VALU) + B (1 LDS read), two waves per SIMD");
     run<2, 9, 1>("A (9 VALU) + B (1 LDS read), two waves per SIMD");
