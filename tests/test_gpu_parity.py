@@ -390,6 +390,38 @@ def test_persistent_walk_random_shapes():
         assert _rel_ok(a, ref, dtype) or (a.float() - ref.float()).abs().max().item() <= 2 * TOL[dtype], (trial, B, H, S, causal)
 
 
+def test_c_abi_strided_views_and_long_sequence():
+    """Through the C ABI directly (the Python shim, like the reference, insists on contiguous
+    tensors): q, k, v, o as the first H heads of (B, S, 2H, 128) buffers -- seq_stride = 2H*128,
+    head_stride = 128 -- and one S = 32768 item walk (n_kv = 512 tiles per item), against the same
+    data laid out contiguously."""
+    import ctypes
+    lib = _capi.load()
+    for cfg in (kc.best_config(kc.DType.BF16, 4096),
+                kc.FlashForwardKernelConfig(kc.DType.BF16, 128, 256, 128, 8, True, True, True, 0, 0, 0, False, True)):
+        B, S, H = 3, 1024, 5
+        gen = torch.Generator(device=DEV).manual_seed(11)
+        big = [torch.randn((B, S, 2 * H, 128), dtype=torch.bfloat16, device=DEV, generator=gen) for _ in range(3)]
+        obig = torch.zeros((B, S, 2 * H, 128), dtype=torch.bfloat16, device=DEV)
+        q, k, v = (t[:, :, :H] for t in big)
+        o = obig[:, :, :H]
+        args = _capi.FaFwdArgs(q=q.data_ptr(), k=k.data_ptr(), v=v.data_ptr(), o=o.data_ptr(), batch=B, seq_len=S,
+                               n_heads=H, d_head=128, batch_stride=q.stride(0), seq_stride=q.stride(1),
+                               head_stride=q.stride(2), cfg=_capi.make_config(cfg))
+        _capi.check(lib.fa_fwd_launch(ctypes.byref(args), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        torch.cuda.synchronize()
+        ref = flash_attention.forward(cfg, q.contiguous(), k.contiguous(), v.contiguous())
+        assert torch.equal(o, ref), str(cfg)
+        assert torch.count_nonzero(obig[:, :, H:]) == 0   # the other heads of the buffer are untouched
+    cfg = kc.best_config(kc.DType.BF16, 32768)
+    other = kc.FlashForwardKernelConfig(kc.DType.BF16, 128, 128, 64, 4, True, True, True, 0, 0, 0, True, False)
+    gen = torch.Generator(device=DEV).manual_seed(12)
+    q, k, v = (torch.randn((1, 32768, 2, 128), dtype=torch.bfloat16, device=DEV, generator=gen) for _ in range(3))
+    a = flash_attention.forward(cfg, q, k, v)
+    assert torch.isfinite(a.float()).all()
+    assert (a.float() - flash_attention.forward(other, q, k, v).float()).abs().max().item() <= TOL[torch.bfloat16]
+
+
 def test_reference_errors_unchanged_without_the_wideners():
     cfg = kc.best_config(kc.DType.BF16, seq_len=320, masked=True)
     q = torch.zeros((1, 320, 2, 128), dtype=torch.bfloat16, device=DEV)
