@@ -79,7 +79,8 @@ constexpr bool plan64_ok(const Plan64 &p) {
     return e == 32 && m == 32 && d == 8;
 }
 
-template <int DT, bool OPT, bool MASK = false, int ABL = 0>
+// (optimized_softmax selects nothing here: the first tile of an item never rescales, by construction)
+template <int DT, bool MASK = false, int ABL = 0>
 __global__ void
 __launch_bounds__(256, 1)
 fa_fwd_kernel64(const KernelArgs args) {
@@ -88,7 +89,7 @@ fa_fwd_kernel64(const KernelArgs args) {
 
     using E = Elem<DT>;
     using vec8 = typename E::vec8;
-    using TR = FwdTraits<DT, QT, NWAVES, BC, SWZ, EAGER, OPT, PIPE, DMA, MASK, D>;
+    using TR = FwdTraits<DT, QT, NWAVES, BC, SWZ, EAGER, false, PIPE, DMA, MASK, D>;
     constexpr int ROWB = 2 * D;              // bytes per K / V / O row (256, or 128 at d_head 64)
     constexpr int CPR = D / 8;               // 16-B chunks per row (16 / 8)
     constexpr int RPP = 64 / CPR;            // tile rows per 1-KiB DMA piece (4 / 8)

@@ -37,7 +37,7 @@ constexpr KernelEntry make_entry() {
     if constexpr (TR::kPersistent) {  // (B_r 256, B_c 64, 4 waves) + buffer: fa_fwd_kernel64.hpp
         static_assert(NWAVES == 4 && BC == 64 && SWZ && EAGER && DMA && D == 128, "64-row pinned schedule");
         return KernelEntry{DT, 64, 4, 64, 1, 1, OPT, 1, 1, MASK ? 2 : 0, 128, TR::kThreads, TR::kLdsBytes, 1,
-                           (kernel_fn)&fa_fwd_kernel64<DT, OPT, MASK>};
+                           (kernel_fn)&fa_fwd_kernel64<DT, MASK>};
     } else {
         return KernelEntry{DT, 32 * QT, NWAVES, BC, SWZ, EAGER, OPT, PIPE, DMA, MASK ? 1 : 0, D, TR::kThreads,
                            TR::kLdsBytes, 0,

@@ -32,7 +32,7 @@ int main(int argc, char **argv) {
     a.batch_stride = (int64_t)S * H * D; a.seq_stride = H * D; a.head_stride = D;
     a.seq_len = S; a.n_heads = H; a.n_bh = B * H; a.n_q_blocks = S / 256; a.n_kv_blocks = S / 64; a.causal = 0;
     a.trace = tr;
-    auto kern = fa::fa_fwd_kernel64<15, true, false, 0>;
+    auto kern = fa::fa_fwd_kernel64<15, false, 0>;
     CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
     // persistent kernel: workgroup w serves items w, w + 256, ...; trace the second item of two workgroups
     const int items[2] = {256 + 100, 256 + 203};

@@ -19,7 +19,7 @@ static std::vector<Variant> variants;
 static hipEvent_t e0, e1;
 
 template <int ABL> void launch(const fa::KernelArgs &a) {
-    auto kern = fa::fa_fwd_kernel64<15, true, false, ABL>;
+    auto kern = fa::fa_fwd_kernel64<15, false, ABL>;
     static bool init = false;
     if (!init) { CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 163840)); init = true; }
     hipLaunchKernelGGL(kern, dim3(a.n_bh * a.n_q_blocks < 256 ? a.n_bh * a.n_q_blocks : 256), dim3(256), 163840, 0, a);

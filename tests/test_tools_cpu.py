@@ -41,9 +41,9 @@ def test_symbol_and_mangled_name_round_trip_to_config():
     assert cfg == kc.FlashForwardKernelConfig(kc.DType.BF16, 128, 256, 64, 8, True, True, True, 0, 0, 0, True, False)
     cfg16 = rocprof_bench.symbol_to_config("void fa::fa_fwd_kernel16<5, 4, 32, true, true, true>(fa::KernelArgs)")
     assert (cfg16.dtype, cfg16.B_r, cfg16.B_c, cfg16.n_warps, cfg16.optimized_softmax) == (kc.DType.FP16, 64, 32, 4, True)
-    cfg64 = rocprof_bench.symbol_to_config("void fa::fa_fwd_kernel64<15, false, false, 0>(fa::KernelArgs)")
+    cfg64 = rocprof_bench.symbol_to_config("void fa::fa_fwd_kernel64<15, false, 0>(fa::KernelArgs)")
     assert cfg64 == kc.FlashForwardKernelConfig(kc.DType.BF16, 128, 256, 64, 4, True, True, True, 0, 0, 0, True, False)
-    assert kernel_resources.demangle_variant("_ZN2fa15fa_fwd_kernel64ILi5ELb1ELb1ELi0EEEvNS_10KernelArgsE")["masked"] == 2
+    assert kernel_resources.demangle_variant("_ZN2fa15fa_fwd_kernel64ILi5ELb1ELi0EEEvNS_10KernelArgsE")["masked"] == 2
     assert rocprof_bench.symbol_to_config("void at::native::foo<float>()") is None
     v = kernel_resources.demangle_variant("_ZN2fa13fa_fwd_kernelILi15ELi1ELi8ELi64ELb1ELb1ELb0ELb1ELb0ELb0ELi128ELi0EEEvNS_10KernelArgsE")
     assert v == dict(dtype=15, rows_per_wave=32, n_waves=8, B_c=64, swizzled=1, eager=1, opt_softmax=0, pipelined=1, dma=0,
