@@ -332,13 +332,37 @@ fa_fwd_kernel64(const KernelArgs args) {
         vec8 Qr2[2][KS];  // the next item's Q (AGPRs), requested during the item's first visit
         float mraw[2];   // row max of the S tile formed by the last visit (the next item's S(0))
         bool seam = false;  // the first two visits after a seam: the epilogue's stores are in flight
-        // next item's Q rows -> the Q AGPRs.  Plain asm loads: hipcc does not count them; the wait
-        // is the vmcnt(0) at the top of the item's last visit.
-        auto load_q_next = [&](auto piece_tag, vec8 &dst) {  // piece = 8*qt + ks, dst = Qr[qt][ks]
-            constexpr int piece = decltype(piece_tag)::value, qt = piece >> 3, ks = piece & 7;
-            const int64_t row = (int64_t)qb_n * TR::kBr + wave * TR::kRowsPerWave + qt * 32 + r31;
-            const uint16_t *qp = Qn + row * ss + hi * 8;
-            asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=a"(dst) : "v"(qp), "i"(ks * 32) : "memory");
+        // ---- the next item's Q, through LDS -------------------------------------------------------
+        // The MFMA wants a lane to hold one Q row's 16-byte chunk; fetched like that from global memory
+        // a wave-instruction touches 32 rows (32 cache lines for 1 KiB), and 16 of them in a burst cost
+        // each wave 0.7-3 k cycles of queueing in the address path (tools/trace64.hip).  So a 32-row Q
+        // tile travels like a K tile: 8 coalesced 1-KiB LDS-DMA pieces (4 whole rows each) into this
+        // wave's O staging area (idle between seams), XOR-swizzled, then 8 conflict-free ds_read_b128
+        // straight into the spare Q set.  One tile per round: tile 0 is requested at the seam (or at
+        // the end of the prologue), read behind the barrier of visit 1, where tile 1 is requested,
+        // which is read behind the barrier of visit 2 -- all on the slow path that the sync point of
+        // an item's first three visits takes anyway, so the steady state carries none of it.
+        const unsigned q_stage = smem_base + 2 * TR::kStages * TILE + wave * 8192;
+        auto lane_now = [&]() {  // volatile: anything derived from threadIdx would be kept live across the walk
+            int l_;
+            asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l_));
+            return l_;
+        };
+        auto request_next_q = [&](int qt) {  // rows 32 qt .. 32 qt + 31 of this wave's rows of the next item
+            const int l_ = lane_now();
+            // piece i: rows 4i .. 4i+3; this lane: row 4i + l/16, chunk (l % 16) ^ (row & 15)
+            //   = ((l % 16) ^ (l / 16)) ^ 4 (i & 3): one lane offset, 64 (i & 3) XORed in per piece
+            const unsigned off = (unsigned)(((int64_t)(l_ >> 4) * ss) * 2) + ((((unsigned)l_ & 15) ^ ((unsigned)l_ >> 4)) << 4);
+            const uint16_t *rows0 = Qn + ((int64_t)qb_n * TR::kBr + wave * TR::kRowsPerWave + 32 * qt) * ss;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) glds16_sv_m0(rows0 + (int64_t)(4 * i) * ss, off ^ (64u * (i & 3)), q_stage + i * 1024);
+        };
+        auto read_next_q = [&](vec8 (&dst)[KS]) {  // this lane's chunks: row l % 32, chunk (2 ks + l/32) ^ (row & 15)
+            const int l_ = lane_now();
+            const unsigned base = q_stage + (l_ & 31) * 256, x = (unsigned)((l_ >> 5) ^ (l_ & 15));
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+                asm volatile("ds_read_b128 %0, %1" : "=a"(dst[ks]) : "v"(base + ((x ^ (2 * ks)) << 4)) : "memory");
         };
         auto visit = [&](int it, auto &S_cur, auto &S_nxt, auto r_tag) {
             constexpr int R = decltype(r_tag)::value;  // it & 3
@@ -353,27 +377,36 @@ fa_fwd_kernel64(const KernelArgs args) {
             // gap-0 lgkmcnt(0) that retires this wave's last LDS reads of visit it-1.
             auto sync_point = [&]() {
                 if (ABL & 8) return;
-                // what may still be in flight behind the pieces this barrier publishes: this visit's
-                // predecessor's 8 pieces, plus -- in the first three visits of an item -- the 16 stores of
-                // the previous item's epilogue and the 16 loads of the next item's Q.  One compare and
-                // one branch on the common path (the selection below costs ~20 scalar instructions in
-                // the one gap where the matrix pipe has nothing else to hide behind).
+                // One compare and one branch on the common path.  The first three visits of an item take
+                // the slow path: more may be in flight behind the pieces the barrier publishes -- in issue
+                // order: [pieces(last visit of the previous item) | 16 epilogue stores] [Q tile 0: 8]
+                // pieces(0) [Q tile 1: 8] pieces(1) pieces(2) -- and the next item's Q tiles are moved
+                // into the spare Q set here (see request_next_q).
                 if (it >= 3) {
                     asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
                     return;
                 }
-                int allow = 8;
-                if constexpr (R == 0) allow = (it == 0 && seam) ? 24 : 8;
-                if constexpr (R == 1) allow = (it == 1) ? 8 + (seam ? 16 : 0) + (has_next ? 16 : 0) : 8;
-                if constexpr (R == 2) allow = (it == 2 && has_next) ? 24 : 8;
+                const int q8 = has_next ? 8 : 0;
+                const int allow = (it < 2) ? (seam ? 24 : 8) + q8 : 8 + q8;
                 if (allow == 8) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+                else if (allow == 16) asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
                 else if (allow == 24) asm volatile("s_waitcnt vmcnt(24)\n\ts_barrier" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(40)\n\ts_barrier" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(32)\n\ts_barrier" ::: "memory");
+                if constexpr (R == 1 || R == 2) {
+                    if (it == R && has_next) {
+                        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // Q tile R-1 landed (only pieces(R-1) are younger)
+                        read_next_q(Qr2[R - 1]);
+                        if constexpr (R == 1) {
+                            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // ... and read: its image may be overwritten
+                            request_next_q(1);
+                        }
+                    }
+                }
             };
             if constexpr (R == 3) {
                 // last visit of an item forms the next item's S(0): swap the next item's Q in
                 if (it + 1 == nkc && has_next) {
-                    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");  // the Q loads (visit 0) are older than 16 pieces
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the LDS reads into the spare set (visits 1, 2)
 #pragma unroll
                     for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
@@ -537,17 +570,6 @@ fa_fwd_kernel64(const KernelArgs args) {
                     if (it + 1 < nkc) mask_tile(S_nxt, nkc - 2 - it, qb_c);
                     else mask_tile(S_nxt, nkn - 1, qb_n);
                 }
-                if constexpr (R == 0 && g == 33) {
-                    // first visit of an item: request the NEXT item's Q rows into the spare Q set
-                    // (64 of the AGPRs are otherwise unused); they are swapped in at the top of
-                    // this item's last visit, several visits after they have landed
-                    if (it == 0 && has_next) {
-                        static_for<0, 16>([&](auto i) {
-                            constexpr int pc = decltype(i)::value;
-                            load_q_next(IntTag<pc>{}, Qr2[pc >> 3][pc & 7]);
-                        });
-                    }
-                }
                 if constexpr (plan.dma[g] >= 0 && !(ABL & 16)) {  // one 1-KiB DMA piece
                     constexpr int j = plan.dma[g] >> 1;
                     // per-piece lane offsets: 6 more VGPRs than one offset + a scalar piece stride (piece j
@@ -618,7 +640,11 @@ fa_fwd_kernel64(const KernelArgs args) {
         dma_v(tile_g(Vc, Vn, 2), 2);
         kq = tile_g(Kc, Kn, 4);
         vq = tile_g(Vc, Vn, 3);
-        if (!(ABL & 8)) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");  // K(0), Q landed
+        if (has_next) request_next_q(0);
+        if (!(ABL & 8)) {  // K(0), Q landed: everything younger may fly
+            if (has_next) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+        }
         barrier();
         {
             // S(0) and its row max, which becomes the first reference max (O = l = 0)
@@ -646,7 +672,10 @@ fa_fwd_kernel64(const KernelArgs args) {
                 neg_msc[qt] = -(finite_or_zero(m[qt]) * c);
                 m_pend[qt] = m[qt];
             }
-            if (!(ABL & 8)) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");  // K(1) landed (under S(0))
+            if (!(ABL & 8)) {  // K(1) landed (under S(0))
+                if (has_next) asm volatile("s_waitcnt vmcnt(28)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+            }
             barrier();
             ring[0] = k_frag(smem + TILE, 0);  // first operands of visit 0: K(1)
             ring[1] = k_frag(smem + TILE, 1);
@@ -719,6 +748,7 @@ fa_fwd_kernel64(const KernelArgs args) {
             set_next();
             kq = tile_g(Kc, Kn, 4);  // visit 0 requests K(4), V(3) (for n_kv == 4 that is already the item after)
             vq = tile_g(Vc, Vn, 3);
+            if (has_next) request_next_q(0);  // (the staging area is free again: store_item's reads have retired)
             seam = true;
             resc_any = 0;
 #pragma unroll
