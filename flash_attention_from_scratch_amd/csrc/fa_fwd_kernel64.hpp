@@ -318,14 +318,12 @@ fa_fwd_kernel64(const KernelArgs args) {
         auto dma_k = [&](const uint16_t *src, int stage) {
 #pragma unroll
             for (int j = 0; j < DMA_PER_WAVE; ++j)
-                glds16_sv_m0(MASK ? src + j * (16 * ss) : src, k_off[MASK ? 0 : j],
-                             smem_base + stage * TILE + (wave + NWAVES * j) * 1024);
+                glds16_sv_m0(src, k_off[j], smem_base + stage * TILE + (wave + NWAVES * j) * 1024);
         };
         auto dma_v = [&](const uint16_t *src, int stage) {
 #pragma unroll
             for (int j = 0; j < DMA_PER_WAVE; ++j)
-                glds16_sv_m0(MASK ? src + j * (16 * ss) : src, v_off[MASK ? 0 : j],
-                             smem_base + V_BASE + stage * TILE + (wave + NWAVES * j) * 1024);
+                glds16_sv_m0(src, v_off[j], smem_base + V_BASE + stage * TILE + (wave + NWAVES * j) * 1024);
         };
         const uint16_t *kq = nullptr, *vq = nullptr;  // next K / V tile to request (set per item below)
         vec8 ring[4];  // operand ring: slot u % 4, rewritten two steps after the MFMAs that read it
@@ -574,15 +572,9 @@ fa_fwd_kernel64(const KernelArgs args) {
                     constexpr int j = plan.dma[g] >> 1;
                     // per-piece lane offsets: 6 more VGPRs than one offset + a scalar piece stride (piece j
                     // of a wave starts 16 rows below piece j-1), but 16 fewer SALU instructions per
-                    // visit (+0.5 %).  The masked variant has no VGPRs to spare and takes the stride.
-                    if constexpr (MASK) {
-                        const int64_t piece_stride = 16 * ss;
-                        if constexpr ((plan.dma[g] & 1) == 0) glds16_sv_m0(kq + j * piece_stride, k_off[0], kdst + NWAVES * j * 1024);
-                        else glds16_sv_m0(vq + j * piece_stride, v_off[0], vdst + NWAVES * j * 1024);
-                    } else {
-                        if constexpr ((plan.dma[g] & 1) == 0) glds16_sv_m0(kq, k_off[j], kdst + NWAVES * j * 1024);
-                        else glds16_sv_m0(vq, v_off[j], vdst + NWAVES * j * 1024);
-                    }
+                    // visit (+0.5 %)
+                    if constexpr ((plan.dma[g] & 1) == 0) glds16_sv_m0(kq, k_off[j], kdst + NWAVES * j * 1024);
+                    else glds16_sv_m0(vq, v_off[j], vdst + NWAVES * j * 1024);
                 }
                 static_for<0, plan.exp_n[g]>([&](auto i) { exp_unit(plan.exp_first[g] + decltype(i)::value); });
                 static_for<0, plan.max_n[g]>([&](auto i) { max_unit(plan.max_first[g] + decltype(i)::value); });
