@@ -190,11 +190,10 @@ fa_fwd_kernel64(const KernelArgs args) {
     const float c = (float)((double)(1.0f / __builtin_sqrtf((float)D)) * 1.4426950408889634074);
 
     f32x16 O[QT][DTILES];
-    float m[QT], l[QT];
+    float m[QT];
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
         m[qt] = -__builtin_inff();
-        l[qt] = 0.0f;
 #pragma unroll
         for (int t = 0; t < DTILES; ++t)
 #pragma unroll
@@ -252,6 +251,10 @@ fa_fwd_kernel64(const KernelArgs args) {
         f32x16 Sa[2][NT], Sb[2][NT];
         u32x4 Pw[2][4] = {};     // P[qt][16-key slice]: B operand of O^T += V^T P^T
         float neg_msc[2];        // -(m c)
+        float thr[2];            // m + TAU / c: a row max above it moves the reference max
+        // running row sums (fp32 P, before rounding: softmax.cuh:66-83), two chains per Q tile; l = their
+        // sum, taken in the epilogue (the reference adds a per-tile sum to l: same terms, other order)
+        float rs[2][2] = {{0.0f, 0.0f}, {0.0f, 0.0f}};
         float m_pend[2];         // candidate reference max found during the previous visit
         unsigned resc_any = 0;   // bit qt: Q tile qt moves its reference max at the next visit's top
         auto k_frag = [&](const char *kt, int step) -> vec8 {  // step = 2*ks + nt
@@ -426,10 +429,13 @@ fa_fwd_kernel64(const KernelArgs args) {
 #pragma unroll
                 for (int qt = 0; qt < 2; ++qt) {
                     if (!(resc_any & (1u << qt))) continue;
-                    const float alpha = __builtin_amdgcn_exp2f((m[qt] - m_pend[qt]) * c);
-                    m[qt] = m_pend[qt];
-                    neg_msc[qt] = -(finite_or_zero(m[qt]) * c);
-                    l[qt] *= alpha;
+                    const float m_new = fmaxf(m[qt], m_pend[qt]);
+                    const float alpha = __builtin_amdgcn_exp2f((m[qt] - m_new) * c);
+                    m[qt] = m_new;
+                    neg_msc[qt] = -(finite_or_zero(m_new) * c);
+                    thr[qt] = m_new + TAU / c;
+                    rs[qt][0] *= alpha;
+                    rs[qt][1] *= alpha;
 #pragma unroll
                     for (int t = 0; t < DTILES; ++t)
 #pragma unroll
@@ -438,8 +444,7 @@ fa_fwd_kernel64(const KernelArgs args) {
             }
             const char *kt = smem + ((R + 1) & 3) * TILE;
             const char *vt = smem + V_BASE + R * TILE;
-            float rs[2][2] = {{0.0f, 0.0f}, {0.0f, 0.0f}};
-            float vm[2][2], m_new[2];
+            float vm[2][2];
             unsigned any01 = 0;
             auto exp_unit = [&](int u) {  // u = 8*s16 + 2*j + qt: in the order P.V consumes P
                 if constexpr (ABL & 2) return;
@@ -476,7 +481,7 @@ fa_fwd_kernel64(const KernelArgs args) {
                 auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
                 return vmax2(__uint_as_float(r[0]), __uint_as_float(r[1]));
             };
-            auto tail_unit = [&](int k) {  // end-of-visit chain, one step per gap (pinned by volatile asm)
+            auto tail_unit = [&](int k) {
                 if (k == 1) {
                     vm[0][0] = vmax2(vm[0][0], vm[0][1]);
                     vm[1][0] = vmax2(vm[1][0], vm[1][1]);
@@ -484,32 +489,20 @@ fa_fwd_kernel64(const KernelArgs args) {
                 }
                 if (k == 2) { vm[0][0] = lane_pair_max(vm[0][0]); asm volatile("" : "+v"(vm[0][0])); }
                 if (k == 3) { vm[1][0] = lane_pair_max(vm[1][0]); asm volatile("" : "+v"(vm[1][0])); }
-                if (k == 4) {  // candidate reference max
-                    mraw[0] = vm[0][0];
-                    mraw[1] = vm[1][0];
-                    m_new[0] = vmax2(m[0], vm[0][0]);
-                    m_new[1] = vmax2(m[1], vm[1][0]);
-                    asm volatile("" : "+v"(m_new[0]), "+v"(m_new[1]));
+                if (k == 4) {
+                    mraw[0] = m_pend[0] = vm[0][0];
+                    mraw[1] = m_pend[1] = vm[1][0];
+                    asm volatile("" : "+v"(m_pend[0]), "+v"(m_pend[1]));
                 }
-                if (k == 5) {
-                    l[0] += rs[0][0] + rs[0][1];
-                    l[1] += rs[1][0] + rs[1][1];
-                    asm volatile("" : "+v"(l[0]), "+v"(l[1]));
-                }
-                if (k == 6 || k == 7) {  // did some row's max rise by more than TAU / c?
+                if (k == 6 || k == 7) {
                     const int qt = k - 6;
-                    m_pend[qt] = m_new[qt];
-                    float rise = (m_new[qt] - m[qt]) * c;
-                    asm volatile("" : "+v"(rise));  // (an "s" pin would make hipcc treat the flag as divergent)
-                    any01 |= (__ballot(rise > TAU) != 0 ? 1u : 0u) << qt;
+                    any01 |= (__ballot(m_pend[qt] > thr[qt]) != 0 ? 1u : 0u) << qt;
                 }
-                if (k == 8) {  // next tiles to request (scalar ALU)
+                if (k == 8) {
                     resc_any = any01;
-                    // visit it+1 requests K(it+5), V(it+4); the stream wraps into the next item
                     kq = (it + 5 == nkc) ? Kn + (int64_t)(nkn - 1) * tile_stride : kq - tile_stride;
                     vq = (it + 4 == nkc) ? Vn + (int64_t)(nkn - 1) * tile_stride : vq - tile_stride;
                     if constexpr (R == 1) seam = false;
-
                 }
             };
             auto tail_step = [&](int k) {  // plan step: 1..8 one unit each; 10..14 the masked plan's merged steps
@@ -662,6 +655,7 @@ fa_fwd_kernel64(const KernelArgs args) {
                     for (int r = 0; r < 16; ++r) v = fmaxf(v, Sa[qt][nt][r]);
                 m[qt] = pair_max(v);
                 neg_msc[qt] = -(finite_or_zero(m[qt]) * c);
+                thr[qt] = m[qt] + TAU / c;
                 m_pend[qt] = m[qt];
             }
             if (!(ABL & 8)) {  // K(1) landed (under S(0))
@@ -688,7 +682,7 @@ fa_fwd_kernel64(const KernelArgs args) {
             const int rsub = lane / CPR, chunk = lane & (CPR - 1);
 #pragma unroll
             for (int qt = 0; qt < 2; ++qt) {
-                const float inv = 1.0f / pair_sum(l[qt]);
+                const float inv = 1.0f / pair_sum(rs[qt][0] + rs[qt][1]);
                 char *wp = stage_o + r31 * ROWB + hi * 8;
 #pragma unroll
                 for (int t = 0; t < DTILES; ++t) {
@@ -747,8 +741,9 @@ fa_fwd_kernel64(const KernelArgs args) {
             for (int qt = 0; qt < 2; ++qt) {
                 m[qt] = mraw[qt];
                 neg_msc[qt] = -(finite_or_zero(m[qt]) * c);
+                thr[qt] = m[qt] + TAU / c;
                 m_pend[qt] = m[qt];
-                l[qt] = 0.0f;
+                rs[qt][0] = rs[qt][1] = 0.0f;
 #pragma unroll
                 for (int t = 0; t < DTILES; ++t)
 #pragma unroll
