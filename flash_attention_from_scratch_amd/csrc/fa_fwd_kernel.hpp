@@ -255,6 +255,10 @@ static FA_DEV void glds16_sv_m0(const void *base_wave_uniform, unsigned lane_byt
                  : "v"(lane_byte_off), "s"(base_wave_uniform), "s"(lds_dst_wave_uniform)
                  : "memory");
 }
+// ... and with the M0 write split off (the caller wrote M0 at least one instruction earlier)
+static FA_DEV void glds16_issue(const void *base_wave_uniform, unsigned lane_byte_off) {
+    asm volatile("global_load_lds_dwordx4 %0, %1" : : "v"(lane_byte_off), "s"(base_wave_uniform) : "memory");
+}
 static FA_DEV void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 // workgroup barrier that the compiler may not move LDS traffic across and that does
 // not drain VMEM (in-flight DMA survives it)

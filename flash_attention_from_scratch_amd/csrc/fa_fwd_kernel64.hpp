@@ -561,13 +561,21 @@ fa_fwd_kernel64(const KernelArgs args) {
                     if (it + 1 < nkc) mask_tile(S_nxt, nkc - 2 - it, qb_c);
                     else mask_tile(S_nxt, nkn - 1, qb_n);
                 }
-                if constexpr (plan.dma[g] >= 0 && !(ABL & 16)) {  // one 1-KiB DMA piece
+                if constexpr (g < 63 && plan.dma[g + 1] >= 0 && !(ABL & 16)) {
+                    // M0 (LDS destination) of the DMA piece of the NEXT gap: the write needs one instruction
+                    // between it and the DMA, and that gap's MFMA is one (hipcc itself never touches M0 here)
+                    constexpr int j = plan.dma[g + 1] >> 1;
+                    asm volatile("s_mov_b32 m0, %0" ::"s"((plan.dma[g + 1] & 1) == 0 ? kdst + NWAVES * j * 1024
+                                                                                      : vdst + NWAVES * j * 1024));
+                }
+                if constexpr (plan.dma[g] >= 0 && !(ABL & 16)) {  // one 1-KiB DMA piece (its M0 was set one gap ago)
                     constexpr int j = plan.dma[g] >> 1;
+                    static_assert(g > 0 && plan.dma[g - 1] < 0, "a DMA piece needs the gap before it for its M0");
                     // per-piece lane offsets: 6 more VGPRs than one offset + a scalar piece stride (piece j
                     // of a wave starts 16 rows below piece j-1), but 16 fewer SALU instructions per
                     // visit (+0.5 %)
-                    if constexpr ((plan.dma[g] & 1) == 0) glds16_sv_m0(kq, k_off[j], kdst + NWAVES * j * 1024);
-                    else glds16_sv_m0(vq, v_off[j], vdst + NWAVES * j * 1024);
+                    if constexpr ((plan.dma[g] & 1) == 0) glds16_issue(kq, k_off[j]);
+                    else glds16_issue(vq, v_off[j]);
                 }
                 static_for<0, plan.exp_n[g]>([&](auto i) { exp_unit(plan.exp_first[g] + decltype(i)::value); });
                 static_for<0, plan.max_n[g]>([&](auto i) { max_unit(plan.max_first[g] + decltype(i)::value); });
