@@ -473,22 +473,26 @@ fa_fwd_kernel64(const KernelArgs args) {
                 const int nt = u >> 4, qt = (u >> 3) & 1, e = 2 * (u & 7), a = u & 1;  // two chains per Q tile
                 if constexpr (ABL & 2) { vm[qt][a] = 0.0f; return; }
                 // asm forms: fmaxf() on MFMA results makes hipcc canonicalise both inputs first
-                if ((u & 7) < 2 && nt == 0) vm[qt][a] = vmax2(S_nxt[qt][nt][e], S_nxt[qt][nt][e + 1]);
-                else vm[qt][a] = vmax3(vm[qt][a], S_nxt[qt][nt][e], S_nxt[qt][nt][e + 1]);
-                asm volatile("" : "+v"(vm[qt][a]));  // pinned to its gap (S_nxt is rewritten next visit)
+                // volatile: pinned to its gap (S_nxt is rewritten next visit).  Not an empty "+v" asm behind
+                // it: hipcc pads an asm that reads what the asm right before it wrote with an s_nop
+                if ((u & 7) < 2 && nt == 0)
+                    asm volatile("v_max_f32 %0, %1, %2" : "=v"(vm[qt][a]) : "v"(S_nxt[qt][nt][e]), "v"(S_nxt[qt][nt][e + 1]));
+                else
+                    asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(vm[qt][a]) : "v"(S_nxt[qt][nt][e]), "v"(S_nxt[qt][nt][e + 1]));
             };
             auto lane_pair_max = [&](float x) {
                 auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-                return vmax2(__uint_as_float(r[0]), __uint_as_float(r[1]));
+                float d;
+                asm volatile("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(__uint_as_float(r[0])), "v"(__uint_as_float(r[1])));
+                return d;
             };
             auto tail_unit = [&](int k) {
                 if (k == 1) {
-                    vm[0][0] = vmax2(vm[0][0], vm[0][1]);
-                    vm[1][0] = vmax2(vm[1][0], vm[1][1]);
-                    asm volatile("" : "+v"(vm[0][0]), "+v"(vm[1][0]));
+                    asm volatile("v_max_f32 %0, %0, %1" : "+v"(vm[0][0]) : "v"(vm[0][1]));
+                    asm volatile("v_max_f32 %0, %0, %1" : "+v"(vm[1][0]) : "v"(vm[1][1]));
                 }
-                if (k == 2) { vm[0][0] = lane_pair_max(vm[0][0]); asm volatile("" : "+v"(vm[0][0])); }
-                if (k == 3) { vm[1][0] = lane_pair_max(vm[1][0]); asm volatile("" : "+v"(vm[1][0])); }
+                if (k == 2) vm[0][0] = lane_pair_max(vm[0][0]);
+                if (k == 3) vm[1][0] = lane_pair_max(vm[1][0]);
                 if (k == 4) {
                     mraw[0] = m_pend[0] = vm[0][0];
                     mraw[1] = m_pend[1] = vm[1][0];
