@@ -87,6 +87,7 @@ struct KernelArgs {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -135,6 +136,9 @@ template <> struct Elem<15> {  // bf16
     static FA_DEV void mfma_acc_a_p(f32x16 &acc, vec8 a, u32x4 p) {  // acc(AGPR) += a * p(VGPR, packed >= 1 step ago)
         asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(p));
     }
+    static FA_DEV void mfma_zero_a(f32x16 &acc, vec8 z) {  // acc(AGPR) = z * z + 0 with z = 0: 16 registers cleared by one instruction
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %1, 0" : "=a"(acc) : "v"(z));
+    }
     static FA_DEV unsigned pack2(float x, float y) {  // RNE, low half = x
         typedef __bf16 pair_t __attribute__((ext_vector_type(2)));
         pair_t r;
@@ -176,6 +180,9 @@ template <> struct Elem<5> {  // fp16
     }
     static FA_DEV void mfma_acc_a_p(f32x16 &acc, vec8 a, u32x4 p) {  // acc(AGPR) += a * p(VGPR, packed >= 1 step ago)
         asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(p));
+    }
+    static FA_DEV void mfma_zero_a(f32x16 &acc, vec8 z) {  // acc(AGPR) = z * z + 0 with z = 0: 16 registers cleared by one instruction
+        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %1, 0" : "=a"(acc) : "v"(z));
     }
     static FA_DEV unsigned pack2(float x, float y) {  // RNE, low half = x
         typedef _Float16 pair_t __attribute__((ext_vector_type(2)));

@@ -90,6 +90,19 @@ fa_fwd_kernel64(const KernelArgs args) {
     using E = Elem<DT>;
     using vec8 = typename E::vec8;
     using TR = FwdTraits<DT, QT, NWAVES, BC, SWZ, EAGER, false, PIPE, DMA, MASK, D>;
+#if defined(FA_TRACE) && FA_TRACE == 3
+#define FA_TL() tl()
+#define FA_VM8 "9"   // the stamp's store is one more vector-memory operation behind the pieces
+#define FA_VM16 "17"
+#define FA_VM24 "25"
+#define FA_VM32 "33"
+#else
+#define FA_TL() ((void)0)
+#define FA_VM8 "8"
+#define FA_VM16 "16"
+#define FA_VM24 "24"
+#define FA_VM32 "32"
+#endif
     constexpr int ROWB = 2 * D;              // bytes per K / V / O row (256, or 128 at d_head 64)
     constexpr int CPR = D / 8;               // 16-B chunks per row (16 / 8)
     constexpr int RPP = 64 / CPR;            // tile rows per 1-KiB DMA piece (4 / 8)
@@ -112,6 +125,22 @@ fa_fwd_kernel64(const KernelArgs args) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r31 = lane & 31;
     const int hi = lane >> 5;
+#if defined(FA_TRACE) && FA_TRACE == 3
+    // timeline build (tools/trace64.hip): every wave stamps (low 32 bits of s_memtime) kernel entry, the
+    // end of the prologue, every visit top and the exit into trace32[(wave * 256 + blockIdx.x) * 96 + n];
+    // every wave, so that all four count the same one extra operation in vmcnt (FA_VM*)
+    unsigned *tl_p = (unsigned *)args.trace + (wave * 256 + (int)blockIdx.x) * 96;
+    auto tl = [&]() {
+        unsigned long long t_;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");
+        const unsigned lo_ = __builtin_amdgcn_readfirstlane((unsigned)t_);
+        int l_;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l_));
+        if (l_ == 0) *tl_p = lo_;
+        ++tl_p;
+    };
+    tl();
+#endif
 
     // ---- workgroup -> (batch*head, Q block); XCD-aware when n_bh % 8 == 0 --------
     const int nq = args.n_q_blocks;
@@ -192,13 +221,27 @@ fa_fwd_kernel64(const KernelArgs args) {
     f32x16 O[QT][DTILES];
     float m[QT];
 #pragma unroll
-    for (int qt = 0; qt < QT; ++qt) {
-        m[qt] = -__builtin_inff();
+    for (int qt = 0; qt < QT; ++qt) m[qt] = -__builtin_inff();
+    // O = 0 by eight MFMAs on a zero operand (16 registers apiece; 128 v_accvgpr_write otherwise)
+    auto zero_o = [&]() {
+        if constexpr (MASK) {  // (the causal variant has no four registers to spare at the seam)
 #pragma unroll
-        for (int t = 0; t < DTILES; ++t)
+            for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) O[qt][t][r] = 0.0f;
-    }
+                for (int t = 0; t < DTILES; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) O[qt][t][r] = 0.0f;
+            return;
+        }
+        typename E::vec8 zz = __builtin_bit_cast(typename E::vec8, u32x4{0u, 0u, 0u, 0u});
+        asm volatile("s_nop 3" : "+v"(zz));  // VALU write -> MFMA operand read
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+            for (int t = 0; t < DTILES; ++t) E::mfma_zero_a(O[qt][t], zz);
+        asm volatile("" ::"v"(zz));  // operand registers stay allocated until the last one has issued
+    };
+    zero_o();
 
     // per-lane LDS read offsets
     //   K A-operand: row 32*nt + r31, chunk (2*ks + hi) ^ (r31 & 15)
@@ -371,6 +414,7 @@ fa_fwd_kernel64(const KernelArgs args) {
             unsigned long long ts[20];
             asm volatile("s_memtime %0" : "=s"(ts[0]));
 #endif
+            FA_TL();
             // the visit's synchronisation point: K(it+2), V(it+1) landed (requested two visits ago;
             // K(it+1), V(it) were published by the previous barrier), the 8 youngest pieces may fly
             // on; behind it every wave has finished visit it-1, whose K / V stages the DMA of this
@@ -384,18 +428,18 @@ fa_fwd_kernel64(const KernelArgs args) {
                 // pieces(0) [Q tile 1: 8] pieces(1) pieces(2) -- and the next item's Q tiles are moved
                 // into the spare Q set here (see request_next_q).
                 if (it >= 3) {
-                    asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+                    asm volatile("s_waitcnt vmcnt(" FA_VM8 ")\n\ts_barrier" ::: "memory");
                     return;
                 }
                 const int q8 = has_next ? 8 : 0;
                 const int allow = (it < 2) ? (seam ? 24 : 8) + q8 : 8 + q8;
-                if (allow == 8) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
-                else if (allow == 16) asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
-                else if (allow == 24) asm volatile("s_waitcnt vmcnt(24)\n\ts_barrier" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(32)\n\ts_barrier" ::: "memory");
+                if (allow == 8) asm volatile("s_waitcnt vmcnt(" FA_VM8 ")\n\ts_barrier" ::: "memory");
+                else if (allow == 16) asm volatile("s_waitcnt vmcnt(" FA_VM16 ")\n\ts_barrier" ::: "memory");
+                else if (allow == 24) asm volatile("s_waitcnt vmcnt(" FA_VM24 ")\n\ts_barrier" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(" FA_VM32 ")\n\ts_barrier" ::: "memory");
                 if constexpr (R == 1 || R == 2) {
                     if (it == R && has_next) {
-                        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // Q tile R-1 landed (only pieces(R-1) are younger)
+                        asm volatile("s_waitcnt vmcnt(" FA_VM8 ")" ::: "memory");  // Q tile R-1 landed (only pieces(R-1) are younger)
                         read_next_q(Qr2[R - 1]);
                         if constexpr (R == 1) {
                             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // ... and read: its image may be overwritten
@@ -675,6 +719,7 @@ fa_fwd_kernel64(const KernelArgs args) {
                 else asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
             }
             barrier();
+            FA_TL();  // S(0) formed, K(1) landed
             ring[0] = k_frag(smem + TILE, 0);  // first operands of visit 0: K(1)
             ring[1] = k_frag(smem + TILE, 1);
         }
@@ -698,26 +743,39 @@ fa_fwd_kernel64(const KernelArgs args) {
                 char *wp = stage_o + r31 * ROWB + hi * 8;
 #pragma unroll
                 for (int t = 0; t < DTILES; ++t) {
-                    float o[16];
+                    // (the tile's accumulator copies start here: hipcc otherwise reads all 128 up front and spills)
+                    asm volatile("" : "+a"(O[qt][t]));
+                    // regs 4rq..4rq+3 : d = 32t + 8rq + 4hi + 0..3  -> chunk 4t + rq, half hi.  Converted in
+                    // pairs (one v_cvt_pk per two values; a per-element convert costs three instructions per pair)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) o[r] = O[qt][t][r] * inv;
-                    // regs 4rq..4rq+3 : d = 32t + 8rq + 4hi + 0..3  -> chunk 4t + rq, half hi
-                    const s16x8 lo_s = __builtin_bit_cast(s16x8, E::pack8(o));
-                    const s16x8 up_s = __builtin_bit_cast(s16x8, E::pack8(o + 8));
-                    *(s16x4 *)(wp + (((4 * t + 0) ^ swz_of(r31)) << 4)) = lo_s.lo;
-                    *(s16x4 *)(wp + (((4 * t + 1) ^ swz_of(r31)) << 4)) = lo_s.hi;
-                    *(s16x4 *)(wp + (((4 * t + 2) ^ swz_of(r31)) << 4)) = up_s.lo;
-                    *(s16x4 *)(wp + (((4 * t + 3) ^ swz_of(r31)) << 4)) = up_s.hi;
+                    for (int rq = 0; rq < 4; ++rq) {
+                        typedef float f32x2 __attribute__((ext_vector_type(2)));
+                        const f32x2 lo2 = f32x2{O[qt][t][4 * rq], O[qt][t][4 * rq + 1]} * inv;  // v_pk_mul_f32
+                        const f32x2 hi2 = f32x2{O[qt][t][4 * rq + 2], O[qt][t][4 * rq + 3]} * inv;
+                        u32x2 w;
+                        w[0] = E::pack2(lo2[0], lo2[1]);
+                        w[1] = E::pack2(hi2[0], hi2[1]);
+                        *(u32x2 *)(wp + (((4 * t + rq) ^ swz_of(r31)) << 4)) = w;
+                    }
                     __builtin_amdgcn_sched_barrier(0);  // one d tile at a time: S(0) of the next item is live
                 }
-                const int64_t row0 = (int64_t)qb_c * TR::kBr + wave * TR::kRowsPerWave + qt * 32;
+                // rows RPP i + rsub of the tile: a scalar row base per store, one 32-bit lane offset for all;
+                // all reads first (the waits then count down), and the read address is one XOR per row
+                // group: row = RPP i + rsub, so chunk ^ swz_of(row) = (chunk ^ rsub) ^ (RPP i & 15)
+                static_assert(D == 128 && RPP == 4, "epilogue address split");
+                const uint16_t *rows0 = Oc + ((int64_t)qb_c * TR::kBr + wave * TR::kRowsPerWave + qt * 32) * ss;
+                const unsigned lane_off = (unsigned)rsub * (unsigned)ss * 2u + (unsigned)chunk * 16u;
+                const unsigned rd0 = (unsigned)rsub * ROWB + ((unsigned)(chunk ^ rsub) << 4);
+                s16x8 v[32 / RPP];
+#pragma unroll
+                for (int i = 0; i < 32 / RPP; ++i)
+                    v[i] = *(const s16x8 *)(stage_o + RPP * i * ROWB + (rd0 ^ (((RPP * i) & 15u) << 4)));
 #pragma unroll
                 for (int i = 0; i < 32 / RPP; ++i) {
-                    const int row = RPP * i + rsub;
-                    const s16x8 v = *(const s16x8 *)(stage_o + row * ROWB + ((chunk ^ swz_of(row)) << 4));
                     // non-temporal: O is written once and not read again by this kernel (+1.3...2.8 % at
-                    // seq_len <= 1024, where the store-issue-bound epilogue is a visible share)
-                    __builtin_nontemporal_store(v, (s16x8 *)(Oc + (row0 + row) * ss + chunk * 8));
+                    // seq_len <= 1024, where the store-issue-bound epilogue is a visible share).
+                    // asm: scalar row base + 32-bit lane offset (hipcc builds a 64-bit address per lane and store)
+                    asm volatile("global_store_dwordx4 %0, %1, %2 nt" ::"v"(lane_off), "v"(v[i]), "s"(rows0 + (int64_t)(RPP * i) * ss));
                 }
             }
         };
@@ -756,11 +814,8 @@ fa_fwd_kernel64(const KernelArgs args) {
                 thr[qt] = m[qt] + TAU / c;
                 m_pend[qt] = m[qt];
                 rs[qt][0] = rs[qt][1] = 0.0f;
-#pragma unroll
-                for (int t = 0; t < DTILES; ++t)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) O[qt][t][r] = 0.0f;
             }
+            zero_o();
 #ifdef FA_TRACE
             asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(te2)::"memory");
             if (item - (int)gridDim.x == args.trace_block && lane == 0) {
@@ -771,6 +826,7 @@ fa_fwd_kernel64(const KernelArgs args) {
 #endif
         }
         dma_wait();  // nothing may still be landing in the LDS when the workgroup retires
+        FA_TL();
         return;
     }
 }

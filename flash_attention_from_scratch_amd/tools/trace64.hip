@@ -11,6 +11,65 @@
 #include <vector>
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(e_), __LINE__); exit(2); } } while (0)
 
+#if FA_TRACE == 3
+// timeline mode (-DFA_TRACE=3): trace64 [seq_len] [batch] -- one launch, every workgroup's wave 0 stamps
+// entry | S(0) formed | visit tops ... | exit (a seam shows as a long visit)
+int main(int argc, char **argv) {
+    const int S = argc > 1 ? atoi(argv[1]) : 512, B = argc > 2 ? atoi(argv[2]) : 16, H = 16, D = 128;
+    const size_t n = (size_t)B * S * H * D;
+    std::vector<uint16_t> h(n);
+    uint16_t *q, *k, *v, *o; unsigned long long *tr;
+    CHECK(hipMalloc(&q, n * 2)); CHECK(hipMalloc(&k, n * 2)); CHECK(hipMalloc(&v, n * 2)); CHECK(hipMalloc(&o, n * 2));
+    const int grid = 256;
+    CHECK(hipMalloc(&tr, 4 * grid * 96 * 8));
+    char *flush; const size_t flush_bytes = (size_t)1 << 30;
+    CHECK(hipMalloc(&flush, flush_bytes));
+    srand(1);
+    for (int t = 0; t < 3; ++t) {
+        for (size_t i = 0; i < n; ++i) {
+            float x = ((rand() & 0xffff) / 65536.0f - 0.5f) * 3.4f;
+            uint32_t u; memcpy(&u, &x, 4); h[i] = (uint16_t)(u >> 16);
+        }
+        CHECK(hipMemcpy(t == 0 ? q : t == 1 ? k : v, h.data(), n * 2, hipMemcpyHostToDevice));
+    }
+    fa::KernelArgs a;
+    a.q = q; a.k = k; a.v = v; a.o = o;
+    a.batch_stride = (int64_t)S * H * D; a.seq_stride = H * D; a.head_stride = D;
+    a.seq_len = S; a.n_heads = H; a.n_bh = B * H; a.n_q_blocks = S / 256; a.n_kv_blocks = S / 64; a.causal = 0;
+    a.trace = tr; a.trace_block = -1; a.trace_visit = -1;
+    auto kern = fa::fa_fwd_kernel64<15, false, 0>;
+    CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
+    hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    for (int mode = 0; mode < 2; ++mode) {  // 0: warm caches, back to back; 1: cache flushed before the launch
+        for (int warm = 0; warm < 5; ++warm) hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 163840, 0, a);
+        if (mode == 1) { CHECK(hipMemset(flush, 1, flush_bytes)); }
+        CHECK(hipMemset(tr, 0, 4 * grid * 96 * 8));
+        CHECK(hipDeviceSynchronize());
+        CHECK(hipEventRecord(e0));
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 163840, 0, a);
+        CHECK(hipEventRecord(e1));
+        CHECK(hipDeviceSynchronize());
+        float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+        std::vector<unsigned> t(grid * 96);  // wave 0's stamps: low 32 bits of s_memtime, 96 slots per workgroup
+        CHECK(hipMemcpy(t.data(), tr, grid * 96 * 4, hipMemcpyDeviceToHost));
+        int cnt = 0;
+        while (cnt < 96 && t[cnt]) ++cnt;
+        printf("== %s: S=%d B=%d  event %.1f us (%d stamps per workgroup: entry, S(0) formed, visit tops, exit)\n",
+               mode ? "flushed" : "warm", S, B, ms * 1000, cnt);
+        const int show[6] = {0, 1, 37, 128, 200, 255};
+        for (int si = 0; si < 6; ++si) {
+            const unsigned *r = t.data() + show[si] * 96;
+            printf("wg %3d: total %7u | prologue %5u |", show[si], r[cnt - 1] - r[0], r[1] - r[0]);
+            for (int i = 2; i < cnt; ++i) printf(" %u", r[i] - r[i - 1]);
+            printf("\n");
+        }
+        printf("mean  : total %7.0f |", [&] { double s_ = 0; for (int w = 0; w < grid; ++w) s_ += (double)(t[w * 96 + cnt - 1] - t[w * 96]); return s_ / grid; }());
+        for (int i = 1; i < cnt; ++i) { double sum = 0; for (int w = 0; w < grid; ++w) sum += (double)(t[w * 96 + i] - t[w * 96 + i - 1]); printf(" %.0f", sum / grid); }
+        printf("\n");
+    }
+    return 0;
+}
+#else
 int main(int argc, char **argv) {
     const int B = 16, H = 16, D = 128, S = 4096;
     const bool zeros = argc > 1 && !strcmp(argv[1], "zeros");
@@ -63,3 +122,4 @@ int main(int argc, char **argv) {
     }
     return 0;
 }
+#endif
