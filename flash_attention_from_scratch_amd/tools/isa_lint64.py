@@ -56,13 +56,19 @@ def lint(path, window=3, raw=2):
                         written |= regs(n.split()[2])  # these exchange: both operands are written
                     if written & rd:
                         findings.append(("WAR", kidx, i, l, n))
-            for k in range(1, raw + 1):
-                if i - k < 0 or code[i - k].startswith("v_mfma"):
-                    break
+            dist = 0  # issue slots between producer and MFMA: an `s_nop n` fills n + 1 of them
+            k = 1
+            while i - k >= 0 and not code[i - k].startswith("v_mfma"):
                 p = code[i - k]
-                if p.startswith("v_") and not p.startswith("v_cmp"):
+                dist += 1
+                if dist > raw:
+                    break
+                if p.startswith("s_nop"):
+                    dist += int(p.split()[1])
+                elif p.startswith("v_") and not p.startswith("v_cmp"):
                     if regs(p.split()[1]) & rd:
                         findings.append(("RAW", kidx, i, l, p))
+                k += 1
     return findings
 
 
