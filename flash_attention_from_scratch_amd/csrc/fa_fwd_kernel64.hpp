@@ -92,12 +92,16 @@ fa_fwd_kernel64(const KernelArgs args) {
     using TR = FwdTraits<DT, QT, NWAVES, BC, SWZ, EAGER, false, PIPE, DMA, MASK, D>;
 #if defined(FA_TRACE) && FA_TRACE == 3
 #define FA_TL() tl()
+#define FA_TLP(i) tl_stamp(i)
+#define FA_TLF() tl_flush()
 #define FA_VM8 "9"   // the stamp's store is one more vector-memory operation behind the pieces
 #define FA_VM16 "17"
 #define FA_VM24 "25"
 #define FA_VM32 "33"
 #else
 #define FA_TL() ((void)0)
+#define FA_TLP(i) ((void)0)
+#define FA_TLF() ((void)0)
 #define FA_VM8 "8"
 #define FA_VM16 "16"
 #define FA_VM24 "24"
@@ -140,6 +144,21 @@ fa_fwd_kernel64(const KernelArgs args) {
         ++tl_p;
     };
     tl();
+    unsigned tl_pro[6] = {};  // prologue stamps, kept in SGPRs and stored behind the prologue's last wait
+    auto tl_stamp = [&](int i) {
+        unsigned long long t_;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");
+        tl_pro[i] = __builtin_amdgcn_readfirstlane((unsigned)t_);
+    };
+    auto tl_flush = [&]() {
+        int l_;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l_));
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            if (l_ == 0) *tl_p = tl_pro[i];
+            ++tl_p;
+        }
+    };
 #endif
 
     // ---- workgroup -> (batch*head, Q block); XCD-aware when n_bh % 8 == 0 --------
@@ -205,15 +224,7 @@ fa_fwd_kernel64(const KernelArgs args) {
             glds16_sv(Kg + (int64_t)(n_kv - 1) * tile_stride, k_off[j], smem_base + (wave + NWAVES * j) * 1024);
     }
 
-    vec8 Qr[QT][KS];
-#pragma unroll
-    for (int qt = 0; qt < QT; ++qt) {
-        const int64_t row = (int64_t)qb * TR::kBr + wave * TR::kRowsPerWave + qt * 32 + r31;
-        const uint16_t *qp = Qg + row * ss + hi * 8;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks)  // straight into the accumulator file; waited for by hand below
-            asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=a"(Qr[qt][ks]) : "v"(qp), "i"(ks * 32) : "memory");
-    }
+    vec8 Qr[QT][KS];  // Q of the current item (AGPRs), filled through LDS (request_q / read_q below)
 
     // forward_kernel.cuh:150-151 (fp32 product of rsqrt(d) and log2 e)
     const float c = (float)((double)(1.0f / __builtin_sqrtf((float)D)) * 1.4426950408889634074);
@@ -392,22 +403,24 @@ fa_fwd_kernel64(const KernelArgs args) {
             asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l_));
             return l_;
         };
-        auto request_next_q = [&](int qt) {  // rows 32 qt .. 32 qt + 31 of this wave's rows of the next item
+        auto request_q = [&](const uint16_t *Qh, int qblk, int qt, unsigned stage) {  // rows 32 qt .. 32 qt + 31 of this wave's rows
             const int l_ = lane_now();
             // piece i: rows 4i .. 4i+3; this lane: row 4i + l/16, chunk (l % 16) ^ (row & 15)
             //   = ((l % 16) ^ (l / 16)) ^ 4 (i & 3): one lane offset, 64 (i & 3) XORed in per piece
             const unsigned off = (unsigned)(((int64_t)(l_ >> 4) * ss) * 2) + ((((unsigned)l_ & 15) ^ ((unsigned)l_ >> 4)) << 4);
-            const uint16_t *rows0 = Qn + ((int64_t)qb_n * TR::kBr + wave * TR::kRowsPerWave + 32 * qt) * ss;
+            const uint16_t *rows0 = Qh + ((int64_t)qblk * TR::kBr + wave * TR::kRowsPerWave + 32 * qt) * ss;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) glds16_sv_m0(rows0 + (int64_t)(4 * i) * ss, off ^ (64u * (i & 3)), q_stage + i * 1024);
+            for (int i = 0; i < 8; ++i) glds16_sv_m0(rows0 + (int64_t)(4 * i) * ss, off ^ (64u * (i & 3)), stage + i * 1024);
         };
-        auto read_next_q = [&](vec8 (&dst)[KS]) {  // this lane's chunks: row l % 32, chunk (2 ks + l/32) ^ (row & 15)
+        auto read_q = [&](vec8 (&dst)[KS], unsigned stage) {  // this lane's chunks: row l % 32, chunk (2 ks + l/32) ^ (row & 15)
             const int l_ = lane_now();
-            const unsigned base = q_stage + (l_ & 31) * 256, x = (unsigned)((l_ >> 5) ^ (l_ & 15));
+            const unsigned base = stage + (l_ & 31) * 256, x = (unsigned)((l_ >> 5) ^ (l_ & 15));
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks)
                 asm volatile("ds_read_b128 %0, %1" : "=a"(dst[ks]) : "v"(base + ((x ^ (2 * ks)) << 4)) : "memory");
         };
+        auto request_next_q = [&](int qt) { request_q(Qn, qb_n, qt, q_stage); };
+        auto read_next_q = [&](vec8 (&dst)[KS]) { read_q(dst, q_stage); };
         auto visit = [&](int it, auto &S_cur, auto &S_nxt, auto r_tag) {
             constexpr int R = decltype(r_tag)::value;  // it & 3
 #ifdef FA_TRACE
@@ -670,23 +683,26 @@ fa_fwd_kernel64(const KernelArgs args) {
             On = (uint16_t *)args.o + off_n;
         };
         set_next();
-        // Every CU starts at once and the first requests (176 KB per workgroup) return at ~11 B/cycle
-        // per CU, in issue order: K(0) and Q -- all S(0) needs -- were asked for first (common code);
-        // then K(1), V(0) | K(2), V(1) | K(3), V(2) in the order the counted waits assume.
+        // Every CU starts at once and the first requests return at ~11 B/cycle per CU, in issue order:
+        // K(0) (common code above) and Q -- all S(0) needs -- go first.  Q travels like the next item's Q
+        // does later (coalesced LDS-DMA pieces, then ds_read_b128 into the Q registers; fetched row-per-lane
+        // a wave-instruction touches 32 cache lines and the 16 of them took ~9 k cycles to issue): tile 0
+        // through this wave's staging area, tile 1 through its quarter of K stage 3 / V stage 3, which
+        // are idle until K(3) / V(2) are requested behind the barrier below.  Then K(1), V(0) here and
+        // K(2), V(1) | K(3), V(2) under S(0), in the order the counted waits assume.
+        FA_TLP(0);  // K(0) requested, next item known
+        request_q(Qg, qb, 0, q_stage);
+        request_q(Qg, qb, 1, smem_base + (wave < 2 ? 3 * TILE : V_BASE + 3 * TILE) + (wave & 1) * 8192);
         dma_k(tile_g(Kc, Kn, 1), 1);
         dma_v(tile_g(Vc, Vn, 0), 0);
-        dma_k(tile_g(Kc, Kn, 2), 2);
-        dma_v(tile_g(Vc, Vn, 1), 1);
-        dma_k(tile_g(Kc, Kn, 3), 3);
-        dma_v(tile_g(Vc, Vn, 2), 2);
-        kq = tile_g(Kc, Kn, 4);
-        vq = tile_g(Vc, Vn, 3);
-        if (has_next) request_next_q(0);
-        if (!(ABL & 8)) {  // K(0), Q landed: everything younger may fly
-            if (has_next) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-        }
-        barrier();
+        FA_TLP(1);  // Q, K(1), V(0) requested
+        if (!(ABL & 8)) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // K(0), Q landed: K(1), V(0) fly on
+        FA_TLP(2);  // K(0), Q landed
+        read_q(Qr[0], q_stage);
+        read_q(Qr[1], smem_base + (wave < 2 ? 3 * TILE : V_BASE + 3 * TILE) + (wave & 1) * 8192);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        barrier();  // K(0) is visible, and every wave has read its Q tile out of stages 3
+        FA_TLP(3);  // Q read, barrier passed
         {
             // S(0) and its row max, which becomes the first reference max (O = l = 0)
             const char *kt = smem;
@@ -698,6 +714,17 @@ fa_fwd_kernel64(const KernelArgs args) {
                 qk_mfma(Sa, step, 0, a_all[step]);
                 qk_mfma(Sa, step, 1, a_all[step]);
             });
+            // the rest of the first requests, issued while the matrix pipe works through S(0): a CU keeps
+            // only ~32 KB of requests in flight, so asking for all 176 KB up front held the waves at the
+            // issue of the last pieces (~11 k cycles) long after K(0) and Q had landed
+            dma_k(tile_g(Kc, Kn, 2), 2);
+            dma_v(tile_g(Vc, Vn, 1), 1);
+            dma_k(tile_g(Kc, Kn, 3), 3);
+            dma_v(tile_g(Vc, Vn, 2), 2);
+            kq = tile_g(Kc, Kn, 4);
+            vq = tile_g(Vc, Vn, 3);
+            if (has_next) request_next_q(0);
+            FA_TLP(4);  // S(0) MFMAs and the remaining requests issued
             asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // MFMA D -> VALU read
 #pragma unroll
             for (int step = 0; step < 16; ++step) asm volatile("" ::"v"(a_all[step]));
@@ -718,7 +745,9 @@ fa_fwd_kernel64(const KernelArgs args) {
                 if (has_next) asm volatile("s_waitcnt vmcnt(28)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
             }
+            FA_TLP(5);  // row max done, K(1) landed
             barrier();
+            FA_TLF();
             FA_TL();  // S(0) formed, K(1) landed
             ring[0] = k_frag(smem + TILE, 0);  // first operands of visit 0: K(1)
             ring[1] = k_frag(smem + TILE, 1);

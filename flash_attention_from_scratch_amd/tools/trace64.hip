@@ -59,8 +59,10 @@ int main(int argc, char **argv) {
         const int show[6] = {0, 1, 37, 128, 200, 255};
         for (int si = 0; si < 6; ++si) {
             const unsigned *r = t.data() + show[si] * 96;
-            printf("wg %3d: total %7u | prologue %5u |", show[si], r[cnt - 1] - r[0], r[1] - r[0]);
-            for (int i = 2; i < cnt; ++i) printf(" %u", r[i] - r[i - 1]);
+            // r[0] entry, r[1..6] prologue stamps, r[7] S(0) formed, r[8..] visit tops, r[cnt-1] exit
+            printf("wg %3d: total %7u | prologue %5u = K0 req %u | Q,K1,V0 req %u | landed %u | Q read+barrier %u | S0 issue+rest req %u | max+K1 wait %u | barrier %u |",
+                   show[si], r[cnt - 1] - r[0], r[7] - r[0], r[1] - r[0], r[2] - r[1], r[3] - r[2], r[4] - r[3], r[5] - r[4], r[6] - r[5], r[7] - r[6]);
+            for (int i = 8; i < cnt; ++i) printf(" %u", r[i] - r[i - 1]);
             printf("\n");
         }
         printf("mean  : total %7.0f |", [&] { double s_ = 0; for (int w = 0; w < grid; ++w) s_ += (double)(t[w * 96 + cnt - 1] - t[w * 96]); return s_ / grid; }());
