@@ -69,6 +69,22 @@ def lint(path, window=3, raw=2):
                     if regs(p.split()[1]) & rd:
                         findings.append(("RAW", kidx, i, l, p))
                 k += 1
+        # AGPR: a visit is 32 MFMAs into VGPRs (S) followed by 32 into AGPRs (O).  Behind its third MFMA
+        # (the rescale of O sits in front of it) no compiler-made accumulator copy may appear: hipcc has
+        # been seen hoisting the rescale path's 128 v_accvgpr_read to the end of the PREVIOUS visit,
+        # 16 behind every P.V MFMA, each waiting for that MFMA to retire (a trace build; +25 % per visit).
+        mf = [i for i, l in enumerate(code) if l.startswith("v_mfma")]
+        kinds = "".join("a" if code[i].split()[1].startswith("a[") else "v" for i in mf)
+        pos = 0
+        while True:
+            j = kinds.find("v" * 32 + "a" * 32, pos)
+            if j < 0:
+                break
+            for i in range(mf[j + 2], mf[j + 63] + 1):
+                if code[i].startswith("v_accvgpr_"):
+                    findings.append(("AGPR", kidx, i, code[mf[j + 63]], code[i]))
+                    break
+            pos = j + 64
     return findings
 
 

@@ -1,6 +1,14 @@
 // trace64.hip -- s_memtime stamps inside ONE visit of the 64-rows-per-wave schedule (debug build
 // with -DFA_TRACE; the shipped library carries no trace code).  Stamps: visit top, after the
 // barrier, then every 4 MFMA gaps (ideal: 4 x 32 = 128 cycles apiece), visit end.
+//
+// Caveats (check a trace build with tools/isa_lint64.py before believing it): the stamps change the
+// code hipcc generates.  Modes 1 and 2 have been seen with the rescale path's 128 v_accvgpr_read
+// hoisted behind the P.V MFMAs of two of the four visit variants (lint finding AGPR; those visits' last
+// eight gaps then read 2-3x too long); mode 3's per-visit stamp (s_memtime + lgkmcnt(0) + a store)
+// costs ~0.8 k cycles per visit, so its visit times are ~25 % above the product kernel's
+// (PMC: SQ_VALU_MFMA_BUSY_CYCLES / SQ_WAVE_CYCLES = 71 %, ~2.75 k cycles per visit) -- use it for the
+// prologue and the seams, which it does not disturb.
 #ifndef FA_TRACE
 #define FA_TRACE 1
 #endif
