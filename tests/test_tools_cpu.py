@@ -124,6 +124,23 @@ def test_isa_lint_flags_operand_war_and_raw(tmp_path):
     assert kinds == ["RAW", "WAR", "WAR"]
 
 
+def test_isa_lint_flags_accumulator_copies_inside_a_visit(tmp_path):
+    """A visit is 32 MFMAs into VGPRs then 32 into AGPRs; a v_accvgpr_* behind its third MFMA is the
+    compiler moving accumulators around inside the pinned stream (seen in a trace build), and an
+    `s_nop n` between a producer and the MFMA counts as n + 1 issue slots."""
+    visit = ["v_mfma_f32_32x32x16_bf16 v[0:15], v[100:103], a[128:131], v[0:15]"] * 32
+    visit += ["v_mfma_f32_32x32x16_bf16 a[0:15], v[100:103], v[104:107], a[0:15]"] * 32
+    clean = tmp_path / "clean.s"
+    clean.write_text("\n".join(["v_mov_b32_e32 v100, 0", "s_nop 3"] + visit + ["s_endpgm"]) + "\n")
+    assert isa_lint64.lint(str(clean), window=3, raw=3) == []
+    close = tmp_path / "close.s"
+    close.write_text("\n".join(["v_mov_b32_e32 v100, 0", "s_nop 0"] + visit + ["s_endpgm"]) + "\n")
+    assert [k for k, *_ in isa_lint64.lint(str(close), window=3, raw=3)] == ["RAW"]
+    bad = tmp_path / "bad.s"
+    bad.write_text("\n".join(visit[:40] + ["v_accvgpr_read_b32 v200, a3"] + visit[40:] + ["s_endpgm"]) + "\n")
+    assert [k for k, *_ in isa_lint64.lint(str(bad), window=3, raw=3)] == ["AGPR"]
+
+
 def test_isa_lint_on_the_built_64_row_kernels(tmp_path):
     """Compile the two hand-placed kernels to ISA (as the library build does) and require that no
     instruction near an inline-asm MFMA touches its operand registers: hipcc cannot see these
