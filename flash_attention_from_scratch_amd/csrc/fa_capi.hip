@@ -117,6 +117,9 @@ void do_init() {
             hipError_t rc = hipFuncSetAttribute((const void *)e.fn,
                                                 hipFuncAttributeMaxDynamicSharedMemorySize,
                                                 e.lds_bytes);
+            if (rc == hipSuccess && e.fn_ragged)
+                rc = hipFuncSetAttribute((const void *)e.fn_ragged, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         e.lds_bytes);
             if (rc != hipSuccess) {
                 g_init_status = FA_ERR_LAUNCH;
                 snprintf(g_init_err, sizeof(g_init_err), "hipFuncSetAttribute(%d B LDS): %s",
@@ -141,9 +144,11 @@ int validate(const fa_fwd_args *a, const fa::KernelEntry **out, bool masked = fa
                     (long long)a->d_head, a->cfg.d_head);
     if (a->batch <= 0 || a->seq_len <= 0 || a->n_heads <= 0)
         return fail(FA_ERR_SHAPE, "batch, seq_len and n_heads must be positive");
-    if (masked && e->masked == 2 && (a->seq_len % a->cfg.B_r != 0 || a->seq_len % a->cfg.B_c != 0))
-        return fail(FA_ERR_SHAPE, "the masked variant of this configuration handles the causal mask only: "
-                                  "seq_len must be a multiple of B_r and B_c");
+    // masked == 2 (persistent kernel): a causal-only form for seq_len % B_r == 0 and a second form for every
+    // other seq_len >= B_c, which fetches a tile that would reach beyond the sequence as its last B_c keys
+    if (masked && e->masked == 2 && a->seq_len % a->cfg.B_r != 0 && (a->seq_len < a->cfg.B_c || !e->fn_ragged))
+        return fail(FA_ERR_SHAPE, "the masked variant of this configuration needs seq_len >= B_c (%d) when "
+                                  "seq_len is not a multiple of B_r", a->cfg.B_c);
     if (!masked && a->seq_len % a->cfg.B_r != 0)
         return fail(FA_ERR_SHAPE, "Only multiples of B_r are supported for seq_len Q currently");
     if (!masked && a->seq_len % a->cfg.B_c != 0)
@@ -175,6 +180,11 @@ int launch(const fa_fwd_args *a, const fa::KernelEntry *e, hipStream_t stream, i
     ka.n_q_blocks = (int32_t)((a->seq_len + a->cfg.B_r - 1) / a->cfg.B_r);   // exact unless masked
     ka.n_kv_blocks = (int32_t)((a->seq_len + a->cfg.B_c - 1) / a->cfg.B_c);
     ka.causal = causal;
+    fa::kernel_fn fn = e->fn;
+    if (e->masked == 2 && a->seq_len % a->cfg.B_r != 0) {  // ragged form: whole ring rounds of K / V tiles
+        fn = e->fn_ragged;
+        ka.n_kv_blocks = ka.n_q_blocks * (a->cfg.B_r / a->cfg.B_c);
+    }
     // 1-D grid over (batch*head, Q block); the kernel un-maps it XCD-aware.
     // (reference: dim3(n_Q_blocks, n_heads, batch), flash_attention.cu:110-112)
     // Persistent variants: one workgroup per CU (a multiple of 8, so an item keeps its XCD) that
@@ -187,7 +197,7 @@ int launch(const fa_fwd_args *a, const fa::KernelEntry *e, hipStream_t stream, i
     const dim3 grid(n_wg);
     const dim3 block((unsigned)e->threads);
     void *params[] = {&ka};
-    hipError_t rc = hipLaunchKernel((const void *)e->fn, grid, block, params, (size_t)e->lds_bytes, stream);
+    hipError_t rc = hipLaunchKernel((const void *)fn, grid, block, params, (size_t)e->lds_bytes, stream);
     if (rc != hipSuccess) return fail(FA_ERR_LAUNCH, "hipLaunchKernel: %s", hipGetErrorString(rc));
     return FA_OK;
 }

@@ -270,7 +270,7 @@ template <int DT, int NWAVES, int BC, bool SWZ, bool EAGER, bool OPT>
 constexpr KernelEntry make_entry16() {
     using TR = FwdTraits16<DT, NWAVES, BC, SWZ, EAGER, OPT>;
     return KernelEntry{DT, 16, NWAVES, BC, SWZ, EAGER, OPT, 0, 1, 0, 128, TR::kThreads, TR::kLdsBytes, 0,
-                       (kernel_fn)&fa_fwd_kernel16<DT, NWAVES, BC, SWZ, EAGER, OPT>};
+                       (kernel_fn)&fa_fwd_kernel16<DT, NWAVES, BC, SWZ, EAGER, OPT>, nullptr};
 }
 
 }  // namespace fa

@@ -80,10 +80,17 @@ constexpr bool plan64_ok(const Plan64 &p) {
 }
 
 // (optimized_softmax selects nothing here: the first tile of an item never rescales, by construction)
-template <int DT, bool MASK = false, int ABL = 0>
+// RAG (a second MASK variant): any seq_len >= 64.  The host rounds the Q blocks up and passes
+// n_kv_blocks = 4 n_q_blocks (the ring arithmetic wants a multiple of four tiles); a tile that would reach
+// beyond the sequence is fetched as the window of its last 64 keys instead (always inside the tensor, no
+// per-lane clamp in the request path) and the keys in front of the tile's own first key are masked, which
+// masks a tile that lies beyond the sequence whole; Q rows beyond the sequence are fetched from its last
+// row and not stored.
+template <int DT, bool MASK = false, int ABL = 0, bool RAG = false>
 __global__ void
 __launch_bounds__(256, 1)
 fa_fwd_kernel64(const KernelArgs args) {
+    static_assert(!RAG || MASK, "the ragged form is a masked variant");
     constexpr int QT = 2, NWAVES = 4, BC = 64, D = 128;
     constexpr bool SWZ = true, EAGER = true, PIPE = true, DMA = true;
 
@@ -215,13 +222,21 @@ fa_fwd_kernel64(const KernelArgs args) {
         v_off[j] = (unsigned)(((8 * (sub / DSUB) + v_lane_row) * ss + (sub % DSUB) * 32 + v_lane_d) * 2);
     }
     const int64_t tile_stride = (int64_t)BC * ss;  // elements between consecutive KV blocks
+    auto tile_at = [&](const uint16_t *head, int t) {  // first row of tile t of a head's K or V
+        if constexpr (RAG) {
+            const int r0 = 64 * t < args.seq_len - 64 ? 64 * t : args.seq_len - 64;  // (see the note at the top)
+            return head + (int64_t)r0 * ss;
+        } else {
+            return head + (int64_t)t * tile_stride;
+        }
+    };
     auto dma_wait = [&]() { if (DMA && !(ABL & 8)) dma_wait_all(); };
     auto barrier = [&]() { if (!(ABL & 8)) wg_barrier(); };
     // ---- first requests of the walk: K(0), then Q (all S(0) needs); the rest follows in the prologue
     if (!(ABL & 16)) {
 #pragma unroll
         for (int j = 0; j < DMA_PER_WAVE; ++j)
-            glds16_sv(Kg + (int64_t)(n_kv - 1) * tile_stride, k_off[j], smem_base + (wave + NWAVES * j) * 1024);
+            glds16_sv(tile_at(Kg, n_kv - 1), k_off[j], smem_base + (wave + NWAVES * j) * 1024);
     }
 
     vec8 Qr[QT][KS];  // Q of the current item (AGPRs), filled through LDS (request_q / read_q below)
@@ -350,14 +365,38 @@ fa_fwd_kernel64(const KernelArgs args) {
         const bool causal = MASK && args.causal;
         int nkc = n_kv, nkn = n_kv;  // tiles of the current / next item
         auto tile_g = [&](const uint16_t *cur, const uint16_t *nxt, int j) {
-            return j < nkc ? cur + (int64_t)(nkc - 1 - j) * tile_stride
-                           : nxt + (int64_t)(nkn - 1 - (j - nkc)) * tile_stride;
+            return j < nkc ? tile_at(cur, nkc - 1 - j) : tile_at(nxt, nkn - 1 - (j - nkc));
         };
         // MASK: logits above the causal diagonal become -inf.  `tile` counts from the start of the
         // sequence, `qb_rows` is the Q block whose rows the S tile belongs to.  A wave's 64 rows meet
         // the diagonal in exactly one 64-key tile; tiles beyond it are masked whole.
         auto mask_tile = [&](auto &S, int tile, int qb_rows) {
-            if constexpr (MASK) {
+            if constexpr (RAG) {
+                const int r0 = 64 * tile < args.seq_len - 64 ? 64 * tile : args.seq_len - 64;  // first key of the window
+                const int delta = 64 * tile - r0;  // keys of the window in front of the tile's own first key
+                if (delta > 0) {  // wave-uniform: the last tiles of a sequence only
+                    const int lim = delta - 4 * hi;
+#pragma unroll
+                    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r)
+                                S[qt][nt][r] = (32 * nt + (r & 3) + 8 * (r >> 2) < lim) ? -__builtin_inff() : S[qt][nt][r];
+                }
+                const int row_min = 256 * qb_rows + 64 * wave;  // this wave's first row
+                if (causal && r0 + 63 > row_min) {  // wave-uniform: some key of the window lies above some row's diagonal
+#pragma unroll
+                    for (int qt = 0; qt < 2; ++qt) {
+                        const int lim = row_min + 32 * qt + r31 - r0 - 4 * hi;  // key-in-window > lim: above the diagonal
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r)
+                                S[qt][nt][r] = (32 * nt + (r & 3) + 8 * (r >> 2) > lim) ? -__builtin_inff() : S[qt][nt][r];
+                    }
+                }
+            } else if constexpr (MASK) {
                 const int d = tile - (4 * qb_rows + wave);
                 if (causal && d >= 0) {  // wave-uniform
 #pragma unroll
@@ -408,6 +447,19 @@ fa_fwd_kernel64(const KernelArgs args) {
             // piece i: rows 4i .. 4i+3; this lane: row 4i + l/16, chunk (l % 16) ^ (row & 15)
             //   = ((l % 16) ^ (l / 16)) ^ 4 (i & 3): one lane offset, 64 (i & 3) XORed in per piece
             const unsigned off = (unsigned)(((int64_t)(l_ >> 4) * ss) * 2) + ((((unsigned)l_ & 15) ^ ((unsigned)l_ >> 4)) << 4);
+            if constexpr (RAG) {
+                const int row_b = qblk * TR::kBr + wave * TR::kRowsPerWave + 32 * qt;
+                if (row_b + 31 >= args.seq_len) {  // wave-uniform: rows beyond the sequence are fetched from its last row
+                    const unsigned chunk_b = (((unsigned)l_ & 15) ^ ((unsigned)l_ >> 4)) << 4;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        int rg = row_b + 4 * i + (l_ >> 4);
+                        rg = rg < args.seq_len - 1 ? rg : args.seq_len - 1;
+                        glds16_sv_m0(Qh, (unsigned)rg * (unsigned)(ss * 2) + (chunk_b ^ (64u * (i & 3))), stage + i * 1024);
+                    }
+                    return;
+                }
+            }
             const uint16_t *rows0 = Qh + ((int64_t)qblk * TR::kBr + wave * TR::kRowsPerWave + 32 * qt) * ss;
 #pragma unroll
             for (int i = 0; i < 8; ++i) glds16_sv_m0(rows0 + (int64_t)(4 * i) * ss, off ^ (64u * (i & 3)), stage + i * 1024);
@@ -494,9 +546,17 @@ fa_fwd_kernel64(const KernelArgs args) {
                     rs[qt][0] *= alpha;
                     rs[qt][1] *= alpha;
 #pragma unroll
-                    for (int t = 0; t < DTILES; ++t)
+                    for (int t = 0; t < DTILES; ++t) {
+                        // RAG: the accumulator copies start here, behind the pads above, and end behind the
+                        // multiply: in that variant (and in trace builds) hipcc otherwise hoists the reads out of
+                        // this branch to the end of the previous visit, right behind the MFMAs that write the
+                        // tiles (tools/isa_lint64.py, finding AGPR).  The other variants do not need the pins
+                        // (the lint checks that) and measure 0.3 % faster without them, at 65 more VGPRs.
+                        if constexpr (RAG) asm volatile("" : "+a"(O[qt][t]));
 #pragma unroll
                         for (int r = 0; r < 16; ++r) O[qt][t][r] *= alpha;
+                        if constexpr (RAG) asm volatile("" : "+a"(O[qt][t]));
+                    }
                 }
             }
             const char *kt = smem + ((R + 1) & 3) * TILE;
@@ -561,8 +621,13 @@ fa_fwd_kernel64(const KernelArgs args) {
                 }
                 if (k == 8) {
                     resc_any = any01;
-                    kq = (it + 5 == nkc) ? Kn + (int64_t)(nkn - 1) * tile_stride : kq - tile_stride;
-                    vq = (it + 4 == nkc) ? Vn + (int64_t)(nkn - 1) * tile_stride : vq - tile_stride;
+                    if constexpr (RAG) {  // (a window per tile: no pointer chain)
+                        kq = tile_g(Kc, Kn, it + 5);
+                        vq = tile_g(Vc, Vn, it + 4);
+                    } else {
+                        kq = (it + 5 == nkc) ? Kn + (int64_t)(nkn - 1) * tile_stride : kq - tile_stride;
+                        vq = (it + 4 == nkc) ? Vn + (int64_t)(nkn - 1) * tile_stride : vq - tile_stride;
+                    }
                     if constexpr (R == 1) seam = false;
                 }
             };
@@ -804,6 +869,9 @@ fa_fwd_kernel64(const KernelArgs args) {
                     // non-temporal: O is written once and not read again by this kernel (+1.3...2.8 % at
                     // seq_len <= 1024, where the store-issue-bound epilogue is a visible share).
                     // asm: scalar row base + 32-bit lane offset (hipcc builds a 64-bit address per lane and store)
+                    if constexpr (RAG) {  // rows beyond the sequence are not stored
+                        if (qb_c * TR::kBr + wave * TR::kRowsPerWave + qt * 32 + RPP * i + rsub >= args.seq_len) continue;
+                    }
                     asm volatile("global_store_dwordx4 %0, %1, %2 nt" ::"v"(lane_off), "v"(v[i]), "s"(rows0 + (int64_t)(RPP * i) * ss));
                 }
             }

@@ -22,12 +22,13 @@ struct KernelEntry {
     int opt_softmax;
     int pipelined;      // cfg.mma_double_buffer_loads
     int async_copy;     // 1: LDS-DMA transport, 0: register-staged
-    int masked;         // 1: handles ragged seq_len and the causal mask; 2: causal mask only (seq_len % B_r == 0)
+    int masked;         // 1: handles ragged seq_len and the causal mask; 2: the same through two device forms (fn, fn_ragged)
     int d_head;         // 128 (reference scope) or 64
     int threads;
     int lds_bytes;
     int persistent;     // 1: launch one workgroup per CU; the kernel walks the items itself
     kernel_fn fn;
+    kernel_fn fn_ragged;  // masked == 2 only: the form for seq_len % B_r != 0 (any seq_len >= 64); else null
 };
 
 template <int DT, int QT, int NWAVES, int BC, bool SWZ, bool EAGER, bool OPT, bool PIPE, bool DMA,
@@ -36,12 +37,16 @@ constexpr KernelEntry make_entry() {
     using TR = FwdTraits<DT, QT, NWAVES, BC, SWZ, EAGER, OPT, PIPE, DMA, MASK, D>;
     if constexpr (TR::kPersistent) {  // (B_r 256, B_c 64, 4 waves) + buffer: fa_fwd_kernel64.hpp
         static_assert(NWAVES == 4 && BC == 64 && SWZ && EAGER && DMA && D == 128, "64-row pinned schedule");
-        return KernelEntry{DT, 64, 4, 64, 1, 1, OPT, 1, 1, MASK ? 2 : 0, 128, TR::kThreads, TR::kLdsBytes, 1,
-                           (kernel_fn)&fa_fwd_kernel64<DT, MASK>};
+        if constexpr (MASK)
+            return KernelEntry{DT, 64, 4, 64, 1, 1, OPT, 1, 1, 2, 128, TR::kThreads, TR::kLdsBytes, 1,
+                               (kernel_fn)&fa_fwd_kernel64<DT, true>, (kernel_fn)&fa_fwd_kernel64<DT, true, 0, true>};
+        else
+            return KernelEntry{DT, 64, 4, 64, 1, 1, OPT, 1, 1, 0, 128, TR::kThreads, TR::kLdsBytes, 1,
+                               (kernel_fn)&fa_fwd_kernel64<DT, false>, nullptr};
     } else {
         return KernelEntry{DT, 32 * QT, NWAVES, BC, SWZ, EAGER, OPT, PIPE, DMA, MASK ? 1 : 0, D, TR::kThreads,
                            TR::kLdsBytes, 0,
-                           (kernel_fn)&fa_fwd_kernel<DT, QT, NWAVES, BC, SWZ, EAGER, OPT, PIPE, DMA, MASK, D>};
+                           (kernel_fn)&fa_fwd_kernel<DT, QT, NWAVES, BC, SWZ, EAGER, OPT, PIPE, DMA, MASK, D>, nullptr};
     }
 }
 

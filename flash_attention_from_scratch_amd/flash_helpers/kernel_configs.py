@@ -471,14 +471,12 @@ def best_config(dtype=DType.BF16, seq_len=4096, masked=False) -> FlashForwardKer
     feeds two MFMAs; one workgroup per CU walks the (batch*head, Q block) items) whenever seq_len is a
     multiple of its 256-row Q block; otherwise the pipelined 4-wave x 32-row kernel.
     masked=True: the best config that has a causal / ragged-length variant (forward_ex): the same
-    persistent kernel when seq_len is a multiple of 256 (its masked form does the causal mask only),
-    otherwise 8 waves x 32 rows with 128-key tiles from seq_len 4096 up, else 4 waves x 32 rows."""
-    if masked and seq_len % 256 != 0:
-        if seq_len >= 4096:
-            return FlashForwardKernelConfig(
-                DType(dtype), 128, 256, 128, 8, True, True, True, 0, 0, 0, False, True
-            )
-    elif seq_len % 256 == 0:
+    persistent kernel when seq_len is a multiple of 256 (causal form) or when rounding seq_len up to
+    one costs at most an eighth more rows (its ragged form works on whole 256-row Q blocks and whole
+    rounds of four 64-key tiles; measured ahead of the 32-rows-per-wave kernels from seq_len ~1000 up,
+    profiles/r01/ragged_persistent.txt), otherwise 4 waves x 32 rows."""
+    pad = (-seq_len) % 256
+    if pad == 0 or (masked and seq_len >= 64 and pad * 8 <= seq_len):
         return FlashForwardKernelConfig(
             DType(dtype), 128, 256, 64, 4, True, True, True, 0, 0, 0, True, False
         )

@@ -22,10 +22,11 @@ FIELDS = {"VGPRs": "vgprs", "AGPRs": "agprs", "SGPRs": "sgprs", "ScratchSize [by
 def demangle_variant(name):
     """_ZN2fa13fa_fwd_kernelILi15ELi1ELi8ELi64ELb1ELb1ELb0ELb1ELi0EEE... -> dict"""
     nums = re.findall(r"L[ib](\d+)E", name)
-    if "fa_fwd_kernel64" in name and len(nums) >= 2:  # <DT, MASK, ABL>; serves both optimized_softmax values
+    if "fa_fwd_kernel64" in name and len(nums) >= 2:  # <DT, MASK, ABL, RAG>; serves both optimized_softmax values
         dt, masked = map(int, nums[:2])
+        rag = int(nums[3]) if len(nums) >= 4 else 0  # masked: 2 = causal form, 3 = ragged form of the same entry
         return dict(dtype=dt, rows_per_wave=64, n_waves=4, B_c=64, swizzled=1, eager=1, opt_softmax=0,
-                    pipelined=1, dma=1, masked=2 * masked, d_head=128)
+                    pipelined=1, dma=1, masked=2 * masked + rag, d_head=128)
     if "fa_fwd_kernel16" in name and len(nums) >= 6:
         dt, nw, bc, swz, eager, opt = map(int, nums[:6])
         return dict(dtype=dt, rows_per_wave=16, n_waves=nw, B_c=bc, swizzled=swz, eager=eager,

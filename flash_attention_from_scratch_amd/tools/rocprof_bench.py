@@ -48,7 +48,7 @@ def symbol_to_config(symbol):
         return None
     vals = [{"true": 1, "false": 0}.get(t.strip(), t.strip()) for t in m.group(2).split(",")]
     vals = [int(v) for v in vals]
-    if m.group(1) == "64":  # fa_fwd_kernel64<DT, MASK, ABL>: the persistent (256, 64, 4) + buffer kernel
+    if m.group(1) == "64":  # fa_fwd_kernel64<DT, MASK, ABL, RAG>: the persistent (256, 64, 4) + buffer kernel
         return FlashForwardKernelConfig(DType(vals[0]), 128, 256, 64, 4, True, True, True, 0, 0, 0, True, False)
     if m.group(1):
         dt, nw, bc, swz, eager, opt = vals[:6]

@@ -99,7 +99,8 @@ typedef struct fa_kernel_info {
     int32_t num_regs;        /* VGPR+AGPR per lane (hipFuncAttributes.numRegs) */
     int32_t scratch_bytes;   /* per-thread scratch; 0 = no spills */
     int32_t rows_per_wave;   /* Q rows owned by one wavefront */
-    int32_t masked;          /* 1: the causal / ragged-length variant of cfg */
+    int32_t masked;          /* 1: the causal / ragged-length variant of cfg; 2: the same for the persistent
+                                (256, 64, 4) kernel, which needs seq_len >= B_c when seq_len % B_r != 0 */
 } fa_kernel_info;
 
 /* One-time setup for the current device (idempotent; also called lazily). */

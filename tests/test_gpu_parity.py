@@ -315,9 +315,10 @@ def test_masked_variants_against_eager_sdpa_and_oracle(S, causal):
         for cfg in MASKED:
             if cfg.dtype.to_torch_dtype() != dtype:
                 continue
-            if kc.uses_lazy_rescale(cfg) and S % cfg.B_r:
-                # the persistent kernel's masked form does the causal mask only (fa_kernel_info.masked == 2)
-                with pytest.raises(RuntimeError, match="causal mask only"):
+            if kc.uses_lazy_rescale(cfg) and S % cfg.B_r and S < cfg.B_c:
+                # the persistent kernel's ragged form fetches a tile that would reach beyond the sequence as
+                # the window of its last B_c keys: it needs that many (fa_kernel_info.masked == 2)
+                with pytest.raises(RuntimeError, match="needs seq_len >= B_c"):
                     flash_attention.forward_ex(cfg, q, k, v, causal=causal)
                 continue
             out = flash_attention.forward_ex(cfg, q, k, v, causal=causal)
@@ -362,6 +363,49 @@ def test_persistent_walk_causal(shape):
             qs, ks, vs = (t[b:b + 1, :, h:h + 1].contiguous() for t in (q, k, v))
             eager = fo.eager_attention_masked(qs, ks, vs, True)
             assert _rel_ok(runs[0][b:b + 1, :, h:h + 1], eager, dtype), (str(cfg), shape)
+
+
+@pytest.mark.parametrize("S", [64, 65, 127, 255, 257, 300, 511, 1000, 1025, 2500, 4000, 8191])
+def test_persistent_ragged_lengths(S):
+    """Any seq_len >= 64 on the persistent kernel (second masked form): Q blocks rounded up, whole ring
+    rounds of K / V tiles, a tile that would reach beyond the sequence fetched as the window of its last
+    64 keys with the keys in front of the tile's own first key masked, Q rows beyond the sequence fetched
+    from the last row and not stored.  Full and causal, both dtypes: against the 32-rows-per-wave masked
+    kernel, fp32 eager on two heads, bitwise repeatable, and nothing written outside the S rows (O is a
+    window of a larger buffer whose guard rows must keep their fill)."""
+    import ctypes
+    lib = _capi.load()
+    B, H = (3, 5) if S < 2048 else (2, 3)
+    for dtype, name in ((torch.bfloat16, kc.DType.BF16), (torch.float16, kc.DType.FP16)):
+        cfg = kc.FlashForwardKernelConfig(name, 128, 256, 64, 4, True, True, True, 0, 0, 0, True, False)
+        other = kc.FlashForwardKernelConfig(name, 128, 128, 64, 4, True, True, True, 0, 0, 0, True, False)
+        gen = torch.Generator(device=DEV).manual_seed(S)
+        # q, k, v, o: the first S rows of (B, S + 8, H, 128) buffers (through the C ABI: the shim wants contiguous)
+        big = [torch.randn((B, S + 8, H, 128), dtype=dtype, device=DEV, generator=gen) for _ in range(3)]
+        q, k, v = (t[:, :S] for t in big)
+        qc, kc_, vc = (t.contiguous() for t in (q, k, v))
+        for causal in (False, True):
+            runs = []
+            for _ in range(3):
+                guard = torch.full((B, S + 8, H, 128), 7.0, dtype=dtype, device=DEV)
+                o = guard[:, :S]
+                args = _capi.FaFwdArgs(q=q.data_ptr(), k=k.data_ptr(), v=v.data_ptr(), o=o.data_ptr(), batch=B,
+                                       seq_len=S, n_heads=H, d_head=128, batch_stride=q.stride(0),
+                                       seq_stride=q.stride(1), head_stride=q.stride(2), cfg=_capi.make_config(cfg))
+                _capi.check(lib.fa_fwd_launch_masked(ctypes.byref(args), int(causal),
+                                                     ctypes.c_void_p(torch.cuda.current_stream().cuda_stream), None))
+                torch.cuda.synchronize()
+                assert bool((guard[:, S:] == 7.0).all()), (S, causal, "rows beyond seq_len were written")
+                runs.append(o.contiguous())
+            assert torch.isfinite(runs[0].float()).all(), (S, causal)
+            assert all(torch.equal(runs[0], r) for r in runs[1:]), (str(cfg), S, causal)
+            assert torch.equal(runs[0], flash_attention.forward_ex(cfg, qc, kc_, vc, causal=causal))
+            ref = flash_attention.forward_ex(other, qc, kc_, vc, causal=causal)
+            assert _rel_ok(runs[0], ref, dtype) or (runs[0].float() - ref.float()).abs().max().item() <= 2 * TOL[dtype]
+            for b, h in ((0, 0), (B - 1, H - 1)):
+                qs, ks, vs = (t[b:b + 1, :, h:h + 1].contiguous() for t in (qc, kc_, vc))
+                eager = fo.eager_attention_masked(qs, ks, vs, causal)
+                assert _rel_ok(runs[0][b:b + 1, :, h:h + 1], eager, dtype), (str(cfg), S, causal, b, h)
 
 
 def test_persistent_walk_random_shapes():

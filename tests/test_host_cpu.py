@@ -194,8 +194,8 @@ def test_config_name_round_trips_property():
 
 def test_best_config_selection_rules():
     """The default: the persistent 64-rows-per-wave kernel whenever seq_len is a multiple of its
-    256-row Q block (also for forward_ex: its masked form does the causal mask), otherwise the
-    32-rows-per-wave kernels, whose masked forms take any length."""
+    256-row Q block; for forward_ex also when rounding seq_len up to one costs at most an eighth more
+    rows (its ragged form); otherwise the 32-rows-per-wave kernel, whose masked form takes any length."""
     persistent = dict(B_r=256, B_c=64, n_warps=4, mma_double_buffer_loads=True)
     for dtype in (kc.DType.BF16, kc.DType.FP16):
         for S in (256, 512, 4096, 16384, 32768):
@@ -204,7 +204,10 @@ def test_best_config_selection_rules():
                 assert kc.uses_lazy_rescale(cfg) and cfg.dtype == dtype
                 assert all(getattr(cfg, k) == v for k, v in persistent.items())
                 assert _capi.supported(cfg) and _capi.masked_supported(cfg)
-        for S in (100, 320, 1000, 4000):
-            assert not kc.uses_lazy_rescale(kc.best_config(dtype, S, masked=True))
-            assert _capi.masked_supported(kc.best_config(dtype, S, masked=True))
-        assert (kc.best_config(dtype, 5000, masked=True).B_r, kc.best_config(dtype, 5000, masked=True).B_c) == (256, 128)
+        for S in (1000, 2500, 4000, 5000, 8191):
+            assert kc.uses_lazy_rescale(kc.best_config(dtype, S, masked=True))
+            assert not kc.uses_lazy_rescale(kc.best_config(dtype, S))
+        for S in (1, 63, 100, 320, 769, 1100):
+            cfg = kc.best_config(dtype, S, masked=True)
+            assert not kc.uses_lazy_rescale(cfg) and (cfg.B_r, cfg.B_c, cfg.n_warps) == (128, 64, 4)
+            assert _capi.masked_supported(cfg)
