@@ -21,6 +21,9 @@ struct Plan64 {
 };
 // variant bits (tools/tune64.hip): 1 barrier at the visit top instead of inside the MFMA stream,
 // 2 DMA pieces late in phase 2 instead of early in phase 1
+#ifndef FA_RING_SLOTS
+#define FA_RING_SLOTS 4
+#endif
 constexpr Plan64 make_plan64(int variant, int n_phase1) {
     Plan64 p{};
     const bool bar_top = variant & 1, dma_late = variant & 2, masked = variant & 4;
@@ -422,7 +425,13 @@ fa_fwd_kernel64(const KernelArgs args) {
                 glds16_sv_m0(src, v_off[j], smem_base + V_BASE + stage * TILE + (wave + NWAVES * j) * 1024);
         };
         const uint16_t *kq = nullptr, *vq = nullptr;  // next K / V tile to request (set per item below)
-        vec8 ring[4];  // operand ring: slot u % 4, rewritten two steps after the MFMAs that read it
+        // operand ring: slot u % RS holds operand u; the loads of operands step + LA, step + LA + 1 are issued
+        // at (even) step `step`, into the slots of the two operands whose MFMAs have just issued.  RS = 4:
+        // two steps (4 MFMAs, ~170 cycles) between a load and its use -- less than the LDS latency with four
+        // waves reading operands and the DMA writing: tools/trace64.hip (-DFA_TRACE=2) shows the wait in front
+        // of every fourth MFMA stall 25-50 cycles.  RS = 8: six steps.
+        constexpr int RS = FA_RING_SLOTS, LA = RS - 2;
+        vec8 ring[RS];
         vec8 Qr2[2][KS];  // the next item's Q (AGPRs), requested during the item's first visit
         float mraw[2];   // row max of the S tile formed by the last visit (the next item's S(0))
         bool seam = false;  // the first two visits after a seam: the epilogue's stores are in flight
@@ -552,10 +561,10 @@ fa_fwd_kernel64(const KernelArgs args) {
                         // this branch to the end of the previous visit, right behind the MFMAs that write the
                         // tiles (tools/isa_lint64.py, finding AGPR).  The other variants do not need the pins
                         // (the lint checks that) and measure 0.3 % faster without them, at 65 more VGPRs.
-                        if constexpr (RAG) asm volatile("" : "+a"(O[qt][t]));
+                        if constexpr (RAG || FA_RING_SLOTS > 4) asm volatile("" : "+a"(O[qt][t]));
 #pragma unroll
                         for (int r = 0; r < 16; ++r) O[qt][t][r] *= alpha;
-                        if constexpr (RAG) asm volatile("" : "+a"(O[qt][t]));
+                        if constexpr (RAG || FA_RING_SLOTS > 4) asm volatile("" : "+a"(O[qt][t]));
                     }
                 }
             }
@@ -639,7 +648,7 @@ fa_fwd_kernel64(const KernelArgs args) {
                 if (k == 13) { tail_unit(6); tail_unit(7); }
                 if (k == 14) tail_unit(8);
             };
-            // operand u of the visit: 16 K fragments, 16 V fragments, then the first two K fragments
+            // operand u of the visit: 16 K fragments, 16 V fragments, then the first LA K fragments
             // of the NEXT visit (its tile was published by this visit's barrier), so that no LDS
             // latency is exposed at the visit seam
             const char *kt_next = smem + ((R + 2) & 3) * TILE;
@@ -656,20 +665,27 @@ fa_fwd_kernel64(const KernelArgs args) {
                 // MFMA in front of it; one-ulp run-to-run differences that an s_nop 7 behind every MFMA
                 // removed).  So every operand is kept alive until the NEXT MFMA has issued: an empty asm
                 // that names it, placed behind that MFMA (volatile asm statements keep their order).
-                vec8 prev_a = ring[(step + 3) % 4];  // A operand of the previous step (its slot is reloaded below)
+                vec8 prev_a = ring[(step + RS - 1) % RS];  // A operand of the previous step (its slot is reloaded below)
                 if constexpr (qt == 0 && (step & 1) == 0) {  // operands in pairs: one counted wait per two steps
-                    __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0): operands step, step+1 landed
+                    // operands step, step + 1 landed; the LDS reads of operands step + 2 ... step + LA - 1 (one per
+                    // K fragment, two per V fragment; LDS returns in order) may still fly
+                    constexpr int fly = [] { int n = 0; for (int u = step + 2; u < step + LA; ++u) n += (u >= 16 && u < 32) ? 2 : 1; return n; }();
+#ifdef FA_TRACE
+                    __builtin_amdgcn_s_waitcnt(0xC07F);      // (s_memtime returns out of order: no counting)
+#else
+                    __builtin_amdgcn_s_waitcnt(0xC07F | (fly << 8));
+#endif
 #if defined(FA_TRACE) && FA_TRACE == 1
                     asm volatile("s_memtime %0" : "=s"(ts[2 + step / 2]));
 #endif
-                    ring[(step + 2) % 4] = operand(step + 2);
-                    ring[(step + 3) % 4] = operand(step + 3);
+                    ring[(step + LA) % RS] = operand(step + LA);
+                    ring[(step + LA + 1) % RS] = operand(step + LA + 1);
                 }
                 if constexpr (g < 32) {
-                    qk_mfma(S_nxt, step, qt, ring[step % 4]);
+                    qk_mfma(S_nxt, step, qt, ring[step % RS]);
                 } else {
                     constexpr int s2 = step - 16, s16 = s2 >> 2, t = s2 & 3;
-                    E::mfma_acc_a_p(O[qt][t], ring[step % 4], Pw[qt][s16]);
+                    E::mfma_acc_a_p(O[qt][t], ring[step % RS], Pw[qt][s16]);
                 }
 #if defined(FA_TRACE) && FA_TRACE == 2
                 if constexpr (g >= 48) asm volatile("s_memtime %0" : "=s"(ts[2 + g - 48]));  // fine trace of the visit's last 16 gaps
@@ -814,8 +830,8 @@ fa_fwd_kernel64(const KernelArgs args) {
             barrier();
             FA_TLF();
             FA_TL();  // S(0) formed, K(1) landed
-            ring[0] = k_frag(smem + TILE, 0);  // first operands of visit 0: K(1)
-            ring[1] = k_frag(smem + TILE, 1);
+#pragma unroll
+            for (int u = 0; u < LA; ++u) ring[u] = k_frag(smem + TILE, u);  // first operands of visit 0: K(1)
         }
         // O of one item: finish l, normalise, RNE to 16 bit (final_softmax_normalization
         // softmax.cuh:107-128; forward_kernel.cuh:186-203), through this wave's 8-KB LDS staging
