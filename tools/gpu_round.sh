@@ -11,6 +11,9 @@ echo "== smoke"; timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 
 echo "== pytest"; timeout 1500 python -m pytest tests -m gpu -q --timeout 900 > $OUT/pytest_gpu.txt 2>&1; tail -15 $OUT/pytest_gpu.txt
 echo "== bench"; timeout 600 python bench.py --steps 30 --warmup 10 > $OUT/bench.json 2> $OUT/bench.err; cat $OUT/bench.json; tail -3 $OUT/bench.err
 echo "== bench c3"; timeout 600 python bench.py --workload c3 --steps 10 --warmup 3 --no-cpu-baseline > $OUT/bench_c3.json 2>/dev/null; cut -c1-300 $OUT/bench_c3.json
+echo "== bench c4 (one GPU's shard)"; timeout 600 python bench.py --workload c4 --steps 10 --warmup 3 --no-cpu-baseline > $OUT/bench_c4.json 2>/dev/null; cut -c1-300 $OUT/bench_c4.json
+echo "== bench c2 (seq sweep, harmonic mean)"; timeout 600 python bench.py --workload c2 --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_c2.json 2>/dev/null; cut -c1-400 $OUT/bench_c2.json
+echo "== bench, N=2 code path on one GPU (gloo, both ranks on cuda:0; the timings mean nothing)"; timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 5 --warmup 2 --dist-backend gloo > $OUT/bench_n2_gloo.json 2> $OUT/bench_n2_gloo.err; cut -c1-260 $OUT/bench_n2_gloo.json; tail -2 $OUT/bench_n2_gloo.err
 echo "== wideners"; timeout 600 python flash_attention_from_scratch_amd/tools/bench_wideners.py > $OUT/wideners.txt 2>/dev/null; cat $OUT/wideners.txt
 echo "== dvfs"; timeout 300 python flash_attention_from_scratch_amd/tools/dvfs_probe.py > $OUT/dvfs_probe.txt 2>/dev/null; cat $OUT/dvfs_probe.txt
 echo "== seqsweep"; bash tools/gpu_seqsweep.sh $TAG/seq > /dev/null 2>&1
