@@ -460,11 +460,13 @@ fa_fwd_kernel64(const KernelArgs args) {
                 const int row_b = qblk * TR::kBr + wave * TR::kRowsPerWave + 32 * qt;
                 if (row_b + 31 >= args.seq_len) {  // wave-uniform: rows beyond the sequence are fetched from its last row
                     const unsigned chunk_b = (((unsigned)l_ & 15) ^ ((unsigned)l_ >> 4)) << 4;
+                    const int row_s = row_b < args.seq_len - 32 ? row_b : args.seq_len - 32;  // scalar base row (seq_len >= 64)
+                    const uint16_t *rows_s = Qh + (int64_t)row_s * ss;
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
                         int rg = row_b + 4 * i + (l_ >> 4);
                         rg = rg < args.seq_len - 1 ? rg : args.seq_len - 1;
-                        glds16_sv_m0(Qh, (unsigned)rg * (unsigned)(ss * 2) + (chunk_b ^ (64u * (i & 3))), stage + i * 1024);
+                        glds16_sv_m0(rows_s, (unsigned)(rg - row_s) * (unsigned)(ss * 2) + (chunk_b ^ (64u * (i & 3))), stage + i * 1024);
                     }
                     return;
                 }
