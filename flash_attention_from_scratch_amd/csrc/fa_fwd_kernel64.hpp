@@ -351,8 +351,8 @@ fa_fwd_kernel64(const KernelArgs args) {
         // walk: visit index j of the current item for j < n_kv, visit index j - n_kv of the NEXT item
         // beyond (n_kv % 4 == 0, so a tile's ring stage is j & 3 either way).  The last visits of an
         // item therefore request the next item's first tiles, its last visit forms the next item's
-        // S(0) with the next item's Q (loaded straight into the Q AGPRs one visit earlier), and a
-        // seam costs the O epilogue only.  After the last item the "next" item is the item itself:
+        // S(0) with the next item's Q (brought into the spare Q set during the item's first visits), and a
+        // seam costs the O epilogue and the reset of the item state only.  After the last item the "next" item is the item itself:
         // the re-fetched tiles land in stages nobody reads.
         const int n_items = args.n_bh * nq;
         int item = blockIdx.x;
