@@ -211,3 +211,21 @@ def test_best_config_selection_rules():
             cfg = kc.best_config(dtype, S, masked=True)
             assert not kc.uses_lazy_rescale(cfg) and (cfg.B_r, cfg.B_c, cfg.n_warps) == (128, 64, 4)
             assert _capi.masked_supported(cfg)
+
+
+def test_ragged_window_rule_covers_every_key_exactly_once():
+    """The persistent kernel's ragged form (csrc/fa_fwd_kernel64.hpp, RAG): the host rounds the Q blocks up
+    and runs 4 tiles of 64 keys per Q block; tile t is fetched from row r0 = min(64 t, S - 64) and the first
+    delta = 64 t - r0 keys of that window are masked.  Restated here: for every S >= 64 the unmasked keys of
+    all tiles are exactly 0 .. S-1, each once, and no window leaves the tensor."""
+    for S in list(range(64, 700)) + [1000, 4000, 8191, 16385]:
+        n_tiles = 4 * ((S + 255) // 256)
+        seen = [0] * S
+        for t in range(n_tiles):
+            r0 = min(64 * t, S - 64)
+            delta = 64 * t - r0
+            assert 0 <= r0 and r0 + 64 <= S
+            for key_in_window in range(max(delta, 0), 64):
+                seen[r0 + key_in_window] += 1
+        assert seen == [1] * S, S
+
