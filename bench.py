@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- the driver's benchmark contract for the FA2-forward hot path.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1 spawns one rank per GPU itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A "step" is one pass of the hot path (flash_attention.forward -> libfa_hip.so) over
@@ -14,15 +14,29 @@ the timed region): "scaling": "weak".
 One JSON line on rank 0:
   value      whole-job TFLOP/s = N * steps * 4*B*H*S^2*d / max-over-ranks time
   roofline   MFMA-bound: achieved TFLOP/s of the kernel from HIP events recorded on
-             the launch stream around the K timed launches; peak = 2500 TFLOP/s
-             (MI355X dense bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md)
+             the launch stream around the K timed launches (and after every launch: the
+             per-launch distribution); peak = 2500 TFLOP/s (MI355X dense bf16 MFMA,
+             /opt/skills/guides/MI355X_MICROARCH.md); traffic = HBM bytes per launch from
+             rocprofv3 PMC passes over this same command (FETCH_SIZE x 2 + WRITE_SIZE)
+  clocks     shader / memory clock and socket power sampled from the GPU's hwmon files
+             during the timed region (SURVEY.md 8d asks for them: the chip clocks to its
+             power budget)
   cpu_baseline  torch CPU scaled_dot_product_attention (oracle.fa_oracle.sdpa_cpu)
              on the SAME workload, on this host's cores, rank 0, N=1 only.
+
+--hermetic times every launch on its own behind a cache flush and an idle spin (the
+reference's tools/benchmark/pt_bench.py:145-174 protocol); the default is back-to-back
+launches, which is what the driver's wall clock sees.
 """
 import argparse
+import glob
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
+import threading
 import time
 
 import torch
@@ -32,6 +46,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0}  # dense MFMA, MI355X_MICROARCH.md
+MAX_SCLK_MHZ = 2400.0                            # MI355X_MICROARCH.md, chip-level parameters
 WORKLOADS = {
     # name: (dtype, per-GPU batch, heads, seq_len, d_head)   -- BASELINE.json configs
     "c1": ("bf16", 4, 16, 4096, 128),      # headline
@@ -41,44 +56,6 @@ WORKLOADS = {
 # BASELINE.json configs[2]: bf16 sweep, batch per seq_len from the reference's table
 # (py/flash_helpers/test/utils.py:9-16), heads 16, harmonic mean of TFLOP/s
 C2_SWEEP = [(512, 16), (1024, 16), (2048, 16), (4096, 16), (8192, 8), (16384, 4)]
-
-
-def run_c2_sweep(args, device):
-    """--workload c2: one JSON line whose value is the harmonic mean over the sweep."""
-    import statistics
-
-    import flash_attention
-    from flash_helpers import kernel_configs as kc
-
-    per_s = {}
-    for seq, batch in C2_SWEEP:
-        cfg = kc.parse_kernel_name_into_config(args.kernel) if args.kernel else kc.best_config(kc.DType.BF16, seq)
-        gen = torch.Generator(device=device).manual_seed(seq)
-        q, k, v = (torch.randn((batch, seq, 16, 128), dtype=torch.bfloat16, device=device, generator=gen)
-                   for _ in range(3))
-        o = torch.empty_like(q)
-        for _ in range(args.warmup):
-            flash_attention.forward(cfg, q, k, v, o)
-        torch.cuda.synchronize(device)
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            flash_attention.forward(cfg, q, k, v, o)
-        torch.cuda.synchronize(device)
-        sec = (time.perf_counter() - t0) / args.steps
-        per_s[seq] = {"tflops": mfma_flop(batch, 16, seq, 128) / sec / 1e12, "ms": sec * 1e3,
-                      "batch": batch, "kernel": cfg.short_form()}
-    value = statistics.harmonic_mean([r["tflops"] for r in per_s.values()])
-    print(json.dumps({
-        "metric": "bf16 TFLOPs, harmonic mean over seq_len {512..16384}, d_head=128", "value": value,
-        "unit": "TFLOP/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": sum(r["ms"] for r in per_s.values()), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": "c2: FA2 forward bf16 sweep S in {512,1024,2048,4096,8192,16384}, heads=16, "
-                               "batch {16,16,16,16,8,4}, a step = one pass over all six shapes"},
-        "per_seq_len": per_s,
-        "roofline": {"bound": "mfma", "achieved": value, "peak": PEAK_TFLOPS["bf16"], "unit": "TFLOP/s",
-                     "frac": value / PEAK_TFLOPS["bf16"], "traffic": None},
-    }), flush=True)
 
 
 def mfma_flop(batch, heads, seq, d):
@@ -117,6 +94,143 @@ def max_over_ranks(seconds, world, device):
     return float(t.item())
 
 
+def distribution(samples_ms):
+    """mean / median / min / max / stddev of per-launch milliseconds (pt_bench.py:38-79's fields)."""
+    return {
+        "n": len(samples_ms),
+        "mean": statistics.mean(samples_ms),
+        "median": statistics.median(samples_ms),
+        "min": min(samples_ms),
+        "max": max(samples_ms),
+        "stddev": statistics.stdev(samples_ms) if len(samples_ms) > 1 else 0.0,
+    }
+
+
+# ---- clocks and power from the GPU's hwmon files --------------------------------------------
+def hwmon_dir(device_index):
+    """hwmon directory of torch device `device_index` (matched by PCI address), or None."""
+    try:
+        props = torch.cuda.get_device_properties(device_index)
+        want = "%04x:%02x:%02x." % (props.pci_domain_id, props.pci_bus_id, props.pci_device_id)
+    except Exception:
+        want = None
+    cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device"))
+    picked = None
+    for dev in cards:
+        real = os.path.realpath(dev)
+        if want and want in real:
+            picked = dev
+            break
+    if picked is None and cards and not want:
+        picked = cards[min(device_index, len(cards) - 1)]
+    if picked is None:
+        return None
+    hw = sorted(glob.glob(os.path.join(picked, "hwmon", "hwmon*")))
+    return hw[0] if hw else None
+
+
+class ClockSampler:
+    """Background thread: shader clock (freq1), memory clock (freq2) and socket power (power1) every
+    `period` seconds between start() and stop().  Reading three sysfs files costs the host a few
+    microseconds and the GPU nothing."""
+
+    FILES = {"sclk_mhz": ("freq1_input", 1e-6), "mclk_mhz": ("freq2_input", 1e-6), "power_w": ("power1_input", 1e-6)}
+
+    def __init__(self, hw, period=0.002):
+        self.hw, self.period = hw, period
+        self.samples = {k: [] for k in self.FILES}
+        self._stop = threading.Event()
+        self._thread = None
+
+    def _read(self):
+        for key, (name, scale) in self.FILES.items():
+            try:
+                with open(os.path.join(self.hw, name)) as f:
+                    self.samples[key].append(float(f.read().strip()) * scale)
+            except (OSError, ValueError):
+                pass
+
+    def _run(self):
+        while not self._stop.is_set():
+            self._read()
+            self._stop.wait(self.period)
+
+    def start(self):
+        if self.hw:
+            self._thread = threading.Thread(target=self._run, daemon=True)
+            self._thread.start()
+
+    def stop(self):
+        if self._thread:
+            self._stop.set()
+            self._thread.join()
+            self._read()  # one sample at the end of the region even if it was shorter than a period
+
+    def summary(self):
+        out = {"source": (self.hw or "unavailable") + " (freq1_input, freq2_input, power1_input)"}
+        for key, vals in self.samples.items():
+            if vals:
+                out[key] = {"mean": statistics.mean(vals), "min": min(vals), "max": max(vals), "n": len(vals)}
+        try:
+            with open(os.path.join(self.hw, "power1_cap")) as f:
+                out["power_cap_w"] = float(f.read().strip()) * 1e-6
+        except (OSError, ValueError, TypeError):
+            pass
+        return out
+
+
+# ---- HBM traffic of one launch, measured: rocprofv3 PMC passes over this command -------------
+def committed_traffic(kernel_short_form, workload):
+    """Fallback: the committed PMC result of tools/gpu_pmc.sh (profiles/traffic_<workload>.json)."""
+    path = os.path.join(ROOT, "profiles", f"traffic_{workload}.json")
+    try:
+        with open(path) as f:
+            rec = json.load(f)
+    except (OSError, ValueError):
+        return None
+    return rec.get("hbm_bytes_per_launch") if rec.get("kernel") == kernel_short_form else None
+
+
+def measure_traffic(argv_tail, timeout_s=150):
+    """Run `bench.py --traffic-child <same workload>` under rocprofv3 twice (FETCH_SIZE and WRITE_SIZE
+    each take more than half of the TCC counter slots: separate passes, counters only with
+    --kernel-trace) and return HBM bytes per launch of the dominant kernel:
+    2 * FETCH_SIZE + WRITE_SIZE, both reported in KiB (MI355X_MICROARCH.md, HBM section: gfx950
+    tallies a 128-B read request as 64 B).  None if rocprofv3 is missing or a pass fails."""
+    import csv
+    import shutil
+    import tempfile
+
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(prof):
+        return None, "rocprofv3 not found"
+    kib = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        out_dir = tempfile.mkdtemp(prefix="fa_pmc_", dir="/tmp")
+        cmd = [prof, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out_dir, "-o", "p", "--",
+               sys.executable, os.path.abspath(__file__), "--traffic-child"] + argv_tail
+        env = dict(os.environ, TMPDIR="/tmp")
+        try:
+            subprocess.run(cmd, cwd="/tmp", env=env, timeout=timeout_s, stdout=subprocess.DEVNULL,
+                           stderr=subprocess.DEVNULL, check=True)
+        except (subprocess.SubprocessError, OSError) as exc:
+            shutil.rmtree(out_dir, ignore_errors=True)
+            return None, f"rocprofv3 --pmc {counter}: {type(exc).__name__}"
+        vals = []
+        for path in glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"), recursive=True):
+            with open(path) as f:
+                for row in csv.DictReader(f):
+                    if "fa_fwd" in row.get("Kernel_Name", "") and row.get("Counter_Name") == counter:
+                        vals.append(float(row["Counter_Value"]))
+        shutil.rmtree(out_dir, ignore_errors=True)
+        if not vals:
+            return None, f"no {counter} rows for the kernel"
+        kib[counter] = statistics.mean(vals)
+    return (2 * kib["FETCH_SIZE"] + kib["WRITE_SIZE"]) * 1024.0, \
+        "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over this workload in this run; 2*FETCH+WRITE KiB"
+
+
+# ---- CPU baseline -----------------------------------------------------------------------------
 def cpu_baseline(dtype, batch, heads, seq, d, budget_s=12.0):
     """torch CPU SDPA on the same workload shape, bounded to ~budget_s."""
     from oracle import fa_oracle as fo  # checker / baseline only -- never the product path
@@ -152,16 +266,105 @@ def cpu_baseline(dtype, batch, heads, seq, d, budget_s=12.0):
     }
 
 
-def measured_traffic(kernel_short_form, workload):
-    """HBM bytes per launch from the committed rocprofv3 PMC pass of this kernel on this
-    workload (profiles/traffic_c1.json, written by tools/gpu_pmc.sh); None if absent."""
-    path = os.path.join(ROOT, "profiles", f"traffic_{workload}.json")
-    try:
-        with open(path) as f:
-            rec = json.load(f)
-    except (OSError, ValueError):
-        return None
-    return rec.get("hbm_bytes_per_launch") if rec.get("kernel") == kernel_short_form else None
+# ---- N > 1 without an external launcher ---------------------------------------------------------
+def self_launch(n):
+    """`python bench.py --gpus N` with no RANK in the environment: start one rank per GPU (the same
+    command, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, rendezvous on 127.0.0.1), wait for all of
+    them; rank 0 prints the line.  Returns the worst exit code."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return rc
+
+
+def run_c2_sweep(args, device):
+    """--workload c2: one JSON line whose value is the harmonic mean over the sweep."""
+    import flash_attention
+    from flash_helpers import kernel_configs as kc
+
+    per_s = {}
+    hw = hwmon_dir(device.index or 0)
+    for seq, batch in C2_SWEEP:
+        cfg = kc.parse_kernel_name_into_config(args.kernel) if args.kernel else kc.best_config(kc.DType.BF16, seq)
+        gen = torch.Generator(device=device).manual_seed(seq)
+        q, k, v = (torch.randn((batch, seq, 16, 128), dtype=torch.bfloat16, device=device, generator=gen)
+                   for _ in range(3))
+        o = torch.empty_like(q)
+        for _ in range(args.warmup):
+            flash_attention.forward(cfg, q, k, v, o)
+        torch.cuda.synchronize(device)
+        sampler = ClockSampler(hw)
+        sampler.start()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            flash_attention.forward(cfg, q, k, v, o)
+        torch.cuda.synchronize(device)
+        sec = (time.perf_counter() - t0) / args.steps
+        sampler.stop()
+        clk = sampler.summary()
+        per_s[seq] = {"tflops": mfma_flop(batch, 16, seq, 128) / sec / 1e12, "ms": sec * 1e3,
+                      "batch": batch, "kernel": cfg.short_form(),
+                      "sclk_mhz": clk.get("sclk_mhz", {}).get("mean"), "power_w": clk.get("power_w", {}).get("mean")}
+    value = statistics.harmonic_mean([r["tflops"] for r in per_s.values()])
+    print(json.dumps({
+        "metric": "bf16 TFLOPs, harmonic mean over seq_len {512..16384}, d_head=128", "value": value,
+        "unit": "TFLOP/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": sum(r["ms"] for r in per_s.values()), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": "c2: FA2 forward bf16 sweep S in {512,1024,2048,4096,8192,16384}, heads=16, "
+                               "batch {16,16,16,16,8,4}, a step = one pass over all six shapes"},
+        "per_seq_len": per_s,
+        "roofline": {"bound": "mfma", "achieved": value, "peak": PEAK_TFLOPS["bf16"], "unit": "TFLOP/s",
+                     "frac": value / PEAK_TFLOPS["bf16"], "traffic": None},
+    }), flush=True)
+
+
+def dry_run(args, rank, world):
+    """--cpu-dry-run: the control flow of main() around a step that sleeps (no kernel, no oracle)."""
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+        barrier = dist.barrier
+    else:
+        def barrier():
+            return None
+    _, batch, heads, seq, d = WORKLOADS[args.workload if args.workload != "c2" else "c1"]
+    lo, hi = shard_for_rank(batch * world, world, rank)
+    seconds = timed_steps(lambda: time.sleep(0.002), args.steps, args.warmup, lambda: None, barrier)
+    mine = mfma_flop(hi - lo, heads, seq, d) * args.steps / seconds / 1e12
+    seconds = max_over_ranks(seconds, world, torch.device("cpu"))
+    per_rank = [mine]
+    if world > 1:
+        import torch.distributed as dist
+
+        t = torch.tensor([mine], dtype=torch.float64)
+        got = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(got, t)
+        per_rank = [float(g.item()) for g in got]
+    if rank == 0:
+        value = mfma_flop(hi - lo, heads, seq, d) * world * args.steps / seconds / 1e12
+        print(json.dumps({"metric": "cpu-dry-run (a step is a 2 ms sleep: NOT a measurement)", "value": value,
+                          "unit": "TFLOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": seconds / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": "none", "data": "none (dry run)",
+                          "config": {"workload": "dry run", "global_batch": batch * world,
+                                     "shards": [list(shard_for_rank(batch * world, world, r)) for r in range(world)]},
+                          "per_gpu_tflops": per_rank}), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.destroy_process_group()
 
 
 def main():
@@ -172,26 +375,45 @@ def main():
     ap.add_argument("--workload", default="c1", choices=sorted(WORKLOADS) + ["c2"])
     ap.add_argument("--kernel", default="", help="short-form config; default = best_config(dtype)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
-                    help="nccl (= RCCL) for real multi-GPU runs; gloo lets a 1-GPU box exercise the "
-                         "N>1 code path with every rank on cuda:0 (timings then mean nothing)")
+    ap.add_argument("--no-traffic", action="store_true",
+                    help="skip the two rocprofv3 PMC passes that measure HBM bytes per launch (~1 min)")
+    ap.add_argument("--precondition-ms", type=float, default=400.0,
+                    help="untimed launches of the same step for this long BEFORE the W warm-up steps: the chip's "
+                         "clock governor needs a few hundred ms of load to leave its idle state (a cold 20-step "
+                         "run reads ~12 %% low, DESIGN.md 5); 0 disables; stated in the line")
+    ap.add_argument("--hermetic", action="store_true",
+                    help="every timed launch on its own behind a cache flush + idle spin (pt_bench protocol)")
+    ap.add_argument("--traffic-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-dry-run", action="store_true",
+                    help="no GPU, no kernel: a step is a 2 ms sleep.  Exercises the launcher, the shard arithmetic, "
+                         "the barrier-bracketed timing and the rank-0 line on a CPU-only box (tests/); the line says so")
+    ap.add_argument("--dist-backend", default="gloo", choices=["gloo", "nccl"],
+                    help="barrier + max-over-ranks only (the data path has no collective): gloo (default; on "
+                         "a box with fewer GPUs than ranks the ranks share devices and the timings mean "
+                         "nothing) or nccl (= RCCL)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "RANK" not in os.environ:
+        raise SystemExit(self_launch(args.gpus))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
         raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
+
+    if args.cpu_dry_run:
+        return dry_run(args, rank, world)
 
     import flash_attention
     from flash_helpers import kernel_configs as kc
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
-    if args.dist_backend == "gloo":
-        local_rank = local_rank % torch.cuda.device_count()
+    n_dev = torch.cuda.device_count()
+    if local_rank >= n_dev and args.dist_backend != "gloo":
+        raise SystemExit(f"rank {rank}: no device {local_rank} (nccl needs one GPU per rank)")
+    local_rank = local_rank % n_dev
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     reduce_device = device if args.dist_backend == "nccl" else torch.device("cpu")
@@ -235,31 +457,63 @@ def main():
 
             dist.barrier()
 
-    # events on the launch stream (flash_attention launches on torch's current stream)
-    ev0 = torch.cuda.Event(enable_timing=True)
-    ev1 = torch.cuda.Event(enable_timing=True)
-    state = {"n": 0}
+    if args.traffic_child:  # under rocprofv3 (measure_traffic): a few launches of the workload, nothing else
+        for _ in range(3):
+            step()
+        sync()
+        return
 
-    def step_with_events():
-        if state["n"] == 0:
-            ev0.record(stream)
+    # events on the launch stream (flash_attention launches on torch's current stream): one in front
+    # of the first timed launch and one behind every launch
+    events = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    flush_buf = torch.empty(512 * 1024 * 1024, dtype=torch.int8, device=device) if args.hermetic else None
+    herm_ms = []
+
+    def timed_step(i):
+        if args.hermetic:  # pt_bench.py:145-174: flush (> L2 + Infinity Cache), idle spin, events around the launch
+            flush_buf.zero_()
+            torch.cuda._sleep(1_000_000)
+            sync()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            step()
+            e1.record(stream)
+            sync()
+            herm_ms.append(e0.elapsed_time(e1))
+            return
+        if i == 0:
+            events[0].record(stream)
         step()
-        state["n"] += 1
-        if state["n"] == args.steps:
-            ev1.record(stream)
+        events[i + 1].record(stream)
 
+    sampler = ClockSampler(hwmon_dir(local_rank))
+    # wake the clocks: the same launches, untimed, until --precondition-ms have passed
+    pre_steps, t_pre = 0, time.perf_counter()
+    while (time.perf_counter() - t_pre) * 1e3 < args.precondition_ms:
+        for _ in range(8):
+            step()
+        sync()
+        pre_steps += 8
     for _ in range(args.warmup):
         step()
     sync()
     barrier()
+    sampler.start()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step_with_events()
+    for i in range(args.steps):
+        timed_step(i)
     sync()
     barrier()
     seconds = time.perf_counter() - t0
+    sampler.stop()
+    if args.hermetic:
+        per_launch = herm_ms
+        seconds = sum(herm_ms) * 1e-3  # the flushes and spins are not steps
+        kernel_ms = statistics.mean(herm_ms)
+    else:
+        per_launch = [events[i].elapsed_time(events[i + 1]) for i in range(args.steps)]
+        kernel_ms = events[0].elapsed_time(events[-1]) / args.steps  # avg launch duration, this rank
     seconds = max_over_ranks(seconds, world, reduce_device)
-    kernel_ms = ev0.elapsed_time(ev1) / args.steps  # avg launch duration, this rank
 
     flop_per_step_rank = mfma_flop(hi - lo, heads, seq, d)
     total_flop = flop_per_step_rank * world * args.steps  # equal shards
@@ -267,8 +521,19 @@ def main():
     achieved = flop_per_step_rank / (kernel_ms * 1e-3) / 1e12
     peak = PEAK_TFLOPS[dtype_name]
 
+    per_rank = None
+    if world > 1:  # per-GPU rates next to the aggregate (rank order)
+        import torch.distributed as dist
+
+        mine = torch.tensor([achieved], dtype=torch.float64, device=reduce_device)
+        gathered = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(gathered, mine)
+        per_rank = [float(g.item()) for g in gathered]
+
     if rank == 0:
         props = torch.cuda.get_device_properties(device)
+        clocks = sampler.summary()
+        sclk = clocks.get("sclk_mhz", {}).get("mean")
         line = {
             "metric": "achieved bf16 TFLOPs and % of MFMA peak at seq_len=4096 d_head=128"
                       if args.workload == "c1" else f"achieved {dtype_name} TFLOPs ({args.workload})",
@@ -285,6 +550,10 @@ def main():
             "data": "synthetic",
             "pct_of_mfma_peak": 100.0 * value / (peak * world),
             "ref_convention_tflops": value * (4 * d + 6) / (4 * d),  # B*H*(4S^2d+6S^2), kernel_configs.py:102
+            "protocol": "hermetic: flush + idle spin before every launch, value from the per-launch events"
+                        if args.hermetic else "back-to-back launches",
+            "precondition": {"ms": args.precondition_ms, "untimed_steps": pre_steps,
+                             "why": "clock governor ramp from idle; before the W warm-up steps, outside the timed region"},
             "config": {
                 "workload": f"{args.workload}: FA2 forward {dtype_name} batch={batch}/GPU heads={heads} "
                             f"seq_len={seq} d_head={d} non-causal",
@@ -300,12 +569,29 @@ def main():
                 "peak": peak,
                 "unit": "TFLOP/s",
                 "frac": achieved / peak,
-                "traffic": measured_traffic(cfg.short_form(), args.workload),
+                "traffic": None,
                 "algorithmic_bytes": 4 * (hi - lo) * seq * heads * d * 2,
                 "kernel_ms": kernel_ms,
+                "kernel_ms_per_launch": distribution(per_launch),
                 "flop_per_launch": flop_per_step_rank,
+                # the matrix pipe's rate at the clock the chip actually held (it clocks to its power budget)
+                "peak_at_measured_clock": peak * sclk / MAX_SCLK_MHZ if sclk else None,
+                "frac_of_peak_at_measured_clock": achieved / (peak * sclk / MAX_SCLK_MHZ) if sclk else None,
             },
+            "clocks": clocks,
         }
+        if per_rank:
+            line["per_gpu_tflops"] = per_rank
+            line["aggregate_over_sum_of_gpus"] = value / sum(per_rank)
+        if world == 1 and not args.no_traffic:
+            tail = ["--workload", args.workload] + (["--kernel", args.kernel] if args.kernel else [])
+            traffic, how = measure_traffic(tail)
+            if traffic is None:
+                line["roofline"]["traffic"] = committed_traffic(cfg.short_form(), args.workload)
+                line["roofline"]["traffic_source"] = f"profiles/traffic_{args.workload}.json ({how})"
+            else:
+                line["roofline"]["traffic"] = traffic
+                line["roofline"]["traffic_source"] = how
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(dtype, batch, heads, seq, d)
         print(json.dumps(line), flush=True)

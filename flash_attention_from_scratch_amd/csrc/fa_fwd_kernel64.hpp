@@ -26,15 +26,29 @@ struct Plan64 {
 #endif
 constexpr Plan64 make_plan64(int variant, int n_phase1) {
     Plan64 p{};
-    const bool bar_top = variant & 1, dma_late = variant & 2, masked = variant & 4;
+    const bool bar_top = variant & 1, dma_late = variant & 2, masked = variant & 4, nomax = variant & 8, even = variant & 16;
+    // nomax (the speculative schedule): no row-max units, no end-of-visit chain (only its last step, the
+    // next request pointers).  even (experiment): the 32 softmax units spread evenly over the gaps that carry
+    // no operand reads (g % 4 != 0, not the barrier gap) up to gap 54, the last one P's consumers allow --
+    // measured 14 % behind the phase-1-heavy placement (phase 2 carries twice the LDS operand reads)
     // masked: gaps 32..35 of a diagonal visit rewrite S(it+1) (causal mask) before its row max is
     // taken, so the 32 row-max units start 4 gaps later and the end-of-visit chain runs in 5 steps
     const int m0 = masked ? 4 : 0, odd0 = masked ? 11 : 9, mend = masked ? 27 : 24;
-    int e = 0, m = 0, d = 0;
+    int e = 0, m = 0, d = 0, slot_nm = 0;
+    int n_slots_nm = 0;
+    for (int g = 1; g <= 54; ++g) n_slots_nm += ((g & 3) != 0 && g != 2) ? 1 : 0;
     for (int g = 0; g < 64; ++g) {
         const int h = g - 32;
         int ne = 0, nm = 0, dm = -1, tl = 0;
-        if (g < 32) {
+        if (nomax && even) {
+            if ((g & 3) == 0) {
+                if (g >= 4 && g <= 32) dm = d++;
+            } else if (g != 2 && g <= 54) {
+                if ((slot_nm + 1) * 32 / n_slots_nm > slot_nm * 32 / n_slots_nm) ne = 1;
+                ++slot_nm;
+            }
+            if (g == 63) tl = 8;
+        } else if (g < 32) {
             // gaps g % 4 == 0 carry the operand wait + two K reads; gap 2 the barrier; the DMA
             // pieces follow it, one per four gaps
             if ((g & 3) == 0) {
@@ -56,6 +70,7 @@ constexpr Plan64 make_plan64(int variant, int n_phase1) {
             if (dma_late && h >= 24) dm = d++;
             if (masked) { if (h >= 27) tl = 10 + (h - 27); }          // merged chain steps 10..14
             else if (h >= 24) tl = h - 23;                            // chain steps 1..8
+            if (nomax) { nm = 0; tl = (h == 31) ? 8 : 0; }
         }
         p.exp_first[g] = (signed char)e; p.exp_n[g] = (signed char)ne; e += ne;
         p.max_first[g] = (signed char)m; p.max_n[g] = (signed char)nm; m += nm;
@@ -66,6 +81,7 @@ constexpr Plan64 make_plan64(int variant, int n_phase1) {
 }
 constexpr bool plan64_ok(const Plan64 &p) {
     int e = 0, m = 0, d = 0, bar = -1;
+    bool chain = false;  // the plan carries the row max + the end-of-visit chain (not the speculative schedule)
     for (int g = 0; g < 64; ++g) {
         // P of 16-key slice s16 is consumed from gap 32 + 8 s16 on: its units must be >= 2 gaps older
         for (int u = p.exp_first[g]; u < p.exp_first[g] + p.exp_n[g]; ++u)
@@ -74,12 +90,13 @@ constexpr bool plan64_ok(const Plan64 &p) {
         for (int u = p.max_first[g]; u < p.max_first[g] + p.max_n[g]; ++u)
             if (g < ((u >> 4) ? 34 : 32)) return false;
         if ((p.tail[g] == 1 || p.tail[g] == 10) && m < 32) return false;
+        if (p.tail[g] == 1 || p.tail[g] == 10) chain = true;
         if (p.barrier[g]) bar = g;
         if (p.dma[g] >= 0 && bar >= 0 && g <= bar) return false;      // DMA overwrites what the barrier frees
         if (p.barrier[g] && g >= 28) return false;                    // V(it+1) is first read at gap 30
         e += p.exp_n[g]; m += p.max_n[g]; d += p.dma[g] >= 0;
     }
-    return e == 32 && m == 32 && d == 8;
+    return e == 32 && m == (chain ? 32 : 0) && d == 8;
 }
 
 // (optimized_softmax selects nothing here: the first tile of an item never rescales, by construction)
@@ -89,11 +106,20 @@ constexpr bool plan64_ok(const Plan64 &p) {
 // per-lane clamp in the request path) and the keys in front of the tile's own first key are masked, which
 // masks a tile that lies beyond the sequence whole; Q rows beyond the sequence are fetched from its last
 // row and not stored.
-template <int DT, bool MASK = false, int ABL = 0, bool RAG = false>
+// SPEC (cfg.optimized_softmax; plain variant only): speculative softmax.  The per-tile row max exists
+// only to keep P = 2^((s - m) c) in range -- any reference m gives the same real result -- and its
+// end-of-visit chain (32 v_max3, a lane-pair exchange, two ballots) costs 15-20 % of the kernel
+// (tools/tune64.hip, knob 4096).  So an item is first run with m fixed at the row max of its FIRST tile,
+// no row max and no rescale at all (walk<FAST>); its epilogue checks the row sums l >= every P against
+// a limit that proves nothing overflowed (fp32 exp2, the 16-bit P, the accumulators), and an item that
+// fails -- a row whose logits rise ~100 (bf16) / ~15 (fp16) binades above its first tile's max -- is
+// run again by the lazy-rescale schedule (walk<SAFE>, the whole of the non-SPEC kernel) after the walk.
+template <int DT, bool MASK = false, int ABL = 0, bool RAG = false, bool SPEC = false>
 __global__ void
 __launch_bounds__(256, 1)
 fa_fwd_kernel64(const KernelArgs args) {
     static_assert(!RAG || MASK, "the ragged form is a masked variant");
+    static_assert(!SPEC || !MASK, "the speculative softmax is built for the plain variant");
     constexpr int QT = 2, NWAVES = 4, BC = 64, D = 128;
     constexpr bool SWZ = true, EAGER = true, PIPE = true, DMA = true;
 
@@ -186,15 +212,7 @@ fa_fwd_kernel64(const KernelArgs args) {
             qb_out = bid % nq;
         }
     };
-    int bh, qb;
-    item_coords(blockIdx.x, bh, qb);
-    const int b = bh / args.n_heads, h = bh % args.n_heads;
     const int64_t ss = args.seq_stride;
-    const int64_t head_off = (int64_t)b * args.batch_stride + (int64_t)h * args.head_stride;
-    const uint16_t *Qg = (const uint16_t *)args.q + head_off;
-    const uint16_t *Kg = (const uint16_t *)args.k + head_off;
-    const uint16_t *Vg = (const uint16_t *)args.v + head_off;
-    uint16_t *Og = (uint16_t *)args.o + head_off;
 
     // ---- per-lane DMA source offsets (elements), invariant over tiles ------------
     // piece i (wave-uniform) covers LDS chunks [64 i, 64 i + 64) of a tile.
@@ -210,9 +228,6 @@ fa_fwd_kernel64(const KernelArgs args) {
     const int64_t v_lane_row = (v_w >> 2);                                 // key & 7
     const int v_lane_d = (v_w & 3) * 8;
 
-    // KV blocks are visited last-to-first (forward_kernel.cuh:142,175-184): visit index `it` is
-    // sequence block n_kv-1-it.  Causal: only the 4 (qb + 1) tiles up to the item's diagonal.
-    const int n_kv = (MASK && args.causal) ? 4 * (qb + 1) : args.n_kv_blocks;
     const unsigned smem_base = __builtin_amdgcn_readfirstlane(lds_addr(smem));
     // DMA addressing: SGPR base = head base + tile offset (scalar ALU), VGPR = 32-bit
     // per-lane byte offset of this wave's piece inside a tile (invariant over tiles).
@@ -235,6 +250,47 @@ fa_fwd_kernel64(const KernelArgs args) {
     };
     auto dma_wait = [&]() { if (DMA && !(ABL & 8)) dma_wait_all(); };
     auto barrier = [&]() { if (!(ABL & 8)) wg_barrier(); };
+    // forward_kernel.cuh:150-151 (fp32 product of rsqrt(d) and log2 e)
+    const float c = (float)((double)(1.0f / __builtin_sqrtf((float)D)) * 1.4426950408889634074);
+
+    // per-lane LDS read offsets
+    //   K A-operand: row 32*nt + r31, chunk (2*ks + hi) ^ (r31 & 15)
+    const int ka_swz = SWZ ? swz_of(r31) : 0;
+    const int ka_base = r31 * ROWB;
+    //   V^T A-operand (transpose read): see header comment
+    const int li = lane & 15, lg = lane >> 4;
+    const int va_base = (4 * (lg >> 1) + (li >> 2)) * 64 + (lg & 1) * 32 + (li & 3) * 8;
+
+    // a row whose keys were all masked so far has m = -inf: exponentiate against 0 instead
+    auto finite_or_zero = [&](float mval) { return (MASK && mval == -__builtin_inff()) ? 0.0f : mval; };
+
+    // ---- one walk over this workgroup's items: ordinals o (item = blockIdx.x + o gridDim.x) whose bit
+    // min(o, 63) is set in `todo`.  FAST: the speculative schedule (see SPEC above); returns the ordinals
+    // (same encoding) of the items whose check failed in any row of this wave.
+    auto walk = [&](auto fast_tag, const unsigned long long todo) -> unsigned long long {
+    constexpr bool FAST = decltype(fast_tag)::value;
+    unsigned long long failed = 0;
+    const int n_items = args.n_bh * nq;
+    auto next_ord = [&](int o) {  // next ordinal of this pass behind o, or -1 (scalar; item seams only)
+        for (;;) {
+            ++o;
+            if ((long long)blockIdx.x + (long long)o * (long long)gridDim.x >= (long long)n_items) return -1;
+            if (!SPEC || ((todo >> (o < 63 ? o : 63)) & 1ull)) return o;
+        }
+    };
+    int ord = next_ord(-1);
+    if (ord < 0) return failed;  // (second pass only: nothing of this workgroup's failed)
+    int bh, qb;
+    item_coords((int)blockIdx.x + ord * (int)gridDim.x, bh, qb);
+    const int b = bh / args.n_heads, h = bh % args.n_heads;
+    const int64_t head_off = (int64_t)b * args.batch_stride + (int64_t)h * args.head_stride;
+    const uint16_t *Qg = (const uint16_t *)args.q + head_off;
+    const uint16_t *Kg = (const uint16_t *)args.k + head_off;
+    const uint16_t *Vg = (const uint16_t *)args.v + head_off;
+    uint16_t *Og = (uint16_t *)args.o + head_off;
+    // KV blocks are visited last-to-first (forward_kernel.cuh:142,175-184): visit index `it` is
+    // sequence block n_kv-1-it.  Causal: only the 4 (qb + 1) tiles up to the item's diagonal.
+    const int n_kv = (MASK && args.causal) ? 4 * (qb + 1) : args.n_kv_blocks;
     // ---- first requests of the walk: K(0), then Q (all S(0) needs); the rest follows in the prologue
     if (!(ABL & 16)) {
 #pragma unroll
@@ -243,9 +299,6 @@ fa_fwd_kernel64(const KernelArgs args) {
     }
 
     vec8 Qr[QT][KS];  // Q of the current item (AGPRs), filled through LDS (request_q / read_q below)
-
-    // forward_kernel.cuh:150-151 (fp32 product of rsqrt(d) and log2 e)
-    const float c = (float)((double)(1.0f / __builtin_sqrtf((float)D)) * 1.4426950408889634074);
 
     f32x16 O[QT][DTILES];
     float m[QT];
@@ -268,20 +321,9 @@ fa_fwd_kernel64(const KernelArgs args) {
         for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
             for (int t = 0; t < DTILES; ++t) E::mfma_zero_a(O[qt][t], zz);
-        asm volatile("" ::"v"(zz));  // operand registers stay allocated until the last one has issued
+        asm volatile("s_nop 7" ::"v"(zz));  // operand registers stay allocated until the last one has read them
     };
     zero_o();
-
-    // per-lane LDS read offsets
-    //   K A-operand: row 32*nt + r31, chunk (2*ks + hi) ^ (r31 & 15)
-    const int ka_swz = SWZ ? swz_of(r31) : 0;
-    const int ka_base = r31 * ROWB;
-    //   V^T A-operand (transpose read): see header comment
-    const int li = lane & 15, lg = lane >> 4;
-    const int va_base = (4 * (lg >> 1) + (li >> 2)) * 64 + (lg & 1) * 32 + (li & 3) * 8;
-
-    // a row whose keys were all masked so far has m = -inf: exponentiate against 0 instead
-    auto finite_or_zero = [&](float mval) { return (MASK && mval == -__builtin_inff()) ? 0.0f : mval; };
 
     {
         // ---- 64 rows per wave, one wave per SIMD, hand-placed registers and order ----------
@@ -318,7 +360,8 @@ fa_fwd_kernel64(const KernelArgs args) {
         static_assert(DMA && D == 128 && BC == 64 && NT == 2 && NWAVES == 4, "64-row pinned schedule");
         static_assert(TR::kStages == 4, "ring depth");
         constexpr float TAU = 8.0f;
-        constexpr Plan64 plan = make_plan64(((ABL >> 8) & 3) | (MASK ? 4 : 0), (ABL & 1024) ? 20 : 22);
+        constexpr Plan64 plan = make_plan64(((ABL >> 8) & 3) | (MASK ? 4 : 0) | (FAST ? 8 : 0) | ((ABL & 8192) ? 16 : 0),
+                                            (ABL & 1024) ? 20 : ((ABL & 16384) ? 23 : 22));
         static_assert(plan64_ok(plan), "filler plan violates a wait-state distance");
         f32x16 Sa[2][NT], Sb[2][NT];
         u32x4 Pw[2][4] = {};     // P[qt][16-key slice]: B operand of O^T += V^T P^T
@@ -354,8 +397,8 @@ fa_fwd_kernel64(const KernelArgs args) {
         // S(0) with the next item's Q (brought into the spare Q set during the item's first visits), and a
         // seam costs the O epilogue and the reset of the item state only.  After the last item the "next" item is the item itself:
         // the re-fetched tiles land in stages nobody reads.
-        const int n_items = args.n_bh * nq;
-        int item = blockIdx.x;
+        int item = (int)blockIdx.x + ord * (int)gridDim.x;
+        int ord_n = -1;  // ordinal of the next item of this pass, or -1
         const uint16_t *Kc = Kg, *Vc = Vg;   // current item
         uint16_t *Oc = Og;
         int qb_c = qb;
@@ -434,7 +477,10 @@ fa_fwd_kernel64(const KernelArgs args) {
         vec8 ring[RS];
         vec8 Qr2[2][KS];  // the next item's Q (AGPRs), requested during the item's first visit
         float mraw[2];   // row max of the S tile formed by the last visit (the next item's S(0))
-        bool seam = false;  // the first two visits after a seam: the epilogue's stores are in flight
+        // the first two visits after a seam: the epilogue's row stores are in flight in front of the pieces
+        // the counted waits allow -- 16 of them, or fewer (RAG: a wave whose rows reach beyond the sequence
+        // skips stores; counted down to a multiple of 8, which only waits for more)
+        int seam_st = 0;
         // ---- the next item's Q, through LDS -------------------------------------------------------
         // The MFMA wants a lane to hold one Q row's 16-byte chunk; fetched like that from global memory
         // a wave-instruction touches 32 rows (32 cache lines for 1 KiB), and 16 of them in a burst cost
@@ -508,7 +554,7 @@ fa_fwd_kernel64(const KernelArgs args) {
                     return;
                 }
                 const int q8 = has_next ? 8 : 0;
-                const int allow = (it < 2) ? (seam ? 24 : 8) + q8 : 8 + q8;
+                const int allow = (it < 2) ? 8 + seam_st + q8 : 8 + q8;
                 if (allow == 8) asm volatile("s_waitcnt vmcnt(" FA_VM8 ")\n\ts_barrier" ::: "memory");
                 else if (allow == 16) asm volatile("s_waitcnt vmcnt(" FA_VM16 ")\n\ts_barrier" ::: "memory");
                 else if (allow == 24) asm volatile("s_waitcnt vmcnt(" FA_VM24 ")\n\ts_barrier" ::: "memory");
@@ -544,7 +590,7 @@ fa_fwd_kernel64(const KernelArgs args) {
             }
             const unsigned kdst = smem_base + R * TILE + wave * 1024;                        // K(it+4) -> stage of K(it)
             const unsigned vdst = smem_base + V_BASE + ((R + 3) & 3) * TILE + wave * 1024;   // V(it+3) -> stage of V(it-1)
-            if (resc_any) {  // wave-uniform, rare: move the reference max of one or both Q tiles
+            if (!FAST && resc_any) {  // wave-uniform, rare: move the reference max of one or both Q tiles
                 asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");  // MFMA D (O) -> VALU read
 #pragma unroll
                 for (int qt = 0; qt < 2; ++qt) {
@@ -561,12 +607,13 @@ fa_fwd_kernel64(const KernelArgs args) {
                         // RAG: the accumulator copies start here, behind the pads above, and end behind the
                         // multiply: in that variant (and in trace builds) hipcc otherwise hoists the reads out of
                         // this branch to the end of the previous visit, right behind the MFMAs that write the
-                        // tiles (tools/isa_lint64.py, finding AGPR).  The other variants do not need the pins
+                        // tiles (tools/isa_lint64.py, finding AGPR); so it does in the second pass of the speculative
+                        // build.  The other variants do not need the pins
                         // (the lint checks that) and measure 0.3 % faster without them, at 65 more VGPRs.
-                        if constexpr (RAG || FA_RING_SLOTS > 4) asm volatile("" : "+a"(O[qt][t]));
+                        if constexpr (RAG || SPEC || FA_RING_SLOTS > 4) asm volatile("" : "+a"(O[qt][t]));
 #pragma unroll
                         for (int r = 0; r < 16; ++r) O[qt][t][r] *= alpha;
-                        if constexpr (RAG || FA_RING_SLOTS > 4) asm volatile("" : "+a"(O[qt][t]));
+                        if constexpr (RAG || SPEC || FA_RING_SLOTS > 4) asm volatile("" : "+a"(O[qt][t]));
                     }
                 }
             }
@@ -580,8 +627,14 @@ fa_fwd_kernel64(const KernelArgs args) {
                 // exp2(s c - m c), softmax.cuh:51-64.  Scalar f32 forms on purpose: v_pk_fma_f32 /
                 // v_pk_add_f32 here measured -6 % / -12 %; splitting the unit into stages over three
                 // gaps (no dependent pair inside a gap) measured -1.5 %.
-                float p0 = __builtin_fmaf(S_cur[qt][s16 >> 1][r], c, neg_msc[qt]);
-                float p1 = __builtin_fmaf(S_cur[qt][s16 >> 1][r + 1], c, neg_msc[qt]);
+                float p0, p1;
+                if constexpr (ABL & 2048) {  // (timing only: what a pre-scaled Q with -m c fed through the MFMA's C operand would save)
+                    p0 = S_cur[qt][s16 >> 1][r];
+                    p1 = S_cur[qt][s16 >> 1][r + 1];
+                } else {
+                    p0 = __builtin_fmaf(S_cur[qt][s16 >> 1][r], c, neg_msc[qt]);
+                    p1 = __builtin_fmaf(S_cur[qt][s16 >> 1][r + 1], c, neg_msc[qt]);
+                }
                 if (!(ABL & 1)) {
                     p0 = __builtin_amdgcn_exp2f(p0);
                     p1 = __builtin_amdgcn_exp2f(p1);
@@ -600,6 +653,7 @@ fa_fwd_kernel64(const KernelArgs args) {
             auto max_unit = [&](int u) {  // u = 0..31: tile (nt = u>>4, qt = (u>>3)&1), elements 2(u&7), +1
                 const int nt = u >> 4, qt = (u >> 3) & 1, e = 2 * (u & 7), a = u & 1;  // two chains per Q tile
                 if constexpr (ABL & 2) { vm[qt][a] = 0.0f; return; }
+                if constexpr (ABL & 4096) return;  // (timing only: no per-tile row max)
                 // asm forms: fmaxf() on MFMA results makes hipcc canonicalise both inputs first
                 // volatile: pinned to its gap (S_nxt is rewritten next visit).  Not an empty "+v" asm behind
                 // it: hipcc pads an asm that reads what the asm right before it wrote with an s_nop
@@ -615,6 +669,7 @@ fa_fwd_kernel64(const KernelArgs args) {
                 return d;
             };
             auto tail_unit = [&](int k) {
+                if constexpr (FAST || (ABL & 4096)) { if (k < 8) return; }
                 if (k == 1) {
                     asm volatile("v_max_f32 %0, %0, %1" : "+v"(vm[0][0]) : "v"(vm[0][1]));
                     asm volatile("v_max_f32 %0, %0, %1" : "+v"(vm[1][0]) : "v"(vm[1][1]));
@@ -631,7 +686,7 @@ fa_fwd_kernel64(const KernelArgs args) {
                     any01 |= (__ballot(m_pend[qt] > thr[qt]) != 0 ? 1u : 0u) << qt;
                 }
                 if (k == 8) {
-                    resc_any = any01;
+                    if constexpr (!FAST) resc_any = any01;
                     if constexpr (RAG) {  // (a window per tile: no pointer chain)
                         kq = tile_g(Kc, Kn, it + 5);
                         vq = tile_g(Vc, Vn, it + 4);
@@ -639,7 +694,7 @@ fa_fwd_kernel64(const KernelArgs args) {
                         kq = (it + 5 == nkc) ? Kn + (int64_t)(nkn - 1) * tile_stride : kq - tile_stride;
                         vq = (it + 4 == nkc) ? Vn + (int64_t)(nkn - 1) * tile_stride : vq - tile_stride;
                     }
-                    if constexpr (R == 1) seam = false;
+                    if constexpr (R == 1) seam_st = 0;
                 }
             };
             auto tail_step = [&](int k) {  // plan step: 1..8 one unit each; 10..14 the masked plan's merged steps
@@ -750,8 +805,9 @@ fa_fwd_kernel64(const KernelArgs args) {
             return (pos / W) * W + (((it_ / (int)gridDim.x) & 1) ? W - 1 - in_w : in_w);
         };
         auto set_next = [&]() {  // coordinates of the item after `item` (or `item` again)
-            const int nitem = item + (int)gridDim.x;
-            has_next = nitem < n_items;
+            ord_n = next_ord(ord);
+            has_next = ord_n >= 0;
+            const int nitem = (int)blockIdx.x + ord_n * (int)gridDim.x;
             int bh_n;
             item_coords(has_next ? nitem : item, bh_n, qb_n);
             if (causal) {
@@ -851,7 +907,15 @@ fa_fwd_kernel64(const KernelArgs args) {
             const int rsub = lane / CPR, chunk = lane & (CPR - 1);
 #pragma unroll
             for (int qt = 0; qt < 2; ++qt) {
-                const float inv = 1.0f / pair_sum(rs[qt][0] + rs[qt][1]);
+                const float l_row = pair_sum(rs[qt][0] + rs[qt][1]);
+                if constexpr (FAST) {
+                    // every P of the row is <= l: below the limit nothing overflowed on the way (fp32 exp2, the
+                    // 16-bit P, fp32 O); NaN fails the compare too.  A failed item is stored all the same (its
+                    // rows are rewritten by the second pass).
+                    constexpr float kLimit = DT == 5 ? 32768.0f : 1.2676506e30f;  // 2^15 (fp16 P < 65504) / 2^100
+                    if (__ballot(!(l_row < kLimit)) != 0) failed |= 1ull << (ord < 63 ? ord : 63);
+                }
+                const float inv = 1.0f / l_row;
                 char *wp = stage_o + r31 * ROWB + hi * 8;
 #pragma unroll
                 for (int t = 0; t < DTILES; ++t) {
@@ -913,15 +977,36 @@ fa_fwd_kernel64(const KernelArgs args) {
             if (!has_next) break;
             // ---- seam: the last visit left the next item's S(0) in Sa and its row max in mraw; its
             // first tiles are landed or in flight, its first operands sit in the ring
-            item += (int)gridDim.x;
+            const int qb_st = qb_c;  // the item just stored
+            (void)qb_st;
+            ord = ord_n;
+            item = (int)blockIdx.x + ord * (int)gridDim.x;
             Kc = Kn; Vc = Vn; Oc = On; qb_c = qb_n;
             nkc = nkn;
             set_next();
             kq = tile_g(Kc, Kn, 4);  // visit 0 requests K(4), V(3) (for n_kv == 4 that is already the item after)
             vq = tile_g(Vc, Vn, 3);
             if (has_next) request_next_q(0);  // (the staging area is free again: store_item's reads have retired)
-            seam = true;
+            seam_st = 16;
+            if constexpr (RAG) {  // stores the epilogue above issued: one per four rows inside the sequence (16 per 64 rows)
+                const int rows_in = args.seq_len - (qb_st * TR::kBr + wave * TR::kRowsPerWave);
+                seam_st = rows_in >= 64 ? 16 : (rows_in >= 32 ? 8 : 0);
+            }
             resc_any = 0;
+            if constexpr (FAST) {
+                // the row max of the S tile the last visit formed (the next item's S(0)): the speculative
+                // schedule has no row-max units, this is the only one an item needs (behind store_item's pads)
+#pragma unroll
+                for (int qt = 0; qt < 2; ++qt) {
+                    float v0 = vmax2(Sa[qt][0][0], Sa[qt][0][1]), v1 = vmax2(Sa[qt][1][0], Sa[qt][1][1]);
+#pragma unroll
+                    for (int r = 2; r < 16; r += 2) {
+                        v0 = vmax3(v0, Sa[qt][0][r], Sa[qt][0][r + 1]);
+                        v1 = vmax3(v1, Sa[qt][1][r], Sa[qt][1][r + 1]);
+                    }
+                    mraw[qt] = pair_max(vmax2(v0, v1));
+                }
+            }
 #pragma unroll
             for (int qt = 0; qt < 2; ++qt) {
                 m[qt] = mraw[qt];
@@ -933,16 +1018,35 @@ fa_fwd_kernel64(const KernelArgs args) {
             zero_o();
 #ifdef FA_TRACE
             asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(te2)::"memory");
-            if (item - (int)gridDim.x == args.trace_block && lane == 0) {
+            if (item == args.trace_block + (int)gridDim.x && lane == 0) {
                 args.trace[wave * 24 + 21] = te0;
                 args.trace[wave * 24 + 22] = te1;
                 args.trace[wave * 24 + 23] = te2;
             }
 #endif
         }
-        dma_wait();  // nothing may still be landing in the LDS when the workgroup retires
+        dma_wait();  // nothing may still be landing in the LDS when the workgroup retires (or the next pass starts)
         FA_TL();
-        return;
+        return failed;
+    }
+    };  // walk
+
+    if constexpr (SPEC) {
+        unsigned long long failed = walk(BoolTag<true>{}, ~0ull);
+        // every wave's failures -> one workgroup-uniform mask, through the (now idle) LDS
+        barrier();  // every wave has left the rings: its last reads retired, its last pieces landed
+        if (lane == 0) *(unsigned long long *)(smem + wave * 8) = failed;
+        barrier();
+        unsigned long long all = 0;
+#pragma unroll
+        for (int w = 0; w < NWAVES; ++w) all |= *(const unsigned long long *)(smem + w * 8);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)all);
+        const unsigned hi32 = __builtin_amdgcn_readfirstlane((unsigned)(all >> 32));
+        all = ((unsigned long long)hi32 << 32) | lo;
+        barrier();  // (all four slots read before the second pass overwrites K stage 0)
+        if (all) walk(BoolTag<false>{}, all);
+    } else {
+        walk(BoolTag<false>{}, ~0ull);
     }
 }
 

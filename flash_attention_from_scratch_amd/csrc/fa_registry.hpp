@@ -42,7 +42,7 @@ constexpr KernelEntry make_entry() {
                                (kernel_fn)&fa_fwd_kernel64<DT, true>, (kernel_fn)&fa_fwd_kernel64<DT, true, 0, true>};
         else
             return KernelEntry{DT, 64, 4, 64, 1, 1, OPT, 1, 1, 0, 128, TR::kThreads, TR::kLdsBytes, 1,
-                               (kernel_fn)&fa_fwd_kernel64<DT, false>, nullptr};
+                               (kernel_fn)&fa_fwd_kernel64<DT, false, 0, false, OPT>, nullptr};  // opt_softmax: speculative softmax
     } else {
         return KernelEntry{DT, 32 * QT, NWAVES, BC, SWZ, EAGER, OPT, PIPE, DMA, MASK ? 1 : 0, D, TR::kThreads,
                            TR::kLdsBytes, 0,

@@ -461,8 +461,17 @@ def get_kernel_configs(kernels_key=""):
 
 def uses_lazy_rescale(cfg) -> bool:
     """True for the config served by the 64-rows-per-wave device schedule, whose softmax moves
-    its reference max lazily (DESIGN.md 4.6; CPU restatement: oracle blockwise_forward_lazy)."""
+    its reference max lazily (DESIGN.md 3.5; CPU restatement: oracle blockwise_forward_lazy)."""
     return (cfg.d_head, cfg.B_r, cfg.B_c, cfg.n_warps, bool(cfg.mma_double_buffer_loads)) == (128, 256, 64, 4, True)
+
+
+def uses_speculative_softmax(cfg) -> bool:
+    """True for the persistent 64-rows-per-wave config with ``optimized_softmax``: an item is first
+    run against the row max of its first K/V tile only (no per-tile row max, no rescale), its row
+    sums are checked against an overflow limit in the epilogue, and an item that fails is run again
+    by the lazy-rescale schedule (CPU restatement: blockwise_forward_lazy with an
+    infinite threshold)."""
+    return uses_lazy_rescale(cfg) and bool(cfg.optimized_softmax)
 
 
 def best_config(dtype=DType.BF16, seq_len=4096, masked=False) -> FlashForwardKernelConfig:
@@ -477,8 +486,10 @@ def best_config(dtype=DType.BF16, seq_len=4096, masked=False) -> FlashForwardKer
     profiles/r01/ragged_persistent.txt), otherwise 4 waves x 32 rows."""
     pad = (-seq_len) % 256
     if pad == 0 or (masked and seq_len >= 64 and pad * 8 <= seq_len):
+        # optimized_softmax = the speculative softmax (built for the plain form; the masked forms
+        # serve both flag values with the lazy-rescale schedule)
         return FlashForwardKernelConfig(
-            DType(dtype), 128, 256, 64, 4, True, True, True, 0, 0, 0, True, False
+            DType(dtype), 128, 256, 64, 4, True, True, True, 0, 0, 0, True, not masked
         )
     return FlashForwardKernelConfig(
         DType(dtype), 128, 128, 64, 4, True, True, True, 0, 0, 0, True, False

@@ -46,10 +46,15 @@ def lint(path, window=3, raw=2):
                 continue
             ops = l.split()[1:]
             rd = regs(ops[1]) | regs(ops[2])
-            for k in range(1, window + 1):
+            slots, k = 0, 0  # issue slots behind the MFMA: an `s_nop n` fills n + 1 of them
+            while slots < window:
+                k += 1
                 if i + k >= len(code) or code[i + k].startswith("v_mfma"):
                     break
                 n = code[i + k]
+                slots += 1 + (int(n.split()[1]) if n.startswith("s_nop") else 0)
+                if slots > window:
+                    break
                 if n.startswith("v_") or n.startswith("ds_read") or n.startswith("global_load") or n.startswith("scratch_load"):
                     written = regs(n.split()[1])
                     if n.startswith("v_permlane32_swap") or n.startswith("v_swap"):

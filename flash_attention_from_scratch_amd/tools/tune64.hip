@@ -8,7 +8,7 @@
 #include <vector>
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(e_), __LINE__); exit(2); } } while (0)
 
-static uint16_t *q, *k, *v, *o;
+static uint16_t *q, *k, *v, *o, *q_scaled;  // q_scaled = q * c (bit 2048 variants: exp2 of the raw logit)
 static const int B = 16, H = 16, D = 128;
 static int S = 4096;
 static int only_abl = -1;  // argv: only=<abl>
@@ -18,11 +18,14 @@ struct Variant { const char *name; int abl; void (*launch)(const fa::KernelArgs 
 static std::vector<Variant> variants;
 static hipEvent_t e0, e1;
 
+// ABL bit 1 << 20: the speculative-softmax build (SPEC) of the same knobs
 template <int ABL> void launch(const fa::KernelArgs &a) {
-    auto kern = fa::fa_fwd_kernel64<15, false, ABL>;
+    auto kern = fa::fa_fwd_kernel64<15, false, (ABL & 0xfffff), false, ((ABL >> 20) & 1) != 0>;
     static bool init = false;
     if (!init) { CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 163840)); init = true; }
-    hipLaunchKernelGGL(kern, dim3(a.n_bh * a.n_q_blocks < 256 ? a.n_bh * a.n_q_blocks : 256), dim3(256), 163840, 0, a);
+    fa::KernelArgs b = a;
+    if (ABL & 2048) b.q = q_scaled;
+    hipLaunchKernelGGL(kern, dim3(b.n_bh * b.n_q_blocks < 256 ? b.n_bh * b.n_q_blocks : 256), dim3(256), 163840, 0, b);
 }
 template <int ABL> void add(const char *name) {
     if (only_abl >= 0 && ABL != only_abl) return;
@@ -57,7 +60,7 @@ static void time_all() {
 int main(int argc, char **argv) {
     const size_t n = (size_t)B * 4096 * H * D;
     std::vector<uint16_t> h(n);
-    CHECK(hipMalloc(&q, n * 2)); CHECK(hipMalloc(&k, n * 2)); CHECK(hipMalloc(&v, n * 2)); CHECK(hipMalloc(&o, n * 2));
+    CHECK(hipMalloc(&q, n * 2)); CHECK(hipMalloc(&q_scaled, n * 2)); CHECK(hipMalloc(&k, n * 2)); CHECK(hipMalloc(&v, n * 2)); CHECK(hipMalloc(&o, n * 2));
     srand(1);
     bool zeros = false;
     for (int i = 1; i < argc; ++i) {
@@ -71,6 +74,13 @@ int main(int argc, char **argv) {
             uint32_t u; memcpy(&u, &x, 4); h[i] = (uint16_t)(u >> 16);
         }
         CHECK(hipMemcpy(t == 0 ? q : t == 1 ? k : v, h.data(), n * 2, hipMemcpyHostToDevice));
+        if (t == 0) {
+            for (size_t i = 0; i < n; ++i) {
+                uint32_t u = (uint32_t)h[i] << 16; float x; memcpy(&x, &u, 4);
+                x *= 0.12751743f; memcpy(&u, &x, 4); h[i] = (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+            }
+            CHECK(hipMemcpy(q_scaled, h.data(), n * 2, hipMemcpyHostToDevice));
+        }
     }
     CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
 #define X(abl, name) add<abl>(name);

@@ -134,6 +134,22 @@ def blockwise_forward_lazy(q, k, v, B_r, B_c, tau=8.0, n_threads=0):
     return o
 
 
+SPEC_TAU = 1e30  # "never move the reference max": the speculative schedule's first pass
+
+
+def blockwise_for_config(cfg, q, k, v, n_threads=0):
+    """The CPU restatement of the arithmetic the device variant behind `cfg` performs on inputs that
+    do not trip the speculative schedule's overflow check (those rows are redone with tau = 8)."""
+    from flash_helpers import kernel_configs as kc
+
+    if kc.uses_speculative_softmax(cfg):
+        return blockwise_forward_lazy(q, k, v, cfg.B_r, cfg.B_c, tau=SPEC_TAU, n_threads=n_threads)
+    if kc.uses_lazy_rescale(cfg):
+        return blockwise_forward_lazy(q, k, v, cfg.B_r, cfg.B_c, n_threads=n_threads)
+    return blockwise_forward(q, k, v, cfg.B_r, cfg.B_c, optimized_softmax=cfg.optimized_softmax,
+                             n_threads=n_threads)
+
+
 def blockwise_forward_masked(q, k, v, B_r, B_c, causal=False, optimized_softmax=False, n_threads=0):
     """Widened modes (not in the reference): any seq_len, optional causal mask."""
     _check(q, k, v)

@@ -71,11 +71,7 @@ def test_golden_fixtures(cfg, case):
     assert err <= TOL[g["dtype"]], err
     lhs, rhs = fo.tolerance_rule(out, g["o_b16"], g["o_f32"])
     assert lhs <= rhs, (lhs, rhs)
-    if kc.uses_lazy_rescale(cfg):
-        ref = fo.blockwise_forward_lazy(g["q"], g["k"], g["v"], cfg.B_r, cfg.B_c)
-    else:
-        ref = fo.blockwise_forward(g["q"], g["k"], g["v"], cfg.B_r, cfg.B_c,
-                                   optimized_softmax=cfg.optimized_softmax)
+    ref = fo.blockwise_for_config(cfg, g["q"], g["k"], g["v"])
     assert (out.float() - ref.float()).abs().max().item() <= TOL[g["dtype"]]
 
 
@@ -180,7 +176,7 @@ def test_online_softmax_rescale_is_exercised():
 
 def test_64_row_variant_against_its_lazy_rescale_restatement():
     """(B_r 256, B_c 64, 4 waves, buffer) keeps O and l relative to a reference max that moves
-    only past a threshold (DESIGN.md 4.6).  Checked against the CPU restatement of exactly that
+    only past a threshold (DESIGN.md 3.5).  Checked against the CPU restatement of exactly that
     arithmetic and against fp32 eager, on data whose row maxima keep rising along the visit order
     (keys near the start of the sequence are visited last)."""
     for dtype, name in ((torch.bfloat16, kc.DType.BF16), (torch.float16, kc.DType.FP16)):
@@ -212,8 +208,9 @@ def test_persistent_walk_seams(shape):
     require bitwise run-to-run determinism (a cold first run included: the operand-register hazard
     the schedule guards against showed up exactly there)."""
     B, H, S = shape
-    for dtype, name in ((torch.bfloat16, kc.DType.BF16), (torch.float16, kc.DType.FP16)):
-        cfg = kc.FlashForwardKernelConfig(name, 128, 256, 64, 4, True, True, True, 0, 0, 0, True, False)
+    for dtype, name, opt in ((torch.bfloat16, kc.DType.BF16, False), (torch.float16, kc.DType.FP16, False),
+                             (torch.bfloat16, kc.DType.BF16, True), (torch.float16, kc.DType.FP16, True)):
+        cfg = kc.FlashForwardKernelConfig(name, 128, 256, 64, 4, True, True, True, 0, 0, 0, True, opt)
         other = kc.FlashForwardKernelConfig(name, 128, 128, 64, 4, True, True, True, 0, 0, 0, True, False)
         qc = ut.QKVConfig(n_heads=H, d_head=128, batch_size=B, seq_len=S, dtype=dtype, device=torch.device(DEV))
         q, k, v = ut.generate_qkv(qc, seed=B + S)
@@ -225,6 +222,102 @@ def test_persistent_walk_seams(shape):
         sl = slice(B - 1, B)  # the items served last
         eager = ut.py_flash_attention(q[sl], k[sl], v[sl], upcast=True)
         assert (runs[0][sl].float() - eager.float()).abs().max().item() <= TOL[dtype]
+
+
+def _persistent_cfg(name, speculative):
+    return kc.FlashForwardKernelConfig(name, 128, 256, 64, 4, True, True, True, 0, 0, 0, True, speculative)
+
+
+def _sign_vector(seed):
+    gen = torch.Generator().manual_seed(seed)
+    return (torch.randint(0, 2, (128,), generator=gen).float() * 2 - 1).to(DEV)
+
+
+def test_speculative_softmax_against_its_restatement():
+    """optimized_softmax on the persistent kernel = the speculative softmax: the first
+    pass keeps the row max of an item's first tile as the reference for the whole item.  On inputs
+    that do not trip the overflow check the result is the lazy restatement with an infinite
+    threshold; rising logits (P up to ~2^40 in bf16) lose nothing."""
+    for dtype, name in ((torch.bfloat16, kc.DType.BF16), (torch.float16, kc.DType.FP16)):
+        cfg = _persistent_cfg(name, True)
+        assert kc.uses_speculative_softmax(cfg)
+        qc = ut.QKVConfig(n_heads=3, d_head=128, batch_size=2, seq_len=1024, dtype=dtype, device=torch.device(DEV))
+        q, k, v = ut.generate_qkv(qc, seed=91)
+        kk_list = [k]
+        if dtype == torch.bfloat16:  # fp16 takes the second pass on such data (next test)
+            kk_list.append((k.float() * torch.linspace(6, 1, 1024, device=DEV).view(1, -1, 1, 1)).to(dtype))
+        for kk in kk_list:
+            out = flash_attention.forward(cfg, q, kk, v)
+            ref = ut.py_flash_attention(q, kk, v, upcast=True).float()
+            oracle = fo.blockwise_forward_lazy(q.cpu(), kk.cpu(), v.cpu(), 256, 64, tau=fo.SPEC_TAU).float()
+            assert torch.isfinite(out.float()).all()
+            tol = TOL[dtype] * (1 + ref.abs())
+            assert ((out.float() - ref).abs() <= tol).all()
+            assert ((out.float().cpu() - oracle).abs() <= tol.cpu()).all()
+
+
+@pytest.mark.parametrize("rise", ["overflow", "moderate"])
+def test_speculative_softmax_second_pass(rise):
+    """An item whose logits rise far above its first tile's row max fails the epilogue's check and is
+    run again by the lazy-rescale schedule after the walk: its 256 rows must then be BIT-identical to
+    what the lazy-rescale build (optimized_softmax = False) computes, every other item keeps the
+    first pass's result, and everything stays within tolerance of fp32 eager.  `overflow`: q.k c of
+    ~14 000 binades (exp2 overflows fp32: inf / NaN in the first pass) -- both dtypes fail.
+    `moderate`: ~20 binades -- fp16 fails (P would pass 65504), bf16 does not."""
+    a = 30.0 if rise == "overflow" else 1.107
+    for dtype, name in ((torch.bfloat16, kc.DType.BF16), (torch.float16, kc.DType.FP16)):
+        spec, safe = _persistent_cfg(name, True), _persistent_cfg(name, False)
+        # 2 * 3 * 4 = 24 items on 24 workgroups, and 40 * 16 * 1 = 640 items on 256 (ordinals 0..2)
+        for (B, H, S, b_, h_, rows, key) in ((2, 3, 1024, 1, 2, slice(300, 310), 0), (40, 16, 256, 33, 5, slice(17, 19), 70)):
+            qc = ut.QKVConfig(n_heads=H, d_head=128, batch_size=B, seq_len=S, dtype=dtype, device=torch.device(DEV))
+            q, k, v = ut.generate_qkv(qc, seed=7 + B)
+            u = _sign_vector(B).to(dtype)
+            k[b_, key, h_] = a * u           # (key 0 lies in the LAST visited tile, key 70 in the third)
+            q[b_, rows, h_] = a * u
+            out = flash_attention.forward(spec, q, k, v)
+            out_safe = flash_attention.forward(safe, q, k, v)
+            assert torch.isfinite(out.float()).all()
+            qb = rows.start // 256
+            blk = (b_, slice(256 * qb, 256 * qb + 256), h_)
+            takes_second_pass = rise == "overflow" or dtype == torch.float16
+            if takes_second_pass:
+                assert torch.equal(out[blk], out_safe[blk]), (str(dtype), rise, B)
+            ref = ut.py_flash_attention(q, k, v, upcast=True).float()
+            tol = TOL[dtype] * (1 + ref.abs())
+            assert ((out.float() - ref).abs() <= tol).all()
+            assert ((out_safe.float() - ref).abs() <= tol).all()
+            for _ in range(3):  # both passes are deterministic
+                assert torch.equal(flash_attention.forward(spec, q, k, v), out)
+
+
+def test_speculative_softmax_second_pass_beyond_ordinal_63():
+    """A workgroup records failed items in a 64-bit mask of walk ordinals; ordinals >= 63 share the
+    last bit (the second pass then redoes all of them).  130 * 128 items of one Q block each on 256
+    workgroups = 65 rounds: spikes in rounds 2, 63 and 64."""
+    B, H, S = 130, 128, 256
+    dtype, name = torch.bfloat16, kc.DType.BF16
+    spec, safe = _persistent_cfg(name, True), _persistent_cfg(name, False)
+    gen = torch.Generator(device=DEV).manual_seed(12)
+    q, k, v = (torch.randn((B, S, H, 128), dtype=dtype, device=DEV, generator=gen) for _ in range(3))
+    u = _sign_vector(3).to(dtype)
+    # XCD-aware item numbering (one Q block per head): item -> bh = (item >> 3) * 8 + (item & 7) = item
+    spiked = []
+    for item in (2 * 256 + 5, 63 * 256 + 77, 64 * 256 + 255, 64 * 256 + 3):
+        b_, h_ = divmod(item, H)
+        assert b_ < B
+        k[b_, 100, h_] = 30.0 * u
+        q[b_, 40:44, h_] = 30.0 * u
+        spiked.append((b_, h_))
+    out = flash_attention.forward(spec, q, k, v)
+    out_safe = flash_attention.forward(safe, q, k, v)
+    assert torch.isfinite(out.float()).all()
+    for b_, h_ in spiked:
+        assert torch.equal(out[b_, :, h_], out_safe[b_, :, h_])
+    assert (out.float() - out_safe.float()).abs().max().item() <= TOL[dtype]
+    for b_, h_ in spiked + [(0, 0), (B - 1, H - 1), (64, 64)]:
+        sl = (slice(b_, b_ + 1), slice(None), slice(h_, h_ + 1))
+        ref = ut.py_flash_attention(q[sl].contiguous(), k[sl].contiguous(), v[sl].contiguous(), upcast=True)
+        assert ((out[sl].float() - ref.float()).abs() <= TOL[dtype] * (1 + ref.float().abs())).all()
 
 
 def test_error_behaviour_matches_reference():
@@ -290,6 +383,72 @@ def test_full_size_properties(name, dtype, B, H, S):
     other = replace(cfg, B_r=128, B_c=64, n_warps=4, optimized_softmax=False)
     oo = flash_attention.forward(other, q, k, v)
     assert (oo.float() - out.float()).abs().max().item() <= TOL[dtype]
+
+
+# BASELINE.json configs[2]: the bf16 seq_len sweep, batch from the reference's table
+# (py/flash_helpers/test/utils.py:9-17), heads 16 -- every shape at full size
+C2 = [(S, ut.BATCH_SIZE_FOR_SEQ_LEN[S]) for S in (512, 1024, 2048, 4096, 8192, 16384)]
+
+
+@pytest.mark.parametrize("S,B", C2, ids=["c2-S%d-B%d" % sb for sb in C2])
+def test_c2_sweep_shape_properties(S, B):
+    H, dtype = ut.BENCHMARK_N_HEADS, torch.bfloat16
+    cfg = kc.best_config(kc.DType.BF16, S)
+    qc = ut.QKVConfig(n_heads=H, d_head=128, batch_size=B, seq_len=S, dtype=dtype, device=torch.device(DEV))
+    q, k, v = ut.generate_qkv(qc, seed=S)
+    out = flash_attention.forward(cfg, q, k, v)
+    assert torch.isfinite(out.float()).all()
+    # exact linearity in V under a power of two
+    out2 = flash_attention.forward(cfg, q, k, v * 2)
+    assert torch.equal(out2, out * 2)
+    # batch-shard bit-identity (a sub-batch is the same items on other workgroups)
+    sub = flash_attention.forward(cfg, q[B // 2:].contiguous(), k[B // 2:].contiguous(), v[B // 2:].contiguous())
+    assert torch.equal(sub, out[B // 2:])
+    # convex hull of V, constant V
+    vmin = v.float().amin(dim=1, keepdim=True) - 2e-2
+    vmax = v.float().amax(dim=1, keepdim=True) + 2e-2
+    assert ((out.float() >= vmin) & (out.float() <= vmax)).all()
+    oc = flash_attention.forward(cfg, q, k, torch.ones_like(v))
+    assert (oc.float() - 1).abs().max().item() <= 2.0 ** -7
+    # one head against fp32 eager, and everything against another tile shape
+    sl = (slice(B - 1, B), slice(None), slice(3, 4))
+    ref = ut.py_flash_attention(q[sl].contiguous(), k[sl].contiguous(), v[sl].contiguous(), upcast=True)
+    assert (out[sl].float() - ref.float()).abs().max().item() <= TOL[dtype]
+    other = kc.FlashForwardKernelConfig(kc.DType.BF16, 128, 128, 64, 4, True, True, True, 0, 0, 0, True, False)
+    oo = flash_attention.forward(other, q, k, v)
+    assert (oo.float() - out.float()).abs().max().item() <= TOL[dtype]
+    # bitwise run-to-run determinism at full size
+    assert torch.equal(flash_attention.forward(cfg, q, k, v), out)
+
+
+def test_c4_all_eight_shards_on_one_gpu():
+    """BASELINE.json configs[4]: batch 64, heads 32, seq_len 8192 bf16, sharded 8 ways by batch with no
+    exchange (src/flash_attention.cu:110-112: the grid is independent over batch x head x Q block).
+    All eight shards of bench.py's shard_for_rank are walked on the one GPU here: every shard's output
+    must be bit-identical to the same batch entries computed inside a two-shard launch (an item's
+    result may not depend on which launch, workgroup or walk position served it), and a head of every
+    shard is checked against fp32 eager."""
+    import bench
+
+    G, H, S, dtype = 64, 32, 8192, torch.bfloat16
+    cfg = kc.best_config(kc.DType.BF16, S)
+    gen = torch.Generator(device=DEV).manual_seed(64)
+    q, k, v = (torch.randn((G, S, H, 128), dtype=dtype, device=DEV, generator=gen) for _ in range(3))
+    shards = [bench.shard_for_rank(G, 8, r) for r in range(8)]
+    assert shards[0] == (0, 8) and shards[-1] == (56, 64) and all(hi - lo == 8 for lo, hi in shards)
+    outs = []
+    for lo, hi in shards:
+        o = flash_attention.forward(cfg, q[lo:hi], k[lo:hi], v[lo:hi])  # contiguous batch slices, as a rank holds them
+        assert torch.isfinite(o.float()).all()
+        outs.append(o)
+    for r in range(0, 8, 2):  # two-shard recomputation: entries lo .. hi of shards r, r + 1 in one launch
+        lo, hi = shards[r][0], shards[r + 1][1]
+        both = flash_attention.forward(cfg, q[lo:hi], k[lo:hi], v[lo:hi])
+        assert torch.equal(both[:8], outs[r]) and torch.equal(both[8:], outs[r + 1])
+    for r, (lo, hi) in enumerate(shards):
+        sl = (slice(lo + r, lo + r + 1), slice(None), slice(4 * r, 4 * r + 1))
+        ref = ut.py_flash_attention(q[sl].contiguous(), k[sl].contiguous(), v[sl].contiguous(), upcast=True)
+        assert (outs[r][r:r + 1, :, 4 * r:4 * r + 1].float() - ref.float()).abs().max().item() <= TOL[dtype]
 
 
 # ---- scope wideners beyond the reference: causal mask, ragged seq_len (SURVEY 8f-3) -----------
@@ -422,7 +581,7 @@ def test_persistent_walk_random_shapes():
             S = 256 * rng.choice([1, 2, 4])
         causal = bool(trial & 1)
         dtype, name = ((torch.bfloat16, kc.DType.BF16), (torch.float16, kc.DType.FP16))[(trial >> 1) & 1]
-        cfg = kc.FlashForwardKernelConfig(name, 128, 256, 64, 4, True, True, True, 0, 0, 0, True, False)
+        cfg = kc.FlashForwardKernelConfig(name, 128, 256, 64, 4, True, True, True, 0, 0, 0, True, bool(trial & 4))
         other = kc.FlashForwardKernelConfig(name, 128, 128, 64, 4, True, True, True, 0, 0, 0, True, False)
         gen = torch.Generator(device=DEV).manual_seed(trial)
         q, k, v = (torch.randn((B, S, H, 128), dtype=dtype, device=DEV, generator=gen) for _ in range(3))

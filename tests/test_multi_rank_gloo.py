@@ -68,3 +68,30 @@ def test_shard_partition_properties():
             sizes = [hi - lo for lo, hi in spans]
             assert max(sizes) - min(sizes) <= 1
     assert bench.mfma_flop(4, 16, 4096, 128) == 549755813888
+
+
+@pytest.mark.parametrize("n", [1, 2])
+def test_bench_launches_its_own_ranks(n):
+    """`python bench.py --gpus N` with no RANK in the environment starts one rank per GPU itself
+    (rendezvous on 127.0.0.1, gloo for the barrier and the max over ranks) and rank 0 prints ONE JSON
+    line.  --cpu-dry-run replaces the kernel by a sleep so that the launcher, the shards, the
+    barrier-bracketed timing and the per-rank gather run on a CPU-only box."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n), "--steps", "5",
+                          "--warmup", "2", "--cpu-dry-run"], env=env, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == n and rec["steps"] == 5 and rec["warmup"] == 2 and rec["scaling"] == "weak"
+    assert len(rec["per_gpu_tflops"]) == n
+    assert rec["config"]["global_batch"] == 4 * n
+    assert rec["config"]["shards"] == [[4 * r, 4 * r + 4] for r in range(n)]
+    assert 2.0 <= rec["ms_per_step"] < 50.0          # five 2-ms sleeps per rank, max over ranks
+    # the aggregate is N ranks' work over the slowest rank's time: never more than the sum of the ranks
+    assert rec["value"] <= sum(rec["per_gpu_tflops"]) * (1 + 1e-9)

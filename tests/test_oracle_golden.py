@@ -46,7 +46,7 @@ def test_c_blockwise_optimized_softmax_is_same_arithmetic(tag, case):
 
 @pytest.mark.parametrize("tag,case", CASES)
 def test_c_lazy_rescale_restatement_meets_the_reference_bars(tag, case):
-    """The 64-rows-per-wave device variant moves its reference max lazily (DESIGN.md 4.6).  Its
+    """The 64-rows-per-wave device variant moves its reference max lazily (DESIGN.md 3.5).  Its
     CPU restatement must meet the same bars as the reference's arithmetic on the reference's
     fixtures; with a vanishing threshold it rescales whenever a max moves, which IS the
     reference's arithmetic, bit for bit."""
@@ -60,6 +60,37 @@ def test_c_lazy_rescale_restatement_meets_the_reference_bars(tag, case):
     # an (almost) zero threshold rescales whenever a max moves: the reference's arithmetic
     eager_rescale = fo.blockwise_forward_lazy(g["q"], g["k"], g["v"], B_r, 64, tau=1e-30)
     assert torch.equal(eager_rescale, fo.blockwise_forward(g["q"], g["k"], g["v"], B_r, 64))
+
+
+@pytest.mark.parametrize("tag,case", CASES)
+def test_c_speculative_restatement_meets_the_reference_bars(tag, case):
+    """The speculative softmax keeps the row max of the FIRST visited tile as the
+    reference for the whole item -- the lazy restatement with an infinite threshold.  Any reference
+    gives the same real result while nothing overflows, so it must meet the reference's bars too."""
+    g = load_eager_golden(tag, case)
+    S = g["q"].shape[1]
+    B_r = 256 if S % 256 == 0 else 64
+    out = fo.blockwise_forward_lazy(g["q"], g["k"], g["v"], B_r, 64, tau=fo.SPEC_TAU)
+    assert torch.isfinite(out.float()).all()
+    assert (out.float() - g["o_f32"].float()).abs().max().item() <= 2 * ULP[tag]
+    lhs, rhs = fo.tolerance_rule(out, g["o_b16"], g["o_f32"])
+    assert lhs <= rhs
+
+
+def test_c_speculative_restatement_rising_logits_bf16():
+    """bf16 has fp32's exponent range: P far above 1 (row maxima rising ~60 binades along the visit
+    order) loses nothing -- relative rounding is scale-free -- so the never-rescale restatement
+    still matches fp32 eager as closely as the reference's arithmetic does."""
+    torch.manual_seed(5)
+    q, k, v = (torch.randn(1, 1024, 2, 128).to(torch.bfloat16) for _ in range(3))
+    k = (k.float() * torch.linspace(8, 1, 1024).view(1, -1, 1, 1)).to(torch.bfloat16)
+    ref = fo.eager_attention(q, k, v, upcast=True).float()
+    spec = fo.blockwise_forward_lazy(q, k, v, 256, 64, tau=fo.SPEC_TAU).float()
+    exact = fo.blockwise_forward(q, k, v, 256, 64).float()
+    assert torch.isfinite(spec).all()
+    tol = 4 * 2.0 ** -9 * (1 + ref.abs())
+    assert ((spec - ref).abs() <= tol).all()
+    assert ((exact - ref).abs() <= tol).all()
 
 
 def test_c_lazy_rescale_staircase_logits():
