@@ -23,7 +23,7 @@ CONFIG_FIELDS = (
 EXPORTED_SYMBOLS = (
     "fa_init", "fa_fwd_supported", "fa_fwd_lds_bytes", "fa_fwd_launch",
     "fa_fwd_launch_timed", "fa_num_kernels", "fa_get_kernel", "fa_last_error", "fa_version",
-    "fa_fwd_masked_supported", "fa_fwd_launch_masked",
+    "fa_fwd_masked_supported", "fa_fwd_launch_masked", "fa_device_state",
 )
 
 
@@ -78,6 +78,8 @@ def load():
     cfg_p, args_p = ctypes.POINTER(FaFwdConfig), ctypes.POINTER(FaFwdArgs)
     lib.fa_init.restype = ctypes.c_int
     lib.fa_init.argtypes = []
+    lib.fa_device_state.restype = ctypes.c_int
+    lib.fa_device_state.argtypes = [ctypes.c_int] + [ctypes.POINTER(ctypes.c_int)] * 3
     lib.fa_fwd_supported.restype = ctypes.c_int
     lib.fa_fwd_supported.argtypes = [cfg_p]
     lib.fa_fwd_lds_bytes.restype = ctypes.c_int
@@ -149,3 +151,10 @@ def kernels():
 
 def version() -> str:
     return load().fa_version().decode()
+
+
+def device_state(device: int):
+    """(inited, status, num_cus) of libfa_hip.so's per-device setup for `device` (fa_device_state)."""
+    a, b, c = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+    check(load().fa_device_state(int(device), ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
+    return bool(a.value), b.value, c.value

@@ -85,33 +85,38 @@ const fa::KernelEntry *find_kernel(const fa_fwd_config *c, const char **why, boo
     return plain;
 }
 
-std::once_flag g_init_once;
-int g_init_status = FA_OK;
-char g_init_err[256] = "";
+// One-time setup PER DEVICE (the reference's device guard + module init, src/flash_attention.cu:42,142-149):
+// the arch check, the CU count that caps the persistent grid and the > 48 KB dynamic-LDS opt-in of every
+// kernel function all belong to the device that is current at the call, so a process that drives several
+// GPUs gets each of them initialised at its first launch there, and a failure on one device (not a gfx950)
+// does not stick to the others.
+struct DeviceState {
+    std::once_flag once;
+    int status = FA_OK;
+    char err[256] = "";
+    int num_cus = 256;  // persistent variants launch one workgroup per CU
+    int inited = 0;
+};
+constexpr int kMaxDevices = 64;
+DeviceState g_dev[kMaxDevices];
 
-int g_num_cus = 256;  // persistent variants launch one workgroup per CU
-
-void do_init() {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) {
-        g_init_status = FA_ERR_DEVICE;
-        snprintf(g_init_err, sizeof(g_init_err), "no HIP device available");
-        return;
-    }
+void do_init(int dev, DeviceState *st) {
+    st->inited = 1;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, dev) != hipSuccess) {
-        g_init_status = FA_ERR_DEVICE;
-        snprintf(g_init_err, sizeof(g_init_err), "hipGetDeviceProperties failed");
+        st->status = FA_ERR_DEVICE;
+        snprintf(st->err, sizeof(st->err), "hipGetDeviceProperties failed for device %d", dev);
         return;
     }
-    g_num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    st->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
-        g_init_status = FA_ERR_DEVICE;
-        snprintf(g_init_err, sizeof(g_init_err),
-                 "Flash Attention (HIP) requires gfx950 / MI355X (current: %s)", prop.gcnArchName);
+        st->status = FA_ERR_DEVICE;
+        snprintf(st->err, sizeof(st->err),
+                 "Flash Attention (HIP) requires gfx950 / MI355X (device %d: %s)", dev, prop.gcnArchName);
         return;
     }
-    // flash_attention.cu:142-149: opt in to large dynamic shared memory per kernel.
+    // flash_attention.cu:142-149: opt in to large dynamic shared memory per kernel (a per-device
+    // attribute of the function: applied with `dev` current)
     for (const auto &e : registry()) {
         if (e.lds_bytes > 48 * 1024) {
             hipError_t rc = hipFuncSetAttribute((const void *)e.fn,
@@ -121,13 +126,31 @@ void do_init() {
                 rc = hipFuncSetAttribute((const void *)e.fn_ragged, hipFuncAttributeMaxDynamicSharedMemorySize,
                                          e.lds_bytes);
             if (rc != hipSuccess) {
-                g_init_status = FA_ERR_LAUNCH;
-                snprintf(g_init_err, sizeof(g_init_err), "hipFuncSetAttribute(%d B LDS): %s",
-                         e.lds_bytes, hipGetErrorString(rc));
+                st->status = FA_ERR_LAUNCH;
+                snprintf(st->err, sizeof(st->err), "hipFuncSetAttribute(%d B LDS) on device %d: %s",
+                         e.lds_bytes, dev, hipGetErrorString(rc));
                 return;
             }
         }
     }
+}
+
+// State of the CURRENT device, initialised on first use; nullptr (and the thread's error set) if there is none.
+DeviceState *current_device(int *status) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) {
+        (void)hipGetLastError();
+        *status = fail(FA_ERR_DEVICE, "no HIP device available");
+        return nullptr;
+    }
+    if (dev < 0 || dev >= kMaxDevices) {
+        *status = fail(FA_ERR_DEVICE, "device ordinal %d out of range (max %d)", dev, kMaxDevices - 1);
+        return nullptr;
+    }
+    DeviceState *st = &g_dev[dev];
+    std::call_once(st->once, do_init, dev, st);
+    *status = st->status == FA_OK ? FA_OK : fail(st->status, "%s", st->err);
+    return st->status == FA_OK ? st : nullptr;
 }
 
 int validate(const fa_fwd_args *a, const fa::KernelEntry **out, bool masked = false) {
@@ -156,6 +179,19 @@ int validate(const fa_fwd_args *a, const fa::KernelEntry **out, bool masked = fa
     if (a->seq_len > INT32_MAX - 1024 || a->batch * a->n_heads > INT32_MAX ||
         a->batch * a->n_heads * ((a->seq_len + a->cfg.B_r - 1) / a->cfg.B_r) > INT32_MAX)
         return fail(FA_ERR_SHAPE, "problem too large for a 1-D grid");
+    // The kernels keep per-lane offsets inside a tile / Q block in 32 bits (row * seq_stride * 2 bytes for up
+    // to max(B_r, B_c) rows); the batch and head strides only enter 64-bit scalar bases.  All four tensors
+    // share the strides, so a zero or negative one would make rows of O alias.
+    if (a->seq_stride <= 0 || a->batch_stride < 0 || a->head_stride < 0 ||
+        (a->batch > 1 && a->batch_stride == 0) || (a->n_heads > 1 && a->head_stride == 0))
+        return fail(FA_ERR_SHAPE, "strides must be positive (batch %lld, seq %lld, head %lld elements)",
+                    (long long)a->batch_stride, (long long)a->seq_stride, (long long)a->head_stride);
+    {
+        const int64_t rows = a->cfg.B_r > a->cfg.B_c ? a->cfg.B_r : a->cfg.B_c;
+        if (a->seq_stride > (int64_t)0xffffffffLL / (2 * rows))
+            return fail(FA_ERR_SHAPE, "seq_stride %lld too large: %lld rows * seq_stride * 2 bytes must fit 32 bits",
+                        (long long)a->seq_stride, (long long)rows);
+    }
     // 16-byte vector accesses: element strides must be multiples of 8, pointers 16-B aligned.
     if ((a->batch_stride | a->seq_stride | a->head_stride) & 7)
         return fail(FA_ERR_ALIGN, "strides must be multiples of 8 elements (16 bytes)");
@@ -165,7 +201,7 @@ int validate(const fa_fwd_args *a, const fa::KernelEntry **out, bool masked = fa
     return FA_OK;
 }
 
-int launch(const fa_fwd_args *a, const fa::KernelEntry *e, hipStream_t stream, int causal = 0) {
+int launch(const fa_fwd_args *a, const fa::KernelEntry *e, const DeviceState *dev, hipStream_t stream, int causal = 0) {
     fa::KernelArgs ka;
     ka.q = a->q;
     ka.k = a->k;
@@ -191,7 +227,7 @@ int launch(const fa_fwd_args *a, const fa::KernelEntry *e, hipStream_t stream, i
     // walks items blockIdx.x, + gridDim.x, ... itself.
     unsigned n_wg = (unsigned)(ka.n_bh * ka.n_q_blocks);
     if (e->persistent) {
-        const unsigned cap = (unsigned)(g_num_cus & ~7) ? (unsigned)(g_num_cus & ~7) : 8u;
+        const unsigned cap = (unsigned)(dev->num_cus & ~7) ? (unsigned)(dev->num_cus & ~7) : 8u;
         if (n_wg > cap) n_wg = cap;
     }
     const dim3 grid(n_wg);
@@ -207,8 +243,17 @@ int launch(const fa_fwd_args *a, const fa::KernelEntry *e, hipStream_t stream, i
 extern "C" {
 
 int fa_init(void) {
-    std::call_once(g_init_once, do_init);
-    if (g_init_status != FA_OK) return fail(g_init_status, "%s", g_init_err);
+    int rc = FA_OK;
+    (void)current_device(&rc);
+    return rc;
+}
+
+int fa_device_state(int device, int *inited, int *status, int *num_cus) {
+    if (device < 0 || device >= kMaxDevices) return fail(FA_ERR_DEVICE, "device ordinal %d out of range", device);
+    const DeviceState &st = g_dev[device];
+    if (inited) *inited = st.inited;
+    if (status) *status = st.status;
+    if (num_cus) *num_cus = st.num_cus;
     return FA_OK;
 }
 
@@ -226,12 +271,38 @@ int fa_fwd_lds_bytes(const fa_fwd_config *cfg) {
     return e->lds_bytes;
 }
 
+// Enqueue (ms == nullptr) or enqueue between two events on the stream and wait for the second one
+// (flash_attention.cu:119-132).  Whatever was created is destroyed on every path.
+static int launch_maybe_timed(const fa_fwd_args *args, const fa::KernelEntry *e, const DeviceState *dev,
+                              hipStream_t s, int causal, float *ms) {
+    if (!ms) return launch(args, e, dev, s, causal);
+    hipEvent_t start = nullptr, stop = nullptr;
+    hipError_t hrc = hipEventCreate(&start);
+    if (hrc == hipSuccess) hrc = hipEventCreate(&stop);
+    if (hrc == hipSuccess) hrc = hipEventRecord(start, s);
+    int rc = FA_OK;
+    if (hrc == hipSuccess) {
+        rc = launch(args, e, dev, s, causal);
+        hrc = hipEventRecord(stop, s);  // (recorded even if the launch failed: nothing is left pending)
+        if (hrc == hipSuccess) hrc = hipEventSynchronize(stop);
+    }
+    float elapsed = 0.0f;
+    if (hrc == hipSuccess && rc == FA_OK) hrc = hipEventElapsedTime(&elapsed, start, stop);
+    if (start) (void)hipEventDestroy(start);
+    if (stop) (void)hipEventDestroy(stop);
+    if (rc != FA_OK) return rc;
+    if (hrc != hipSuccess) return fail(FA_ERR_LAUNCH, "event timing / kernel execution: %s", hipGetErrorString(hrc));
+    *ms = elapsed;
+    return FA_OK;
+}
+
 int fa_fwd_launch(const fa_fwd_args *args, void *stream) {
     const fa::KernelEntry *e = nullptr;
     int rc = validate(args, &e);
     if (rc != FA_OK) return rc;
-    if ((rc = fa_init()) != FA_OK) return rc;
-    return launch(args, e, (hipStream_t)stream);
+    const DeviceState *dev = current_device(&rc);
+    if (!dev) return rc;
+    return launch(args, e, dev, (hipStream_t)stream);
 }
 
 int fa_fwd_launch_timed(const fa_fwd_args *args, void *stream, float *ms) {
@@ -239,23 +310,9 @@ int fa_fwd_launch_timed(const fa_fwd_args *args, void *stream, float *ms) {
     const fa::KernelEntry *e = nullptr;
     int rc = validate(args, &e);
     if (rc != FA_OK) return rc;
-    if ((rc = fa_init()) != FA_OK) return rc;
-    hipStream_t s = (hipStream_t)stream;
-    hipEvent_t start, stop;
-    if (hipEventCreate(&start) != hipSuccess || hipEventCreate(&stop) != hipSuccess)
-        return fail(FA_ERR_LAUNCH, "hipEventCreate failed");
-    (void)hipEventRecord(start, s);
-    rc = launch(args, e, s);
-    (void)hipEventRecord(stop, s);
-    hipError_t hrc = hipEventSynchronize(stop);
-    float elapsed = 0.0f;
-    if (hrc == hipSuccess) hrc = hipEventElapsedTime(&elapsed, start, stop);
-    (void)hipEventDestroy(start);
-    (void)hipEventDestroy(stop);
-    if (rc != FA_OK) return rc;
-    if (hrc != hipSuccess) return fail(FA_ERR_LAUNCH, "kernel execution: %s", hipGetErrorString(hrc));
-    *ms = elapsed;
-    return FA_OK;
+    const DeviceState *dev = current_device(&rc);
+    if (!dev) return rc;
+    return launch_maybe_timed(args, e, dev, (hipStream_t)stream, 0, ms);
 }
 
 int fa_fwd_masked_supported(const fa_fwd_config *cfg) {
@@ -268,24 +325,9 @@ int fa_fwd_launch_masked(const fa_fwd_args *args, int causal, void *stream, floa
     const fa::KernelEntry *e = nullptr;
     int rc = validate(args, &e, true);
     if (rc != FA_OK) return rc;
-    if ((rc = fa_init()) != FA_OK) return rc;
-    hipStream_t s = (hipStream_t)stream;
-    if (!ms) return launch(args, e, s, causal != 0);
-    hipEvent_t start, stop;
-    if (hipEventCreate(&start) != hipSuccess || hipEventCreate(&stop) != hipSuccess)
-        return fail(FA_ERR_LAUNCH, "hipEventCreate failed");
-    (void)hipEventRecord(start, s);
-    rc = launch(args, e, s, causal != 0);
-    (void)hipEventRecord(stop, s);
-    hipError_t hrc = hipEventSynchronize(stop);
-    float elapsed = 0.0f;
-    if (hrc == hipSuccess) hrc = hipEventElapsedTime(&elapsed, start, stop);
-    (void)hipEventDestroy(start);
-    (void)hipEventDestroy(stop);
-    if (rc != FA_OK) return rc;
-    if (hrc != hipSuccess) return fail(FA_ERR_LAUNCH, "kernel execution: %s", hipGetErrorString(hrc));
-    *ms = elapsed;
-    return FA_OK;
+    const DeviceState *dev = current_device(&rc);
+    if (!dev) return rc;
+    return launch_maybe_timed(args, e, dev, (hipStream_t)stream, causal != 0, ms);
 }
 
 int fa_num_kernels(void) { return (int)registry().size(); }
@@ -323,6 +365,6 @@ int fa_get_kernel(int index, fa_kernel_info *out) {
 
 const char *fa_last_error(void) { return g_err; }
 
-const char *fa_version(void) { return "fa_hip 0.1 gfx950"; }
+const char *fa_version(void) { return "fa_hip 0.2 gfx950"; }
 
 }  // extern "C"

@@ -8,9 +8,12 @@ reading them.  This script disassembles nothing: it reads the `-S` output and re
         reads as A or B operand (seen on hardware as rare one-ulp run-to-run differences);
   RAW   an MFMA reads as A / B a VGPR written by a VALU instruction fewer than `--raw` instructions
         earlier (v_cvt_pk -> MFMA needs wait states hipcc does not insert for asm);
-  AGPR  compiler-generated v_accvgpr_* inside the main loop (accumulators must stay put).
+  AGPR  compiler-generated v_accvgpr_* inside the main loop (accumulators must stay put);
+  M0    an instruction hipcc itself emitted (outside ;;#ASMSTART / ;;#ASMEND) that reads or writes M0 in
+        a fa_fwd_kernel64 function: the DMA pieces leave their LDS destination in M0 across statements.
 
-Usage: python isa_lint64.py kernel.s [--window 3] [--raw 2]
+Usage: python isa_lint64.py kernel.s [--window 3] [--raw 2] [--only fa_fwd_kernel64]
+The library build runs it over the 64-rows-per-wave slices (csrc/Makefile) and fails on any finding.
 """
 import argparse
 import re
@@ -26,20 +29,53 @@ def regs(tok):
     return {int(m.group(1))} if m else set()
 
 
-def lint(path, window=3, raw=2):
-    lines = [l.strip() for l in open(path).read().split("\n")]
-    findings = []
-    kernels = []
-    cur = []
-    for l in lines:
-        if not l or l.startswith(";") or l.startswith("."):
+M0_USERS = re.compile(r"\bm0\b|^s_movrel|^v_movrel|^s_set_gpr_idx")
+
+
+def split_kernels(path):
+    """-> [(function name, [instruction], [index of the instructions hipcc itself emitted])]: one entry per
+    function of the `-S` output; instructions between ;;#ASMSTART and ;;#ASMEND are the source's own."""
+    kernels, cur, own, name, in_asm = [], [], [], "", False
+    for raw_line in open(path).read().split("\n"):
+        l = raw_line.strip()
+        if l.startswith(";;#ASMSTART"):
+            in_asm = True
+        elif l.startswith(";;#ASMEND"):
+            in_asm = False
+        m = re.match(r"^(_Z\w+):", l)
+        if m and not cur:
+            name = m.group(1)
+        if not l or l.startswith(";") or l.startswith(".") or l.endswith(":"):
             if l.startswith(".Lfunc_end"):
-                kernels.append(cur)
-                cur = []
+                kernels.append((name, cur, own))
+                cur, own, name = [], [], ""
             continue
+        if not in_asm:
+            own.append(len(cur))
         cur.append(l)
     if cur:
-        kernels.append(cur)
+        kernels.append((name, cur, own))
+    return kernels
+
+
+def lint(path, window=3, raw=2, only=None):
+    """Findings [(kind, kernel index, instruction index, mfma / context, offender)].  only: restrict to
+    functions whose (mangled) name contains this string."""
+    findings = []
+    kernels = []
+    for name, code, own in split_kernels(path):
+        if only and only not in name:
+            continue
+        kidx = len(kernels)
+        kernels.append(code)
+        # M0: the hand-placed DMA writes M0 (the LDS destination) in one asm statement and reads it in a
+        # later one, with no save / restore.  That is only sound while hipcc itself never touches M0 in
+        # the function (it is compiler-reserved and NOT preserved around asm statements): no dynamic
+        # register indexing (s_set_gpr_idx, movrel), no sendmsg / LDS-DMA builtin that needs it.
+        if "fa_fwd_kernel64" in name or not name:
+            for i in own:
+                if M0_USERS.search(code[i]):
+                    findings.append(("M0", kidx, i, name, code[i]))
     for kidx, code in enumerate(kernels):
         for i, l in enumerate(code):
             if not l.startswith("v_mfma"):
@@ -98,8 +134,9 @@ if __name__ == "__main__":
     ap.add_argument("asm")
     ap.add_argument("--window", type=int, default=3)
     ap.add_argument("--raw", type=int, default=2)
+    ap.add_argument("--only", default=None, help="only functions whose mangled name contains this")
     a = ap.parse_args()
-    f = lint(a.asm, a.window, a.raw)
+    f = lint(a.asm, a.window, a.raw, a.only)
     for kind, k, i, m, o in f:
         print(f"{kind} kernel#{k} @{i}: {m}   <->   {o}")
     print(f"{len(f)} finding(s)")

@@ -27,7 +27,7 @@
  * cudaGetLastError), launch failures are reported.
  *
  * Threading / streams: no internal threads, no global mutable state besides the
- * const kernel registry and one-time function attributes.  Launches are
+ * const kernel registry and the one-time per-device setup (fa_init).  Launches are
  * asynchronous on the caller's stream; fa_fwd_launch_timed blocks on its stop event.
  */
 #ifndef FA_HIP_H
@@ -74,7 +74,9 @@ typedef struct fa_fwd_config {
  * One forward call.  q, k, v, o are DEVICE pointers to (batch, seq_len, n_heads,
  * d_head) tensors of the 16-bit dtype in cfg.dtype whose last dimension is
  * contiguous; the three strides are in ELEMENTS and shared by all four tensors
- * (flash_attention.cuh:14-19).  o may alias none of the inputs.
+ * (flash_attention.cuh:14-19).  o may alias none of the inputs.  Strides must be positive multiples of 8;
+ * seq_stride additionally <= (2^32 - 1) / (2 max(B_r, B_c)) (32-bit per-lane offsets inside a tile); the
+ * batch and head strides are used in 64-bit arithmetic.
  */
 typedef struct fa_fwd_args {
     const void *q;
@@ -103,8 +105,15 @@ typedef struct fa_kernel_info {
                                 (256, 64, 4) kernel, which needs seq_len >= B_c when seq_len % B_r != 0 */
 } fa_kernel_info;
 
-/* One-time setup for the current device (idempotent; also called lazily). */
+/* One-time setup for the CURRENT device (idempotent; also called lazily by every launch): arch check,
+ * CU count, the > 48 KB dynamic-LDS opt-in of every kernel function.  State is kept per device ordinal,
+ * so a host that drives several GPUs from one process initialises each at its first call there
+ * (the reference: device guard src/flash_attention.cu:42 + module init :142-149). */
 int fa_init(void);
+
+/* Introspection of that per-device state (tests): has `device` been initialised, with which status,
+ * and how many CUs cap the persistent grid there.  Any out pointer may be NULL. */
+int fa_device_state(int device, int *inited, int *status, int *num_cus);
 
 /* 1 if a device kernel exists for cfg, else 0 (never negative). */
 int fa_fwd_supported(const fa_fwd_config *cfg);

@@ -57,6 +57,24 @@ def test_library_loaded_and_device_is_gfx950():
         assert 0 < info.num_regs <= 512
 
 
+def test_c_abi_per_device_state():
+    """libfa_hip.so keeps its one-time setup per device ordinal (arch check, CU count, the > 48 KB LDS
+    opt-in of every kernel function): the current device is initialised by the first call made on it."""
+    inited, status, num_cus = _capi.device_state(0)
+    assert inited and status == 0 and num_cus == torch.cuda.get_device_properties(0).multi_processor_count
+    if torch.cuda.device_count() < 2:
+        pytest.skip("the second half needs two GPUs: a launch on device 1 after device 0 was initialised")
+    cfg = kc.best_config(kc.DType.BF16, 512)
+    outs = []
+    for dev in (0, 1):
+        gen = torch.Generator(device=f"cuda:{dev}").manual_seed(3)
+        q, k, v = (torch.randn((2, 512, 4, 128), dtype=torch.bfloat16, device=f"cuda:{dev}", generator=gen)
+                   for _ in range(3))
+        outs.append(flash_attention.forward(cfg, q, k, v).cpu())   # (the shim launches under q's device)
+        assert _capi.device_state(dev)[:2] == (True, 0)
+    assert torch.equal(outs[0], outs[1])
+
+
 @pytest.mark.parametrize("cfg", VARIANTS, ids=str)
 @pytest.mark.parametrize("case", ["a", "b", "c"])
 def test_golden_fixtures(cfg, case):
@@ -565,6 +583,37 @@ def test_persistent_ragged_lengths(S):
                 qs, ks, vs = (t[b:b + 1, :, h:h + 1].contiguous() for t in (qc, kc_, vc))
                 eager = fo.eager_attention_masked(qs, ks, vs, causal)
                 assert _rel_ok(runs[0][b:b + 1, :, h:h + 1], eager, dtype), (str(cfg), S, causal, b, h)
+
+
+@pytest.mark.parametrize("S", [4000, 2080, 1990])
+def test_ragged_item_seams_under_load(S):
+    """At an item seam the counted DMA waits allow the epilogue's row stores to stay in flight in front
+    of the next item's pieces.  A wave whose rows reach beyond the sequence issues FEWER than 16 stores
+    (S = 4000: waves 2 and 3 of the last Q block issue 8 and 0; S = 2080: 8 / 0 / 0 / 0 for waves 0..3;
+    S = 1990: 16 / 16 / 16 / 2), and a wait that assumed 16 would publish K / V stages whose pieces had not
+    landed -- a timing-dependent wrong result.  Many more items than workgroups (every workgroup crosses
+    ragged seams, with new-head pages at most of them), cold and warm runs, full and causal: bitwise
+    repeatable and equal to the 32-rows-per-wave masked kernel within tolerance on EVERY row."""
+    B, H = 6, 24
+    n_qb = (S + 255) // 256
+    assert B * H * n_qb > 4 * 256
+    for dtype, name in ((torch.bfloat16, kc.DType.BF16), (torch.float16, kc.DType.FP16)):
+        cfg = kc.FlashForwardKernelConfig(name, 128, 256, 64, 4, True, True, True, 0, 0, 0, True, False)
+        other = kc.FlashForwardKernelConfig(name, 128, 128, 64, 4, True, True, True, 0, 0, 0, True, False)
+        gen = torch.Generator(device=DEV).manual_seed(S)
+        q, k, v = (torch.randn((B, S, H, 128), dtype=dtype, device=DEV, generator=gen) for _ in range(3))
+        flush = torch.empty(600 * 1024 * 1024, dtype=torch.int8, device=DEV)
+        for causal in (False, True):
+            ref = flash_attention.forward_ex(other, q, k, v, causal=causal)
+            runs = []
+            for rep in range(6):
+                if rep % 2 == 0:
+                    flush.zero_()  # cold caches and TLBs: late landings at the seams
+                runs.append(flash_attention.forward_ex(cfg, q, k, v, causal=causal))
+            torch.cuda.synchronize()
+            assert all(torch.equal(runs[0], r) for r in runs[1:]), (S, str(dtype), causal)
+            assert torch.isfinite(runs[0].float()).all()
+            assert _rel_ok(runs[0], ref, dtype) or (runs[0].float() - ref.float()).abs().max().item() <= 2 * TOL[dtype]
 
 
 def test_persistent_walk_random_shapes():

@@ -229,3 +229,22 @@ def test_ragged_window_rule_covers_every_key_exactly_once():
                 seen[r0 + key_in_window] += 1
         assert seen == [1] * S, S
 
+
+
+def test_per_device_init_bookkeeping_without_a_gpu():
+    """fa_init keeps its state per device ordinal (a host may drive several GPUs from one process) and a
+    box with no device gets FA_ERR_DEVICE on EVERY call -- nothing is cached for a device that could not
+    even be named.  (The multi-GPU side is a -m gpu test that needs two devices.)"""
+    lib = _capi.load()
+    if torch.cuda.is_available():
+        pytest.skip("CPU-tier bookkeeping test")
+    for _ in range(2):
+        assert lib.fa_init() == -7  # FA_ERR_DEVICE
+        assert b"no HIP device" in lib.fa_last_error()
+    for dev in (0, 1, 63):
+        inited, status, num_cus = _capi.device_state(dev)
+        assert (inited, status) == (False, 0) and num_cus == 256
+    with pytest.raises(RuntimeError):
+        _capi.device_state(64)
+    with pytest.raises(RuntimeError):
+        _capi.device_state(-1)
