@@ -215,6 +215,37 @@ def test_64_row_variant_against_its_lazy_rescale_restatement():
             assert ((out.float().cpu() - oracle).abs() <= tol.cpu()).all()
 
 
+@pytest.mark.parametrize("step", [7.9, 8.1, 3.95])
+def test_row_max_rising_by_about_the_threshold_every_tile(step):
+    """Adversarial for the lazy rescale (TAU = 8): every visited tile lifts the row max by `step`
+    binades -- just under the threshold (P reaches ~2^7.9 before the reference max moves, every
+    second tile: the worst-case P magnitude, in fp16 too), just over it (a rescale at every tile), and
+    half of it.  The logits are exact by construction (q = a u, k_j = b_j u with u in {-1, +1}^128),
+    the other keys of a tile are random, and V is N(0,1).  Lazy and speculative builds, both dtypes
+    (16 tiles x 7.9 binades also overflows the speculative first pass in both: second pass), against fp32
+    eager and the lazy restatement."""
+    S, H, B = 1024, 2, 1
+    c = 1.4426950408889634 / 128 ** 0.5
+    for dtype, name in ((torch.bfloat16, kc.DType.BF16), (torch.float16, kc.DType.FP16)):
+        gen = torch.Generator(device=DEV).manual_seed(int(step * 100))
+        q, k, v = (torch.randn((B, S, H, 128), dtype=dtype, device=DEV, generator=gen) for _ in range(3))
+        u = _sign_vector(11)
+        q[0, 100:132, 0] = (0.25 * u).to(dtype)           # rows 100..131 of head 0: q.k_j = 32 b_j exactly
+        for t in range(S // 64):                            # tile t is visited at position 15 - t
+            rise = step * (S // 64 - 1 - t)                 # binades above the first-visited tile's planted key
+            k[0, 64 * t + 5, 0] = ((rise / c) / 32.0 * u).to(dtype)
+        ref = ut.py_flash_attention(q, k, v, upcast=True).float()
+        for opt in (False, True):
+            cfg = _persistent_cfg(name, opt)
+            out = flash_attention.forward(cfg, q, k, v)
+            assert torch.isfinite(out.float()).all(), (str(dtype), opt)
+            tol = TOL[dtype] * (1 + ref.abs())
+            assert ((out.float() - ref).abs() <= tol).all(), (str(dtype), opt, step)
+        lazy = fo.blockwise_forward_lazy(q.cpu(), k.cpu(), v.cpu(), 256, 64).float()
+        out = flash_attention.forward(_persistent_cfg(name, False), q, k, v)
+        assert ((out.float().cpu() - lazy).abs() <= (TOL[dtype] * (1 + ref.abs())).cpu()).all()
+
+
 @pytest.mark.parametrize("shape", [(8, 16, 1024), (32, 16, 256), (40, 16, 256), (5, 7, 512), (3, 16, 2048)],
                          ids=lambda s: "B%d_H%d_S%d" % s)
 def test_persistent_walk_seams(shape):

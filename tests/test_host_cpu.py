@@ -248,3 +248,50 @@ def test_per_device_init_bookkeeping_without_a_gpu():
         _capi.device_state(64)
     with pytest.raises(RuntimeError):
         _capi.device_state(-1)
+
+
+def test_the_two_distributions_build_and_import_outside_the_repo(tmp_path):
+    """Packaging (the reference's setup.py:45-75 + py/setup.py:6-9): `flash_attention` (+ the
+    `flash_attention_kernels` module and libfa_hip.so as package data) and `flash_helpers` build as
+    wheels, and the reference's import names resolve from the unpacked wheels alone -- with the
+    repository NOT on sys.path -- down to the loaded C-ABI library."""
+    import shutil
+    import sys
+    import zipfile
+
+    src = tmp_path / "src"
+    shutil.copytree(ROOT, src, ignore=shutil.ignore_patterns(".git", "gpurun_out", "__pycache__", "build", "*.o",
+                                                             ".pytest_cache", ".hypothesis", "profiles", "golden"))
+    out = tmp_path / "whl"
+    env = dict(os.environ, FA_SKIP_NATIVE_BUILD="1")  # the library is already built in-tree (build())
+    for where in (src, src / "py"):
+        res = subprocess.run([sys.executable, "-m", "pip", "wheel", ".", "--no-build-isolation", "--no-deps", "-q",
+                              "-w", str(out)], cwd=where, env=env, capture_output=True, text=True, timeout=600)
+        assert res.returncode == 0, res.stderr[-3000:]
+    site = tmp_path / "site"
+    names = {}
+    for whl in sorted(out.glob("*.whl")):
+        with zipfile.ZipFile(whl) as z:
+            names[whl.name.split("-")[0]] = set(z.namelist())
+            z.extractall(site)
+    assert set(names) == {"flash_attention", "flash_helpers"}
+    fa = names["flash_attention"]
+    assert {"flash_attention/__init__.py", "flash_attention_kernels.py",
+            "flash_attention_from_scratch_amd/lib/libfa_hip.so", "flash_attention_from_scratch_amd/_capi.py"} <= fa
+    assert {"flash_helpers/kernel_configs.py", "flash_helpers/test/utils.py", "flash_helpers/test/test.py"} <= names["flash_helpers"]
+    probe = ("import sys; assert not any(p.rstrip('/') == %r for p in sys.path)\n"
+             "import flash_attention, flash_attention_kernels\n"
+             "from flash_helpers.kernel_configs import get_kernels_to_build, best_config\n"
+             "from flash_helpers.test.utils import BATCH_SIZE_FOR_SEQ_LEN\n"
+             "import flash_helpers.test.test as t\n"
+             "from flash_attention_from_scratch_amd import _capi\n"
+             "assert _capi.LIB_PATH.startswith(%r), _capi.LIB_PATH\n"
+             "assert _capi.load().fa_num_kernels() > 40 and all(_capi.supported(c) for c in get_kernels_to_build())\n"
+             "assert hasattr(flash_attention, 'forward') and hasattr(flash_attention, 'forward_timed')\n"
+             "print(len(get_kernels_to_build()), flash_attention.__file__)\n") % (ROOT, str(site))
+    env = {k: v for k, v in os.environ.items() if k != "PYTHONPATH"}
+    env["PYTHONPATH"] = str(site)
+    res = subprocess.run([sys.executable, "-c", probe], cwd=str(tmp_path), env=env, capture_output=True, text=True,
+                         timeout=300)
+    assert res.returncode == 0, res.stderr[-3000:]
+    assert res.stdout.split()[0] == "80" and str(site) in res.stdout
