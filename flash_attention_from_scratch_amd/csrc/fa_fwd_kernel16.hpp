@@ -29,13 +29,23 @@ struct FwdTraits16 {
     static constexpr int kLdsBytes = kKvBytes > kOutBytes ? kKvBytes : kOutBytes;
 };
 
+// Reductions over the four lanes that share a query column (lane, ^16, ^32, ^48) by the gfx950 row
+// exchanges, in the vector ALU: v_permlane16_swap trades the odd 16-lane rows of its first operand for
+// the even rows of its second, v_permlane32_swap the upper half for the lower half, so with the same
+// value in both operands the two results are {own pair's even, own pair's odd} row / {lower, upper}
+// half.  (__shfl_xor lowers to ds_bpermute: an LDS-path round trip on the row max -> rescale -> exp2
+// critical path of every tile.)
 static FA_DEV float quad_max(float x) {
-    x = fmaxf(x, __shfl_xor(x, 16, 64));
-    return fmaxf(x, __shfl_xor(x, 32, 64));
+    auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    x = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+    auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
 }
 static FA_DEV float quad_sum(float x) {
-    x += __shfl_xor(x, 16, 64);
-    return x + __shfl_xor(x, 32, 64);
+    auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    x = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
 
 template <int DT, int NWAVES, int BC, bool SWZ, bool EAGER, bool OPT>

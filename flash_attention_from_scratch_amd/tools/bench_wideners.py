@@ -4,7 +4,12 @@ kernel and torch SDPA on the same device.  FLOPs: full = 4BHS^2d; causal = half 
 (the masked upper triangle is not computed: KV tiles above the diagonal are skipped)."""
 import torch
 
-import flash_attention
+import os as _os
+import sys as _sys
+
+_sys.path.insert(0, _os.path.abspath(_os.path.join(_os.path.dirname(__file__), _os.pardir, _os.pardir)))  # repo root: runs without PYTHONPATH
+
+import flash_attention  # noqa: E402
 from flash_helpers import kernel_configs as kc
 from flash_helpers.test import utils as ut
 

@@ -5,7 +5,12 @@ headline number is set by the chip's power management rather than by the kernel
 random N(0,1) 1074-1105 TFLOP/s, all-zero inputs 1531 TFLOP/s (+40 %)."""
 import torch
 
-import flash_attention
+import os as _os
+import sys as _sys
+
+_sys.path.insert(0, _os.path.abspath(_os.path.join(_os.path.dirname(__file__), _os.pardir, _os.pardir)))  # repo root: runs without PYTHONPATH
+
+import flash_attention  # noqa: E402
 from flash_helpers import kernel_configs as kc
 
 

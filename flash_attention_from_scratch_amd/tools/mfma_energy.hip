@@ -1,0 +1,106 @@
+// mfma_energy.hip -- what the matrix pipe sustains under the chip's power budget as a function of HOW the
+// MFMAs are issued, one wave per SIMD, registers only (no memory traffic): accumulator order (round robin
+// over 4 / over 2 / chained on one), operand reuse (A shared by consecutive pairs, as the 64-row kernel
+// does), register file of the accumulator and of B (VGPR / AGPR), MFMA shape, and operand data (N(0,1),
+// P-like positive values, zeros).  Every variant runs ~30 ms per launch so the clock governor settles.
+// Build: hipcc --offload-arch=gfx950 -O3 mfma_energy.hip -o mfma_energy
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s line %d\n", hipGetErrorString(e_), __LINE__); exit(2); } } while (0)
+
+template <int MODE>
+__global__ void __launch_bounds__(256, 1) mfma_loop(const bf16x8 *ab, float *out, int iters) {
+    const int lane = threadIdx.x & 63;
+    bf16x8 a[8], b[8];
+    for (int i = 0; i < 8; ++i) {
+        a[i] = ab[(i * 64 + lane)];
+        b[i] = ab[((8 + i) * 64 + lane)];
+    }
+    f32x16 c[4] = {};
+    f32x4 d[8] = {};
+    for (int it = 0; it < iters; ++it) {
+        if constexpr (MODE == 0) {  // round robin over 4 accumulators, new A and B every MFMA
+#pragma unroll
+            for (int u = 0; u < 32; ++u) c[u & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[u & 7], b[(u >> 1) & 7], c[u & 3], 0, 0, 0);
+        } else if constexpr (MODE == 1) {  // the 64-row kernel's QK^T order: A shared by a pair, B alternates, 4 accumulators
+#pragma unroll
+            for (int s = 0; s < 16; ++s)
+#pragma unroll
+                for (int qt = 0; qt < 2; ++qt) c[(s & 1) * 2 + qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s & 7], b[qt * 4 + ((s >> 1) & 3)], c[(s & 1) * 2 + qt], 0, 0, 0);
+        } else if constexpr (MODE == 2) {  // chained: 8 consecutive MFMAs on one accumulator
+#pragma unroll
+            for (int u = 0; u < 32; ++u) c[u >> 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[u & 7], b[(u * 3) & 7], c[u >> 3], 0, 0, 0);
+        } else if constexpr (MODE == 3) {  // round robin over 2
+#pragma unroll
+            for (int u = 0; u < 32; ++u) c[u & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[u & 7], b[(u >> 1) & 7], c[u & 1], 0, 0, 0);
+        } else if constexpr (MODE == 4) {  // accumulators and B in AGPRs (the kernel's P.V / QK^T register files)
+#pragma unroll
+            for (int u = 0; u < 32; ++u)
+                asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c[u & 3]) : "v"(a[u & 7]), "a"(b[(u >> 1) & 7]));
+        } else if constexpr (MODE == 5) {  // same A and same B for 4 consecutive MFMAs (maximal operand reuse)
+#pragma unroll
+            for (int u = 0; u < 32; ++u) c[u & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[u >> 2], b[u >> 2], c[u & 3], 0, 0, 0);
+        } else if constexpr (MODE == 6) {  // 16x16x32: same flops per cycle, a quarter of the accumulator per instruction
+#pragma unroll
+            for (int u = 0; u < 64; ++u) d[u & 7] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[u & 7], b[(u >> 1) & 7], d[u & 7], 0, 0, 0);
+        } else if constexpr (MODE == 7) {  // C = 0 (no accumulator read) on every MFMA: what the C operand costs
+#pragma unroll
+            for (int u = 0; u < 32; ++u) {
+                f32x16 z = {};
+                c[u & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[u & 7], b[(u >> 1) & 7], z, 0, 0, 0);
+                asm volatile("" : "+v"(c[u & 3]));
+            }
+        }
+    }
+    float s = 0;
+    for (int i = 0; i < 4; ++i)
+        for (int r = 0; r < 16; ++r) s += c[i][r];
+    for (int i = 0; i < 8; ++i)
+        for (int r = 0; r < 4; ++r) s += d[i][r];
+    if (s == 12345.678f) out[threadIdx.x] = s;  // keep the chain alive
+}
+
+template <int MODE> static double run(const bf16x8 *d_ab, float *d_out, int iters) {
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    double sum = 0;
+    for (int rep = 0; rep < 5; ++rep) {
+        CHECK(hipEventRecord(e0));
+        hipLaunchKernelGGL(mfma_loop<MODE>, dim3(256), dim3(256), 0, 0, d_ab, d_out, iters);
+        CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+        float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+        if (rep >= 2) sum += ms;
+    }
+    const double flop = 256.0 * 4 * iters * 32.0 * 2.0 * 32 * 32 * 16;
+    return flop / (sum / 3 * 1e-3) / 1e12;
+}
+
+int main() {
+    std::vector<uint16_t> h(16 * 64 * 8);
+    bf16x8 *d_ab; float *d_out;
+    CHECK(hipMalloc(&d_ab, h.size() * 2)); CHECK(hipMalloc(&d_out, 4096));
+    srand(3);
+    const int iters = 40000;  // 40000 * 32 MFMAs * 32 cycles = 41 M cycles ~ 20-25 ms
+    const char *names[4] = {"zeros        ", "normal(0,1)  ", "A normal, B P", "uniform +-1.7"};
+    for (int mode = 0; mode < 4; ++mode) {
+        for (size_t i = 0; i < h.size(); ++i) {
+            const float u1 = (rand() + 1.0f) / (RAND_MAX + 2.0f), u2 = (rand() + 1.0f) / (RAND_MAX + 2.0f);
+            const float n = sqrtf(-2.0f * logf(u1)) * cosf(6.2831853f * u2);
+            float x = mode == 0 ? 0.0f : mode == 1 ? n : mode == 2 ? (i < h.size() / 2 ? n : expf(-fabsf(n) * 3.0f)) : (u1 - 0.5f) * 3.4f;
+            uint32_t u; memcpy(&u, &x, 4); h[i] = (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+        }
+        CHECK(hipMemcpy(d_ab, h.data(), h.size() * 2, hipMemcpyHostToDevice));
+        printf("%s: rr4 %6.0f | kernel order %6.0f | chained x8 %6.0f | rr2 %6.0f | acc+B in AGPR %6.0f | operands reused x4 %6.0f | 16x16x32 %6.0f | C=0 %6.0f  TFLOP/s\n",
+               names[mode], run<0>(d_ab, d_out, iters), run<1>(d_ab, d_out, iters), run<2>(d_ab, d_out, iters), run<3>(d_ab, d_out, iters),
+               run<4>(d_ab, d_out, iters), run<5>(d_ab, d_out, iters), run<6>(d_ab, d_out, iters), run<7>(d_ab, d_out, iters));
+        fflush(stdout);
+    }
+    return 0;
+}

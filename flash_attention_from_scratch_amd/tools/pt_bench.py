@@ -23,7 +23,12 @@ from dataclasses import dataclass
 
 import torch
 
-import flash_attention
+import os as _os
+import sys as _sys
+
+_sys.path.insert(0, _os.path.abspath(_os.path.join(_os.path.dirname(__file__), _os.pardir, _os.pardir)))  # repo root: runs without PYTHONPATH
+
+import flash_attention  # noqa: E402
 from flash_helpers.kernel_configs import calc_mfma_flop, calc_self_attn_flop, get_kernel_configs
 from flash_helpers.test.utils import (
     BATCH_SIZE_FOR_SEQ_LEN,
