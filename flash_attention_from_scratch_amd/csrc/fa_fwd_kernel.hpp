@@ -305,14 +305,14 @@ static FA_DEV unsigned lds_addr(const char *p) {
 }
 
 template <int DT, int QT, int NWAVES, int BC, bool SWZ, bool EAGER, bool OPT, bool PIPE, bool DMA = true,
-          bool MASK = false, int D = 128>
+          bool MASK = false, int D = 128, int KSPLIT = 1>
 struct FwdTraits {
     static_assert(!PIPE || EAGER, "the pipelined loop needs both LDS stages");
     static_assert(DMA || EAGER, "register-staged tiles are only built double-buffered");
     static_assert(D == 128 || D == 64, "d_head 128 (the reference's scope) or 64 (widener)");
     static_assert(DMA || D == 128, "the register-staged transport is only built for d_head 128");
     static constexpr int kRowsPerWave = 32 * QT;
-    static constexpr int kBr = kRowsPerWave * NWAVES;
+    static constexpr int kBr = kRowsPerWave * NWAVES / KSPLIT;  // KSPLIT waves share a row group (key split)
     static constexpr int kBc = BC;
     static constexpr int kThreads = NWAVES * 64;
     static constexpr int kTileBytes = BC * 2 * D;               // one K or V tile
@@ -324,8 +324,11 @@ struct FwdTraits {
     // (batch*head, Q block) items and keeps the K/V tile stream running across item seams, so its
     // O staging (8 KB per wave, one 32-row Q tile at a time) lives beside the rings, not in them.
     static constexpr bool kPersistent = (QT == 2 && PIPE);
+    // key split: 16 KB of 16-bit row staging + per row group 16 KB of fp32 O and (m, l) handed over in the epilogue
+    static constexpr int kMergeBytes = KSPLIT == 2 ? 2 * kRowsPerWave * 2 * D + 2 * (kRowsPerWave * D * 4 + 2 * 64 * 4) : 0;
+    static constexpr int kPlainBytes = kKvBytes > kOutBytes ? kKvBytes : kOutBytes;
     static constexpr int kLdsBytes = kPersistent ? kKvBytes + NWAVES * 32 * 2 * D
-                                                 : (kKvBytes > kOutBytes ? kKvBytes : kOutBytes);
+                                                 : (kPlainBytes > kMergeBytes ? kPlainBytes : kMergeBytes);
 };
 
 // ---------------------------------------------------------------------------------
@@ -336,14 +339,23 @@ struct FwdTraits {
 // 8 no barriers / DMA waits, 16 no DMA, 32 plain loads instead of DMA (data discarded);
 // experiments: 64 s_setprio(1) around the MFMA clusters (-3 %), 128 operand prefetch 12 deep
 // (no change).  Results are wrong by construction when ABL & 63 != 0.
+// KSPLIT = 2 (the reference's (B_r 64, B_c 64, 4 warps) configs): B_r / n_warps = 16 rows per wave would
+// mean 16x16x32 MFMAs whose K / V operands feed ONE 16-cycle MFMA each -- 256 B/clk of LDS reads per CU
+// at full matrix rate, the whole LDS bandwidth.  So the four waves are two row groups of 32 rows x two KEY
+// groups instead: wave w works on rows 32 (w & 1) .. +31 and on the 32-key half (w >> 1) of every 64-key
+// LDS tile with 32x32x16 MFMAs (half the LDS bytes per flop), keeps its own (m, l, O) over its half of
+// the keys, and the two partial results of a row group are merged once, in the epilogue, through LDS
+// (the in-workgroup form of a split-KV reduction: m = max, l and O rescaled to it and added).
 template <int DT, int QT, int NWAVES, int BC, bool SWZ, bool EAGER, bool OPT, bool PIPE, bool DMA = true,
-          bool MASK = false, int D = 128, int ABL = 0>
+          bool MASK = false, int D = 128, int ABL = 0, int KSPLIT = 1>
 __global__ void
 __launch_bounds__(NWAVES * 64, (QT == 1) ? 2 : 1)
 fa_fwd_kernel(const KernelArgs args) {
     using E = Elem<DT>;
     using vec8 = typename E::vec8;
-    using TR = FwdTraits<DT, QT, NWAVES, BC, SWZ, EAGER, OPT, PIPE, DMA, MASK, D>;
+    using TR = FwdTraits<DT, QT, NWAVES, BC, SWZ, EAGER, OPT, PIPE, DMA, MASK, D, KSPLIT>;
+    static_assert(KSPLIT == 1 || (KSPLIT == 2 && NWAVES == 4 && QT == 1 && BC == 64 && DMA && !MASK && D == 128),
+                  "the key split is built for (B_r 64, B_c 64, 4 waves)");
     constexpr int ROWB = 2 * D;              // bytes per K / V / O row (256, or 128 at d_head 64)
     constexpr int CPR = D / 8;               // 16-B chunks per row (16 / 8)
     constexpr int RPP = 64 / CPR;            // tile rows per 1-KiB DMA piece (4 / 8)
@@ -352,6 +364,7 @@ fa_fwd_kernel(const KernelArgs args) {
     // 16-B slots of the 256-B LDS bank row (d_head 64: two rows share a bank row)
     auto swz_of = [](int row) { return D == 128 ? (row & 15) : ((row >> 1) & 7); };
     constexpr int NT = BC / 32;              // 32-key tiles per LDS tile
+    constexpr int NTW = NT / KSPLIT;         // ... of which this wave works on NTW, from tile NT0 on
     constexpr int KS = D / 16;               // k steps of the QK^T contraction
     constexpr int DTILES = D / 32;           // 32-wide d tiles of O^T
     constexpr int TILE = TR::kTileBytes;
@@ -372,6 +385,8 @@ fa_fwd_kernel(const KernelArgs args) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r31 = lane & 31;
     const int hi = lane >> 5;
+    const int wave_r = KSPLIT == 2 ? (wave & 1) : wave;   // row group of this wave
+    const int NT0 = KSPLIT == 2 ? (wave >> 1) * NTW : 0;  // first 32-key tile (of an LDS tile) of its key group
 
     // ---- workgroup -> (batch*head, Q block); XCD-aware when n_bh % 8 == 0 --------
     const int nq = args.n_q_blocks;
@@ -550,7 +565,7 @@ fa_fwd_kernel(const KernelArgs args) {
     vec8 Qr[QT][KS];
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
-        int64_t row = (int64_t)qb * TR::kBr + wave * TR::kRowsPerWave + qt * 32 + r31;
+        int64_t row = (int64_t)qb * TR::kBr + wave_r * TR::kRowsPerWave + qt * 32 + r31;
         if (MASK && row >= S_len) row = S_len - 1;  // rows past the end are computed, never stored
         const uint16_t *qp = Qg + row * ss + hi * 8;
 #pragma unroll
@@ -581,22 +596,22 @@ fa_fwd_kernel(const KernelArgs args) {
     const int va_base = (4 * (lg >> 1) + (li >> 2)) * 64 + (lg & 1) * 32 + (li & 3) * 8;
 
     // ---- MASK: logits of keys >= seq_len, or above the causal diagonal, become -inf ---------
-    const int wave_row0 = wg_row0 + wave * TR::kRowsPerWave;
+    const int wave_row0 = wg_row0 + wave_r * TR::kRowsPerWave;
     auto tile_needs_mask = [&](int it) -> bool {  // wave-uniform
         const int kv0 = (n_kv - 1 - it) * BC;
         return MASK && (kv0 + BC > S_len || (args.causal && kv0 + BC - 1 > wave_row0));
     };
-    auto mask_S = [&](f32x16 (&S)[QT][NT], int it) {
+    auto mask_S = [&](f32x16 (&S)[QT][NTW], int it) {
         const int kv0 = (n_kv - 1 - it) * BC;
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) {
             const int q_row = wave_row0 + qt * 32 + r31;
             const int limit = args.causal ? (q_row < S_len - 1 ? q_row : S_len - 1) : S_len - 1;  // last live key
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
+            for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int key = kv0 + 32 * nt + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    const int key = kv0 + 32 * (NT0 + nt) + (r & 3) + 8 * (r >> 2) + 4 * hi;
                     S[qt][nt][r] = key > limit ? -__builtin_inff() : S[qt][nt][r];
                 }
         }
@@ -605,26 +620,26 @@ fa_fwd_kernel(const KernelArgs args) {
     auto finite_or_zero = [&](float mval) { return (MASK && mval == -__builtin_inff()) ? 0.0f : mval; };
 
     // ---- S^T = K Q^T ------------------------------------------------------------
-    auto qk = [&](int stage, f32x16 (&S)[QT][NT]) {
+    auto qk = [&](int stage, f32x16 (&S)[QT][NTW]) {
         const char *kt = smem + stage * TILE;
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
+            for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) S[qt][nt][r] = 0.0f;
         // ks outer / key-tile inner: consecutive MFMAs accumulate into different tiles
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const int off = nt * 32 * ROWB + ka_base + (((2 * ks + hi) ^ ka_swz) << 4);
+            for (int nt = 0; nt < NTW; ++nt) {
+                const int off = (NT0 + nt) * 32 * ROWB + ka_base + (((2 * ks + hi) ^ ka_swz) << 4);
                 const vec8 a = (ABL & 4) ? Qr[0][(ks + nt) % KS] : *(const vec8 *)(kt + off);
 #pragma unroll
                 for (int qt = 0; qt < QT; ++qt) S[qt][nt] = E::mfma(a, Qr[qt][ks], S[qt][nt]);
             }
         }
-        if (SCHED && !PIPE) sched_mfma_fed_from_lds<NT * KS * QT, 1, (ABL & 128) ? 12 : 8>();
+        if (SCHED && !PIPE) sched_mfma_fed_from_lds<NTW * KS * QT, 1, (ABL & 128) ? 12 : 8>();
     };
 
     // ---- online softmax, lane-local (softmax.cuh:85-105) --------------------------
@@ -633,14 +648,14 @@ fa_fwd_kernel(const KernelArgs args) {
     // of this tile is accumulated (scale_l_O, softmax.cuh:36-49).  l is rescaled here;
     // O by rescale_O() -- skipped when alpha == 1 in every lane (multiplying by 1.0f is
     // the identity, so the skip is bit-exact).
-    auto softmax = [&](f32x16 (&S)[QT][NT], vec8 (&Pb)[QT][NT][2], float (&alpha)[QT], auto first_tag) {
+    auto softmax = [&](f32x16 (&S)[QT][NTW], vec8 (&Pb)[QT][NTW][2], float (&alpha)[QT], auto first_tag) {
         constexpr bool FIRST = decltype(first_tag)::value;
         if (ABL & 2) {
 #pragma unroll
             for (int qt = 0; qt < QT; ++qt) {
                 alpha[qt] = 1.0f;
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
+                for (int nt = 0; nt < NTW; ++nt) {
                     float p[16];
 #pragma unroll
                     for (int r = 0; r < 16; ++r) p[r] = S[qt][nt][r];
@@ -654,7 +669,7 @@ fa_fwd_kernel(const KernelArgs args) {
         for (int qt = 0; qt < QT; ++qt) {
             float mx = S[qt][0][0];
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
+            for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) mx = fmaxf(mx, S[qt][nt][r]);
             mx = pair_max(mx);
@@ -671,7 +686,7 @@ fa_fwd_kernel(const KernelArgs args) {
             const float neg_msc = -(finite_or_zero(m_new) * c);
             float rowsum = 0.0f;
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
+            for (int nt = 0; nt < NTW; ++nt) {
                 float p[16];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -699,16 +714,16 @@ fa_fwd_kernel(const KernelArgs args) {
     };
 
     // ---- O^T += V^T P^T ------------------------------------------------------------
-    auto pv = [&](int stage, const vec8 (&Pb)[QT][NT][2]) {
+    auto pv = [&](int stage, const vec8 (&Pb)[QT][NTW][2]) {
         const char *vt = smem + V_BASE + stage * TILE;
         // 16-key slice outer / d tile inner: consecutive MFMAs hit different accumulators
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
+        for (int nt = 0; nt < NTW; ++nt) {
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
 #pragma unroll
                 for (int t = 0; t < DTILES; ++t) {
-                    const int s16 = 2 * nt + half;
+                    const int s16 = 2 * (NT0 + nt) + half;
                     const char *vp = vt + va_base + s16 * (DSUB * 1024) + t * 512;
                     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((FA_LDS(s16x4) *)(vp));
                     const s16x4 up =
@@ -723,7 +738,7 @@ fa_fwd_kernel(const KernelArgs args) {
                 }
             }
         }
-        if (SCHED && !PIPE) sched_mfma_fed_from_lds<DTILES * NT * 2 * QT, 2, (ABL & 128) ? 12 : 8>();
+        if (SCHED && !PIPE) sched_mfma_fed_from_lds<DTILES * NTW * 2 * QT, 2, (ABL & 128) ? 12 : 8>();
     };
 
     using TrueTag = BoolTag<true>;
@@ -745,20 +760,20 @@ fa_fwd_kernel(const KernelArgs args) {
         //            row max of S(it+1)
         // O is only ever rescaled while no P.V is in flight (start of a visit), so the
         // factor applies to exactly the terms accumulated so far (guide T13 hazard).
-        f32x16 Sa[QT][NT], Sb[QT][NT];
+        f32x16 Sa[QT][NTW], Sb[QT][NTW];
         float mx[QT];     // row max of the S tile that becomes S_cur next
-        auto row_max = [&](f32x16 (&S)[QT][NT]) {
+        auto row_max = [&](f32x16 (&S)[QT][NTW]) {
 #pragma unroll
             for (int qt = 0; qt < QT; ++qt) {
                 float v = S[qt][0][0];
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
+                for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) v = fmaxf(v, S[qt][nt][r]);
                 mx[qt] = pair_max(v);
             }
         };
-        auto visit = [&](int it, f32x16 (&S_cur)[QT][NT], f32x16 (&S_nxt)[QT][NT], auto last_tag) {
+        auto visit = [&](int it, f32x16 (&S_cur)[QT][NTW], f32x16 (&S_nxt)[QT][NTW], auto last_tag) {
             constexpr bool LAST = decltype(last_tag)::value;
             FA_STAMP(it, 0);
             wait_and_barrier();
@@ -798,9 +813,9 @@ fa_fwd_kernel(const KernelArgs args) {
                 if (MASK && tile_needs_mask(it + 1)) mask_S(S_nxt, it + 1);
             }
             // ---- vector stream: P = exp2(S_cur c - m c) (softmax.cuh:51-83) -------------
-            vec8 P[QT][NT][2];
+            vec8 P[QT][NTW][2];
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
+            for (int nt = 0; nt < NTW; ++nt) {
 #pragma unroll
                 for (int qt = 0; qt < QT; ++qt) {
                     float p[16];
@@ -821,7 +836,7 @@ fa_fwd_kernel(const KernelArgs args) {
             for (int qt = 0; qt < QT; ++qt) l[qt] += rowsum[qt];
             if (SCHED) {
                 // interleave: 8 operand reads ahead, then per MFMA 1-2 reads + 5 VALU/TRANS
-                constexpr int N_QK = LAST ? 0 : NT * KS * QT, N_PV = DTILES * NT * 2 * QT;
+                constexpr int N_QK = LAST ? 0 : NTW * KS * QT, N_PV = DTILES * NTW * 2 * QT;
                 __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
 #pragma unroll
                 for (int i = 0; i < N_QK; ++i) {
@@ -886,8 +901,8 @@ fa_fwd_kernel(const KernelArgs args) {
                 if (it + 1 < n_kv) { store_k(stage ^ 1); store_v(stage ^ 1); }
                 if (it + 2 < n_kv) { load_k(it + 2); load_v(it + 2); }
             }
-            f32x16 S[QT][NT];
-            vec8 P[QT][NT][2];
+            f32x16 S[QT][NTW];
+            vec8 P[QT][NTW][2];
             float alpha[QT];
             if (ABL & 64) __builtin_amdgcn_s_setprio(1);
             qk(stage, S);
@@ -915,8 +930,8 @@ fa_fwd_kernel(const KernelArgs args) {
             issue_k(it, 0);
             issue_v(it, 0);
             wait_and_barrier();
-            f32x16 S[QT][NT];
-            vec8 P[QT][NT][2];
+            f32x16 S[QT][NTW];
+            vec8 P[QT][NTW][2];
             float alpha[QT];
             qk(0, S);
             if (MASK && tile_needs_mask(it)) mask_S(S, it);
@@ -941,8 +956,43 @@ fa_fwd_kernel(const KernelArgs args) {
     // row stride.  Each wave stages only its own rows; the 16-B chunk index is XORed with
     // (row & 15) so both the 8-B writes and the 16-B reads are bank-conflict free.
     barrier();  // every wave is done with the K/V stages
+    if constexpr (KSPLIT == 2) {
+        // Merge the two key groups of a row group (see the template comment): the wave of key group 1 hands
+        // its (m, l, O) -- per-lane values in the same layout as its partner's -- over through LDS, lane-linear
+        // (16-B chunk j of lane L at (64 j + L) * 16: conflict-free both ways), behind the 16 KB the two storing
+        // waves stage their 16-bit rows in.  m = max(m0, m1); l and O are brought to it and added
+        // (exp2((m_i - m) c), the factor scale_l_O applies, softmax.cuh:36-49) -- per lane: the factors are the
+        // same in the two lanes that share a row, so the deferred lane-pair sum of l commutes with the merge.
+        static_assert(QT == 1, "one 32-row tile per wave");
+        char *xo = smem + 2 * TR::kRowsPerWave * ROWB + wave_r * (DTILES * 4 * 64 * 16 + 2 * 64 * 4);
+        float *xml = (float *)(xo + DTILES * 4 * 64 * 16);
+        if (NT0 != 0) {
+#pragma unroll
+            for (int t = 0; t < DTILES; ++t)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    *(f32x4 *)(xo + ((4 * t + j) * 64 + lane) * 16) =
+                        f32x4{O[0][t][4 * j], O[0][t][4 * j + 1], O[0][t][4 * j + 2], O[0][t][4 * j + 3]};
+            xml[lane] = m[0];
+            xml[64 + lane] = l[0];
+        }
+        barrier();
+        if (NT0 != 0) return;  // (no barrier follows: the storing waves work on wave-private LDS from here on)
+        const float m1 = xml[lane], l1 = xml[64 + lane];
+        const float m_all = fmaxf(m[0], m1);
+        const float a0 = __builtin_amdgcn_exp2f((m[0] - m_all) * c), a1 = __builtin_amdgcn_exp2f((m1 - m_all) * c);
+        l[0] = l[0] * a0 + l1 * a1;
+#pragma unroll
+        for (int t = 0; t < DTILES; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f32x4 o1 = *(const f32x4 *)(xo + ((4 * t + j) * 64 + lane) * 16);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) O[0][t][4 * j + e] = O[0][t][4 * j + e] * a0 + o1[e] * a1;
+            }
+    }
     {
-        char *stage_o = smem + wave * (TR::kRowsPerWave * ROWB);
+        char *stage_o = smem + wave_r * (TR::kRowsPerWave * ROWB);
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) {
             const float inv = 1.0f / pair_sum(l[qt]);
@@ -962,7 +1012,7 @@ fa_fwd_kernel(const KernelArgs args) {
                 *(s16x4 *)(wp + (((4 * t + 3) ^ swz_of(row)) << 4)) = up_s.hi;
             }
         }
-        const int64_t row0 = (int64_t)qb * TR::kBr + wave * TR::kRowsPerWave;
+        const int64_t row0 = (int64_t)qb * TR::kBr + wave_r * TR::kRowsPerWave;
         const int rsub = lane / CPR, chunk = lane & (CPR - 1);
 #pragma unroll
         for (int i = 0; i < TR::kRowsPerWave / RPP; ++i) {

@@ -50,6 +50,16 @@ constexpr KernelEntry make_entry() {
     }
 }
 
+// (B_r 64, B_c 64, 4 waves): the key-split form of the 32-rows-per-wave kernel (KSPLIT = 2 in
+// fa_fwd_kernel.hpp); registered under B_r / n_warps = 16 rows per wave, which is how configs find it
+template <int DT, bool SWZ, bool EAGER, bool OPT, bool PIPE>
+constexpr KernelEntry make_entry_ks() {
+    using TR = FwdTraits<DT, 1, 4, 64, SWZ, EAGER, OPT, PIPE, true, false, 128, 2>;
+    static_assert(TR::kBr == 64, "two row groups of 32");
+    return KernelEntry{DT, 16, 4, 64, SWZ, EAGER, OPT, PIPE, 1, 0, 128, TR::kThreads, TR::kLdsBytes, 0,
+                       (kernel_fn)&fa_fwd_kernel<DT, 1, 4, 64, SWZ, EAGER, OPT, PIPE, true, false, 128, 0, 2>, nullptr};
+}
+
 struct KernelTable {
     const KernelEntry *entries;
     int count;

@@ -48,15 +48,17 @@ def symbol_to_config(symbol):
         return None
     vals = [{"true": 1, "false": 0}.get(t.strip(), t.strip()) for t in m.group(2).split(",")]
     vals = [int(v) for v in vals]
-    if m.group(1) == "64":  # fa_fwd_kernel64<DT, MASK, ABL, RAG>: the persistent (256, 64, 4) + buffer kernel
-        return FlashForwardKernelConfig(DType(vals[0]), 128, 256, 64, 4, True, True, True, 0, 0, 0, True, False)
+    if m.group(1) == "64":  # fa_fwd_kernel64<DT, MASK, ABL, RAG, SPEC>: the persistent (256, 64, 4) + buffer kernel
+        spec = bool(vals[4]) if len(vals) > 4 else False
+        return FlashForwardKernelConfig(DType(vals[0]), 128, 256, 64, 4, True, True, True, 0, 0, 0, True, spec)
     if m.group(1):
         dt, nw, bc, swz, eager, opt = vals[:6]
         rows, pipe = 16, 0
     else:
         dt, qt, nw, bc, swz, eager, opt, pipe, dma = vals[:9]
         d_head = vals[10] if len(vals) > 10 else 128
-        rows = 32 * qt
+        ksplit = vals[12] if len(vals) > 12 else 1  # key split: KSPLIT waves share a 32-row group
+        rows = 32 * qt // ksplit
         return FlashForwardKernelConfig(DType(dt), d_head, rows * nw, bc, nw, bool(dma), bool(eager), bool(swz),
                                         0, 0, 0, bool(pipe), bool(opt))
     return FlashForwardKernelConfig(DType(dt), 128, rows * nw, bc, nw, True, bool(eager), bool(swz),

@@ -41,6 +41,10 @@ def test_symbol_and_mangled_name_round_trip_to_config():
     assert cfg == kc.FlashForwardKernelConfig(kc.DType.BF16, 128, 256, 64, 8, True, True, True, 0, 0, 0, True, False)
     cfg16 = rocprof_bench.symbol_to_config("void fa::fa_fwd_kernel16<5, 4, 32, true, true, true>(fa::KernelArgs)")
     assert (cfg16.dtype, cfg16.B_r, cfg16.B_c, cfg16.n_warps, cfg16.optimized_softmax) == (kc.DType.FP16, 64, 32, 4, True)
+    cfg_ks = rocprof_bench.symbol_to_config("void fa::fa_fwd_kernel<5, 1, 4, 64, true, true, false, true, true, false, 128, 0, 2>(fa::KernelArgs)")
+    assert (cfg_ks.B_r, cfg_ks.B_c, cfg_ks.n_warps, cfg_ks.mma_double_buffer_loads) == (64, 64, 4, True)
+    cfg_spec = rocprof_bench.symbol_to_config("void fa::fa_fwd_kernel64<15, false, 0, false, true>(fa::KernelArgs)")
+    assert cfg_spec.optimized_softmax and (cfg_spec.B_r, cfg_spec.n_warps) == (256, 4)
     cfg64 = rocprof_bench.symbol_to_config("void fa::fa_fwd_kernel64<15, false, 0>(fa::KernelArgs)")
     assert cfg64 == kc.FlashForwardKernelConfig(kc.DType.BF16, 128, 256, 64, 4, True, True, True, 0, 0, 0, True, False)
     assert kernel_resources.demangle_variant("_ZN2fa15fa_fwd_kernel64ILi5ELb1ELi0EEEvNS_10KernelArgsE")["masked"] == 2
