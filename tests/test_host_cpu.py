@@ -107,6 +107,17 @@ def test_launch_argument_validation_needs_no_gpu():
     assert rc == -5
     rc, msg = status(_args(cfg, q=4100))
     assert rc == -5
+    # strides: sign, zero with more than one entry, and the 32-bit range of row * seq_stride * 2 bytes
+    for over in (dict(seq_stride=-128), dict(seq_stride=0), dict(batch_stride=-8), dict(head_stride=-8),
+                 dict(batch=2, batch_stride=0), dict(n_heads=2, head_stride=0)):
+        rc, msg = status(_args(cfg, **over))
+        assert rc == -4 and "strides must be positive" in msg, over
+    limit = 0xFFFFFFFF // (2 * 128)  # B_r = 128 rows
+    rc, msg = status(_args(cfg, seq_stride=(limit // 8 + 1) * 8))
+    assert rc == -4 and "too large" in msg
+    if not torch.cuda.is_available():  # (with a GPU this would launch on the fake pointers)
+        rc, msg = status(_args(cfg, seq_stride=(limit // 8) * 8, batch_stride=1 << 40))
+        assert rc == -7  # valid arguments: the first HIP call (no device here) is what fails
     bad = _args(cfg)
     bad.cfg.dtype = 6
     rc, msg = status(bad)
