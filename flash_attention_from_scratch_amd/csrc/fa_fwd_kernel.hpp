@@ -553,14 +553,17 @@ fa_fwd_kernel(const KernelArgs args) {
         args.trace[(wave * 64 + 63) * 8 + 7] = __builtin_amdgcn_s_getreg((31 << 11) | 4);  // HW_REG_HW_ID
 #endif
     // ---- prologue: first tiles in flight, then Q -> VGPRs --------------------------
-    if (EAGER && DMA) {
-        issue_k(0, 0);
-        issue_v(0, 0);
-    }
-    if (!DMA) {
-        load_k(0);
-        load_v(0);
-    }
+    auto first_requests = [&]() {
+        if (EAGER && DMA) {
+            issue_k(0, 0);
+            issue_v(0, 0);
+        }
+        if (!DMA) {
+            load_k(0);
+            load_v(0);
+        }
+    };
+    first_requests();
 
     vec8 Qr[QT][KS];
 #pragma unroll
@@ -577,15 +580,18 @@ fa_fwd_kernel(const KernelArgs args) {
 
     f32x16 O[QT][DTILES];
     float m[QT], l[QT];
+    auto reset_state = [&]() {
 #pragma unroll
-    for (int qt = 0; qt < QT; ++qt) {
-        m[qt] = -__builtin_inff();
-        l[qt] = 0.0f;
+        for (int qt = 0; qt < QT; ++qt) {
+            m[qt] = -__builtin_inff();
+            l[qt] = 0.0f;
 #pragma unroll
-        for (int t = 0; t < DTILES; ++t)
+            for (int t = 0; t < DTILES; ++t)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) O[qt][t][r] = 0.0f;
-    }
+                for (int r = 0; r < 16; ++r) O[qt][t][r] = 0.0f;
+        }
+    };
+    reset_state();
 
     // per-lane LDS read offsets
     //   K A-operand: row 32*nt + r31, chunk (2*ks + hi) ^ (r31 & 15)
@@ -648,8 +654,9 @@ fa_fwd_kernel(const KernelArgs args) {
     // of this tile is accumulated (scale_l_O, softmax.cuh:36-49).  l is rescaled here;
     // O by rescale_O() -- skipped when alpha == 1 in every lane (multiplying by 1.0f is
     // the identity, so the skip is bit-exact).
-    auto softmax = [&](f32x16 (&S)[QT][NTW], vec8 (&Pb)[QT][NTW][2], float (&alpha)[QT], auto first_tag) {
+    auto softmax = [&](f32x16 (&S)[QT][NTW], vec8 (&Pb)[QT][NTW][2], float (&alpha)[QT], auto first_tag, auto fast_tag) {
         constexpr bool FIRST = decltype(first_tag)::value;
+        constexpr bool FAST = decltype(fast_tag)::value;  // speculative: m stays the first tile's row max
         if (ABL & 2) {
 #pragma unroll
             for (int qt = 0; qt < QT; ++qt) {
@@ -668,13 +675,18 @@ fa_fwd_kernel(const KernelArgs args) {
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) {
             float mx = S[qt][0][0];
+            if constexpr (!FAST || FIRST) {
 #pragma unroll
-            for (int nt = 0; nt < NTW; ++nt)
+                for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, S[qt][nt][r]);
-            mx = pair_max(mx);
+                    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, S[qt][nt][r]);
+                mx = pair_max(mx);
+            }
             float m_new;
-            if (FIRST && OPT) {
+            if (FAST && !FIRST) {
+                m_new = m[qt];
+                alpha[qt] = 1.0f;
+            } else if (FIRST && OPT) {
                 m_new = mx;
                 alpha[qt] = 1.0f;
             } else {
@@ -745,6 +757,17 @@ fa_fwd_kernel(const KernelArgs args) {
     using FalseTag = BoolTag<false>;
 
     static_assert(!(QT == 2 && PIPE), "the 64-rows-per-wave pipelined schedule lives in fa_fwd_kernel64.hpp");
+    // SPEC (cfg.optimized_softmax on the double-buffered plain variants): the speculative softmax of
+    // fa_fwd_kernel64.hpp on a one-item workgroup.  attempt<FAST> keeps the row max of the
+    // FIRST visited tile as the reference for every tile -- no row max, no rescale factor, no O rescale --
+    // and checks the row sums l >= every P against the overflow limit at the end; if any wave of the
+    // workgroup fails, all of them run the item again with the running max (attempt<SAFE>): the K / V
+    // stream simply starts over.
+    // (not on the register-staged transport: with its landing registers live across both attempts two
+    // of those variants spill)
+    constexpr bool SPEC = OPT && EAGER && !MASK && DMA;
+    auto attempt = [&](auto fast_tag) -> bool {
+    constexpr bool FAST = decltype(fast_tag)::value;
     if constexpr (PIPE) {
         // In-wave software pipeline with two S accumulators.  While the matrix pipe forms
         // S(it+1) = K(it+1) Q^T and then O += V(it) P(it), the VALU turns the finished S(it)
@@ -793,6 +816,11 @@ fa_fwd_kernel(const KernelArgs args) {
             float neg_msc[QT], rowsum[QT];
 #pragma unroll
             for (int qt = 0; qt < QT; ++qt) {
+                if constexpr (FAST) {  // m = the first tile's row max (set once, below): nothing moves
+                    neg_msc[qt] = -(m[qt] * c);
+                    rowsum[qt] = 0.0f;
+                    continue;
+                }
                 const float m_new = fmaxf(m[qt], mx[qt]);
                 const float alpha = __builtin_amdgcn_exp2f((m[qt] - finite_or_zero(m_new)) * c);
                 l[qt] *= alpha;
@@ -831,7 +859,7 @@ fa_fwd_kernel(const KernelArgs args) {
             }
             // ---- matrix stream 2: O += V(it) P --------------------------------------------
             pv(it & 1, P);
-            if (!LAST) row_max(S_nxt);
+            if (!LAST && !FAST) row_max(S_nxt);
 #pragma unroll
             for (int qt = 0; qt < QT; ++qt) l[qt] += rowsum[qt];
             if (SCHED) {
@@ -859,6 +887,10 @@ fa_fwd_kernel(const KernelArgs args) {
             qk(0, Sa);
             if (MASK && tile_needs_mask(0)) mask_S(Sa, 0);
             row_max(Sa);
+            if constexpr (FAST) {
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt) m[qt] = mx[qt];
+            }
         } else {
             // registers: K(0), V(0) -> LDS; then K(1), V(1) in flight; after S(0): K(1) -> LDS,
             // K(2) in flight.  Invariant at the top of visit `it`: LDS holds K(it+1), V(it)
@@ -870,6 +902,10 @@ fa_fwd_kernel(const KernelArgs args) {
             qk(0, Sa);
             if (MASK && tile_needs_mask(0)) mask_S(Sa, 0);
             row_max(Sa);
+            if constexpr (FAST) {
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt) m[qt] = mx[qt];
+            }
             if (n_kv > 1) store_k(1);
             if (n_kv > 2) load_k(2);
         }
@@ -909,8 +945,8 @@ fa_fwd_kernel(const KernelArgs args) {
             if (ABL & 64) __builtin_amdgcn_s_setprio(0);
             if (MASK && tile_needs_mask(it)) mask_S(S, it);
             FA_STAMP(it, 2);
-            softmax(S, P, alpha, first_tag);
-            if (!decltype(first_tag)::value) rescale_O(alpha);
+            softmax(S, P, alpha, first_tag, fast_tag);
+            if (!decltype(first_tag)::value && !FAST) rescale_O(alpha);
             FA_STAMP(it, 3);
             if (ABL & 64) __builtin_amdgcn_s_setprio(1);
             pv(stage, P);
@@ -936,13 +972,43 @@ fa_fwd_kernel(const KernelArgs args) {
             qk(0, S);
             if (MASK && tile_needs_mask(it)) mask_S(S, it);
             if (OPT && it == 0) {
-                softmax(S, P, alpha, TrueTag{});
+                softmax(S, P, alpha, TrueTag{}, FalseTag{});
             } else {
-                softmax(S, P, alpha, FalseTag{});
+                softmax(S, P, alpha, FalseTag{}, FalseTag{});
                 rescale_O(alpha);
             }
             pv(0, P);
         }
+    }
+
+    barrier();  // every wave is done with the K/V stages
+    if constexpr (FAST) {
+        // every P of a row is <= its l: below the limit nothing overflowed (fp32 exp2, the 16-bit P, fp32 O);
+        // NaN fails the compare too.  One verdict per workgroup, through the idle LDS.
+        constexpr float kLimit = DT == 5 ? 32768.0f : 1.2676506e30f;  // 2^15 (fp16 P < 65504) / 2^100
+        bool bad = false;
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) bad |= !(pair_sum(l[qt]) < kLimit);
+        const int wave_bad = __ballot(bad) != 0 ? 1 : 0;
+        if (lane == 0) *(int *)(smem + wave * 4) = wave_bad;
+        barrier();
+        int any = 0;
+#pragma unroll
+        for (int w = 0; w < NWAVES; ++w) any |= *(const int *)(smem + w * 4);
+        any = __builtin_amdgcn_readfirstlane(any);
+        barrier();  // (flags read before anything is staged or requested over them)
+        return any == 0;
+    }
+    return true;
+    };  // attempt
+    bool done = false;
+    if constexpr (SPEC) done = attempt(TrueTag{});
+    if (!done) {
+        if constexpr (SPEC) {  // start over with the running max
+            reset_state();
+            first_requests();
+        }
+        attempt(FalseTag{});
     }
 
     if ((ABL & 32) && args.seq_len < 0) {  // never true: keeps the landing registers allocated
@@ -955,7 +1021,6 @@ fa_fwd_kernel(const KernelArgs args) {
     // 256-B rows (16 B per lane, 4 rows per wave-instruction) instead of 8-B pieces at a
     // row stride.  Each wave stages only its own rows; the 16-B chunk index is XORed with
     // (row & 15) so both the 8-B writes and the 16-B reads are bank-conflict free.
-    barrier();  // every wave is done with the K/V stages
     if constexpr (KSPLIT == 2) {
         // Merge the two key groups of a row group (see the template comment): the wave of key group 1 hands
         // its (m, l, O) -- per-lane values in the same layout as its partner's -- over through LDS, lane-linear

@@ -143,7 +143,7 @@ def blockwise_for_config(cfg, q, k, v, n_threads=0):
     from flash_helpers import kernel_configs as kc
 
     if kc.uses_speculative_softmax(cfg):
-        return blockwise_forward_lazy(q, k, v, cfg.B_r, cfg.B_c, tau=SPEC_TAU, n_threads=n_threads)
+        return blockwise_forward_lazy(q, k, v, min(cfg.B_r, q.shape[1]), cfg.B_c, tau=SPEC_TAU, n_threads=n_threads)
     if kc.uses_lazy_rescale(cfg):
         return blockwise_forward_lazy(q, k, v, cfg.B_r, cfg.B_c, n_threads=n_threads)
     return blockwise_forward(q, k, v, cfg.B_r, cfg.B_c, optimized_softmax=cfg.optimized_softmax,

@@ -339,6 +339,34 @@ def test_speculative_softmax_second_pass(rise):
                 assert torch.equal(flash_attention.forward(spec, q, k, v), out)
 
 
+def test_speculative_softmax_on_the_32_row_kernels_starts_over():
+    """optimized_softmax on the double-buffered 32-rows-per-wave variants (and the key-split (64, 64, 4)
+    form) is the speculative softmax too: a workgroup whose check fails runs its item again with the
+    running max.  That second attempt is the arithmetic of the same variant without the flag, so the
+    rows of the failed workgroup must equal the optimized_softmax = False build bit for bit; all rows
+    stay within tolerance of fp32 eager."""
+    shapes = [(128, 64, 4, True), (128, 64, 4, False), (128, 32, 4, True), (256, 128, 8, False), (64, 64, 4, True),
+              (64, 64, 4, False), (256, 64, 8, True)]
+    for dtype, name in ((torch.bfloat16, kc.DType.BF16), (torch.float16, kc.DType.FP16)):
+        qc = ut.QKVConfig(n_heads=3, d_head=128, batch_size=2, seq_len=1024, dtype=dtype, device=torch.device(DEV))
+        q, k, v = ut.generate_qkv(qc, seed=19)
+        u = _sign_vector(5).to(dtype)
+        k[1, 3, 2] = 30.0 * u            # key 3 lies in the LAST visited tile
+        q[1, 600:604, 2] = 30.0 * u      # rows 600..603 of (batch 1, head 2)
+        ref = ut.py_flash_attention(q, k, v, upcast=True).float()
+        tol = TOL[dtype] * (1 + ref.abs())
+        for B_r, B_c, nw, buf in shapes:
+            spec = kc.FlashForwardKernelConfig(name, 128, B_r, B_c, nw, True, True, True, 0, 0, 0, buf, True)
+            plain = replace(spec, optimized_softmax=False)
+            assert kc.uses_speculative_softmax(spec) and not kc.uses_speculative_softmax(plain)
+            out, out_plain = flash_attention.forward(spec, q, k, v), flash_attention.forward(plain, q, k, v)
+            assert torch.isfinite(out.float()).all(), str(spec)
+            blk = slice((600 // B_r) * B_r, (600 // B_r) * B_r + B_r)   # the workgroup that holds rows 600..603
+            assert torch.equal(out[1, blk, 2], out_plain[1, blk, 2]), str(spec)
+            assert ((out.float() - ref).abs() <= tol).all(), str(spec)
+            assert torch.equal(flash_attention.forward(spec, q, k, v), out)
+
+
 def test_speculative_softmax_second_pass_beyond_ordinal_63():
     """A workgroup records failed items in a 64-bit mask of walk ordinals; ordinals >= 63 share the
     last bit (the second pass then redoes all of them).  130 * 128 items of one Q block each on 256
@@ -541,12 +569,17 @@ def test_masked_variants_against_eager_sdpa_and_oracle(S, causal):
 
 def test_masked_variant_equals_plain_kernel_when_nothing_is_masked():
     """At a tile-multiple seq_len without causal mask the widened variant must reproduce the
-    reference-scope kernel bit for bit."""
+    reference-scope kernel bit for bit.  (The masked forms always keep a running max; where
+    optimized_softmax selects the speculative softmax in the plain kernel, its arithmetic is that of
+    the plain kernel WITHOUT the flag -- the first-block skip multiplies by exact zeros and ones.)"""
     for cfg in MASKED:
         dtype = cfg.dtype.to_torch_dtype()
         gen = torch.Generator(device=DEV).manual_seed(3)
         q, k, v = (torch.randn((2, 1024, 4, 128), dtype=dtype, device=DEV, generator=gen) for _ in range(3))
-        assert torch.equal(flash_attention.forward_ex(cfg, q, k, v), flash_attention.forward(cfg, q, k, v)), str(cfg)
+        plain = replace(cfg, optimized_softmax=False) if kc.uses_speculative_softmax(cfg) else cfg
+        assert torch.equal(flash_attention.forward_ex(cfg, q, k, v), flash_attention.forward(plain, q, k, v)), str(cfg)
+        if plain is not cfg:
+            assert (flash_attention.forward(cfg, q, k, v).float() - flash_attention.forward(plain, q, k, v).float()).abs().max().item() <= TOL[dtype]
 
 
 @pytest.mark.parametrize("shape", [(8, 16, 1024), (40, 16, 256), (5, 7, 512), (3, 16, 2048), (2, 16, 4096),
