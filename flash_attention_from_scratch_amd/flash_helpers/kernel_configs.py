@@ -499,5 +499,5 @@ def best_config(dtype=DType.BF16, seq_len=4096, masked=False) -> FlashForwardKer
             DType(dtype), 128, 256, 64, 4, True, True, True, 0, 0, 0, True, not masked
         )
     return FlashForwardKernelConfig(
-        DType(dtype), 128, 128, 64, 4, True, True, True, 0, 0, 0, True, False
+        DType(dtype), 128, 128, 64, 4, True, True, True, 0, 0, 0, True, not masked
     )
