@@ -108,7 +108,9 @@ typedef struct fa_kernel_info {
 /* One-time setup for the CURRENT device (idempotent; also called lazily by every launch): arch check,
  * CU count, the > 48 KB dynamic-LDS opt-in of every kernel function.  State is kept per device ordinal,
  * so a host that drives several GPUs from one process initialises each at its first call there
- * (the reference: device guard src/flash_attention.cu:42 + module init :142-149). */
+ * (the reference: device guard src/flash_attention.cu:42 + module init :142-149).  fa_fwd_launch itself is
+ * one plain kernel launch -- capturable into a hipGraph -- but this setup queries the device: call
+ * fa_init() on the device BEFORE starting a stream capture there. */
 int fa_init(void);
 
 /* Introspection of that per-device state (tests): has `device` been initialised, with which status,
