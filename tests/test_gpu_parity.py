@@ -142,6 +142,34 @@ def test_output_buffer_ownership_and_determinism():
     assert torch.equal(out2, first) and ms > 0
 
 
+def test_launch_is_capturable_into_a_hip_graph():
+    """fa_fwd_launch is one plain asynchronous kernel launch on the caller's stream (persistent variants
+    included: no cooperative launch, no host round trip), so a forward can be captured into a hipGraph and
+    replayed on new data in the same buffers -- how a serving loop would issue it."""
+    for cfg in (kc.best_config(kc.DType.BF16, 1024), kc.best_config(kc.DType.FP16, 320)):
+        dtype = cfg.dtype.to_torch_dtype()
+        S = 1024 if cfg.B_r == 256 else 384
+        gen = torch.Generator(device=DEV).manual_seed(9)
+        q, k, v = (torch.randn((2, S, 4, 128), dtype=dtype, device=DEV, generator=gen) for _ in range(3))
+        o = torch.empty_like(q)
+        expect = flash_attention.forward(cfg, q, k, v).clone()   # (also the per-device setup, outside the capture)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            flash_attention.forward(cfg, q, k, v, o)
+        o.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(o, expect), str(cfg)
+        q2, k2, v2 = (torch.randn((2, S, 4, 128), dtype=dtype, device=DEV, generator=gen) for _ in range(3))
+        expect2 = flash_attention.forward(cfg, q2, k2, v2).clone()
+        q.copy_(q2), k.copy_(k2), v.copy_(v2)
+        for _ in range(3):
+            graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(o, expect2), str(cfg)
+
+
 def test_every_variant_is_bitwise_deterministic_under_load():
     """LDS stage-recycling protocol check (no racecheck tool on ROCm): every device variant,
     many workgroups in flight (uneven progress), three runs, identical bits; and variants that
