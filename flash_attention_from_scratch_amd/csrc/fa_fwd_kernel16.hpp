@@ -124,6 +124,10 @@ fa_fwd_kernel16(const KernelArgs args) {
 
     int kv_block = args.n_kv_blocks - 1;
     if (EAGER) issue_tile(kv_block, 0);
+    // SPEC (cfg.optimized_softmax, double-buffered variants): the speculative softmax (see
+    // fa_fwd_kernel.hpp): attempt<FAST> keeps the first visited tile's row max as the reference for all
+    // tiles -- no quad reduction, no rescale -- and checks l at the end; a workgroup that fails starts over.
+    constexpr bool SPEC = OPT && EAGER;
 
     vec8 Qr[KS];
     {
@@ -136,19 +140,25 @@ fa_fwd_kernel16(const KernelArgs args) {
     const float c = (float)((double)(1.0f / __builtin_sqrtf((float)D)) * 1.4426950408889634074);
 
     f32x4 O[DT16];
+    float m, l;
+    auto reset_state = [&]() {
 #pragma unroll
-    for (int t = 0; t < DT16; ++t)
+        for (int t = 0; t < DT16; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) O[t][r] = 0.0f;
-    float m = -__builtin_inff(), l = 0.0f;
+            for (int r = 0; r < 4; ++r) O[t][r] = 0.0f;
+        m = -__builtin_inff();
+        l = 0.0f;
+    };
+    reset_state();
 
     const int ka_swz = SWZ ? r15 : 0;
     const int ka_base = r15 * 256;
     const int li = lane & 15;
     const int va_base = (4 * g + (li >> 2)) * 32 + (li & 3) * 8;
 
-    auto compute_tile = [&](int stage, auto first_tag) {
+    auto compute_tile = [&](int stage, auto first_tag, auto fast_tag) {
         constexpr bool FIRST = decltype(first_tag)::value;
+        constexpr bool FAST = decltype(fast_tag)::value;
         const char *kt_ptr = smem + stage * TILE;
         const char *vt_ptr = smem + V_BASE + stage * TILE;
 
@@ -171,13 +181,17 @@ fa_fwd_kernel16(const KernelArgs args) {
         sched_mfma_fed_from_lds<KT * KS, 1, 8>();
 
         float mx = S[0][0];
+        if constexpr (!FAST || FIRST) {
 #pragma unroll
-        for (int kt = 0; kt < KT; ++kt)
+            for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) mx = fmaxf(mx, S[kt][r]);
-        mx = quad_max(mx);
+                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, S[kt][r]);
+            mx = quad_max(mx);
+        }
         float m_new;
-        if (FIRST && OPT) {
+        if (FAST && !FIRST) {
+            m_new = m;
+        } else if (FIRST && OPT) {
             m_new = mx;
         } else {
             m_new = fmaxf(m, mx);
@@ -225,30 +239,55 @@ fa_fwd_kernel16(const KernelArgs args) {
     using TrueTag = BoolTag<true>;
     using FalseTag = BoolTag<false>;
     const int n_kv = args.n_kv_blocks;
-    if (EAGER) {
-        dma_wait_all();
-        wg_barrier();
-        if (n_kv > 1) issue_tile(kv_block - 1, 1);
-        if (OPT) compute_tile(0, TrueTag{}); else compute_tile(0, FalseTag{});
-        for (int it = 1; it < n_kv; ++it) {
-            const int stage = it & 1;
+    auto attempt = [&](auto fast_tag) -> bool {
+        constexpr bool FAST = decltype(fast_tag)::value;
+        if (EAGER) {
             dma_wait_all();
             wg_barrier();
-            if (it + 1 < n_kv) issue_tile(kv_block - it - 1, stage ^ 1);
-            compute_tile(stage, FalseTag{});
+            if (n_kv > 1) issue_tile(kv_block - 1, 1);
+            if (OPT) compute_tile(0, TrueTag{}, fast_tag); else compute_tile(0, FalseTag{}, fast_tag);
+            for (int it = 1; it < n_kv; ++it) {
+                const int stage = it & 1;
+                dma_wait_all();
+                wg_barrier();
+                if (it + 1 < n_kv) issue_tile(kv_block - it - 1, stage ^ 1);
+                compute_tile(stage, FalseTag{}, fast_tag);
+            }
+        } else {
+            for (int it = 0; it < n_kv; ++it) {
+                if (it > 0) wg_barrier();
+                issue_tile(kv_block - it, 0);
+                dma_wait_all();
+                wg_barrier();
+                if (OPT && it == 0) compute_tile(0, TrueTag{}, fast_tag); else compute_tile(0, FalseTag{}, fast_tag);
+            }
         }
-    } else {
-        for (int it = 0; it < n_kv; ++it) {
-            if (it > 0) wg_barrier();
-            issue_tile(kv_block - it, 0);
-            dma_wait_all();
+        wg_barrier();  // every wave is done with the K/V stages
+        if constexpr (FAST) {  // l >= every P of the row: below the limit nothing overflowed; one verdict per workgroup
+            constexpr float kLimit = DT == 5 ? 32768.0f : 1.2676506e30f;  // 2^15 (fp16 P < 65504) / 2^100
+            const int wave_bad = __ballot(!(quad_sum(l) < kLimit)) != 0 ? 1 : 0;
+            if (lane == 0) *(int *)(smem + wave * 4) = wave_bad;
             wg_barrier();
-            if (OPT && it == 0) compute_tile(0, TrueTag{}); else compute_tile(0, FalseTag{});
+            int any = 0;
+#pragma unroll
+            for (int w = 0; w < NWAVES; ++w) any |= *(const int *)(smem + w * 4);
+            any = __builtin_amdgcn_readfirstlane(any);
+            wg_barrier();
+            return any == 0;
         }
+        return true;
+    };
+    bool done = false;
+    if constexpr (SPEC) done = attempt(TrueTag{});
+    if (!done) {
+        if constexpr (SPEC) {  // start over with the running max
+            reset_state();
+            issue_tile(kv_block, 0);
+        }
+        attempt(FalseTag{});
     }
 
     // epilogue: O staged through LDS (each wave its own 16 rows), stored as whole rows
-    wg_barrier();
     {
         const float inv = 1.0f / quad_sum(l);
         char *stage_o = smem + wave * (16 * 256);

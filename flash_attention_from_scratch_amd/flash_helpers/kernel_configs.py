@@ -470,15 +470,11 @@ def uses_speculative_softmax(cfg) -> bool:
     first run against the row max of its first K/V tile only (no per-tile row max, no rescale), its row
     sums are checked against an overflow limit at the end, and an item that fails is run again with the
     running max -- by the lazy-rescale schedule on the persistent 64-rows-per-wave kernel, by the same
-    workgroup starting over on the 32-rows-per-wave kernels (double-buffered LDS-DMA variants, the key-split
-    (64, 64, 4) form included).  CPU restatement: blockwise_forward_lazy with an infinite threshold.
-    Elsewhere (16 rows per wave, single-stage progression steps) the flag keeps the reference's meaning:
-    the first K/V block skips the rescale."""
-    if not (cfg.optimized_softmax and cfg.eager_load_blocks and cfg.async_copy):
-        return False
-    rows = cfg.B_r // cfg.n_warps
-    key_split = (rows, cfg.n_warps, cfg.B_c, bool(cfg.swizzled), bool(cfg.async_copy), cfg.d_head) == (16, 4, 64, True, True, 128)
-    return rows in (32, 64) or key_split
+    workgroup starting over on the other kernels (every double-buffered LDS-DMA variant).  CPU
+    restatement: blockwise_forward_lazy with an infinite threshold.  On the single-stage progression
+    steps and the register-staged variants the flag keeps the reference's meaning: the first K/V block
+    skips the rescale."""
+    return bool(cfg.optimized_softmax and cfg.eager_load_blocks and cfg.async_copy)
 
 
 def best_config(dtype=DType.BF16, seq_len=4096, masked=False) -> FlashForwardKernelConfig:

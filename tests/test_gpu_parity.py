@@ -368,13 +368,13 @@ def test_speculative_softmax_second_pass(rise):
 
 
 def test_speculative_softmax_on_the_32_row_kernels_starts_over():
-    """optimized_softmax on the double-buffered 32-rows-per-wave variants (and the key-split (64, 64, 4)
-    form) is the speculative softmax too: a workgroup whose check fails runs its item again with the
+    """optimized_softmax on the double-buffered 32-rows-per-wave variants (the key-split (64, 64, 4) form
+    and the 16-rows-per-wave (64, 32, 4) kernel too) is the speculative softmax too: a workgroup whose check fails runs its item again with the
     running max.  That second attempt is the arithmetic of the same variant without the flag, so the
     rows of the failed workgroup must equal the optimized_softmax = False build bit for bit; all rows
     stay within tolerance of fp32 eager."""
     shapes = [(128, 64, 4, True), (128, 64, 4, False), (128, 32, 4, True), (256, 128, 8, False), (64, 64, 4, True),
-              (64, 64, 4, False), (256, 64, 8, True)]
+              (64, 64, 4, False), (256, 64, 8, True), (64, 32, 4, False)]
     for dtype, name in ((torch.bfloat16, kc.DType.BF16), (torch.float16, kc.DType.FP16)):
         qc = ut.QKVConfig(n_heads=3, d_head=128, batch_size=2, seq_len=1024, dtype=dtype, device=torch.device(DEV))
         q, k, v = ut.generate_qkv(qc, seed=19)
