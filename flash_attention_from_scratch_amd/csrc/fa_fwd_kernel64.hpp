@@ -1033,18 +1033,22 @@ fa_fwd_kernel64(const KernelArgs args) {
 
     if constexpr (SPEC) {
         unsigned long long failed = walk(BoolTag<true>{}, ~0ull);
-        // every wave's failures -> one workgroup-uniform mask, through the (now idle) LDS
-        barrier();  // every wave has left the rings: its last reads retired, its last pieces landed
-        if (lane == 0) *(unsigned long long *)(smem + wave * 8) = failed;
+        // every wave's failures -> one workgroup-uniform mask.  Each wave leaves its mask in its OWN O staging
+        // area (beside the rings: no K / V piece ever lands there, and its own epilogue reads have retired),
+        // so one barrier publishes all four.
+        char *slot = smem + 2 * TR::kStages * TILE;
+        if (lane == 0) *(unsigned long long *)(slot + wave * 8192) = failed;
         barrier();
         unsigned long long all = 0;
 #pragma unroll
-        for (int w = 0; w < NWAVES; ++w) all |= *(const unsigned long long *)(smem + w * 8);
+        for (int w = 0; w < NWAVES; ++w) all |= *(const unsigned long long *)(slot + w * 8192);
         const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)all);
         const unsigned hi32 = __builtin_amdgcn_readfirstlane((unsigned)(all >> 32));
         all = ((unsigned long long)hi32 << 32) | lo;
-        barrier();  // (all four slots read before the second pass overwrites K stage 0)
-        if (all) walk(BoolTag<false>{}, all);
+        if (all) {
+            barrier();  // (all four slots read before the second pass requests its first Q tile into one of them)
+            walk(BoolTag<false>{}, all);
+        }
     } else {
         walk(BoolTag<false>{}, ~0ull);
     }
