@@ -99,7 +99,8 @@ constexpr bool plan64_ok(const Plan64 &p) {
     return e == 32 && m == (chain ? 32 : 0) && d == 8;
 }
 
-// (optimized_softmax selects nothing here: the first tile of an item never rescales, by construction)
+// (the reference's meaning of optimized_softmax -- the first tile skips the rescale -- holds here by
+// construction; the flag selects SPEC below instead)
 // RAG (a second MASK variant): any seq_len >= 64.  The host rounds the Q blocks up and passes
 // n_kv_blocks = 4 n_q_blocks (the ring arithmetic wants a multiple of four tiles); a tile that would reach
 // beyond the sequence is fetched as the window of its last 64 keys instead (always inside the tensor, no
@@ -268,767 +269,767 @@ fa_fwd_kernel64(const KernelArgs args) {
     // min(o, 63) is set in `todo`.  FAST: the speculative schedule (see SPEC above); returns the ordinals
     // (same encoding) of the items whose check failed in any row of this wave.
     auto walk = [&](auto fast_tag, const unsigned long long todo) -> unsigned long long {
-    constexpr bool FAST = decltype(fast_tag)::value;
-    unsigned long long failed = 0;
-    const int n_items = args.n_bh * nq;
-    auto next_ord = [&](int o) {  // next ordinal of this pass behind o, or -1 (scalar; item seams only)
-        for (;;) {
-            ++o;
-            if ((long long)blockIdx.x + (long long)o * (long long)gridDim.x >= (long long)n_items) return -1;
-            if (!SPEC || ((todo >> (o < 63 ? o : 63)) & 1ull)) return o;
+        constexpr bool FAST = decltype(fast_tag)::value;
+        unsigned long long failed = 0;
+        const int n_items = args.n_bh * nq;
+        auto next_ord = [&](int o) {  // next ordinal of this pass behind o, or -1 (scalar; item seams only)
+            for (;;) {
+                ++o;
+                if ((long long)blockIdx.x + (long long)o * (long long)gridDim.x >= (long long)n_items) return -1;
+                if (!SPEC || ((todo >> (o < 63 ? o : 63)) & 1ull)) return o;
+            }
+        };
+        int ord = next_ord(-1);
+        if (ord < 0) return failed;  // (second pass only: nothing of this workgroup's failed)
+        int bh, qb;
+        item_coords((int)blockIdx.x + ord * (int)gridDim.x, bh, qb);
+        const int b = bh / args.n_heads, h = bh % args.n_heads;
+        const int64_t head_off = (int64_t)b * args.batch_stride + (int64_t)h * args.head_stride;
+        const uint16_t *Qg = (const uint16_t *)args.q + head_off;
+        const uint16_t *Kg = (const uint16_t *)args.k + head_off;
+        const uint16_t *Vg = (const uint16_t *)args.v + head_off;
+        uint16_t *Og = (uint16_t *)args.o + head_off;
+        // KV blocks are visited last-to-first (forward_kernel.cuh:142,175-184): visit index `it` is
+        // sequence block n_kv-1-it.  Causal: only the 4 (qb + 1) tiles up to the item's diagonal.
+        const int n_kv = (MASK && args.causal) ? 4 * (qb + 1) : args.n_kv_blocks;
+        // ---- first requests of the walk: K(0), then Q (all S(0) needs); the rest follows in the prologue
+        if (!(ABL & 16)) {
+#pragma unroll
+            for (int j = 0; j < DMA_PER_WAVE; ++j)
+                glds16_sv(tile_at(Kg, n_kv - 1), k_off[j], smem_base + (wave + NWAVES * j) * 1024);
         }
-    };
-    int ord = next_ord(-1);
-    if (ord < 0) return failed;  // (second pass only: nothing of this workgroup's failed)
-    int bh, qb;
-    item_coords((int)blockIdx.x + ord * (int)gridDim.x, bh, qb);
-    const int b = bh / args.n_heads, h = bh % args.n_heads;
-    const int64_t head_off = (int64_t)b * args.batch_stride + (int64_t)h * args.head_stride;
-    const uint16_t *Qg = (const uint16_t *)args.q + head_off;
-    const uint16_t *Kg = (const uint16_t *)args.k + head_off;
-    const uint16_t *Vg = (const uint16_t *)args.v + head_off;
-    uint16_t *Og = (uint16_t *)args.o + head_off;
-    // KV blocks are visited last-to-first (forward_kernel.cuh:142,175-184): visit index `it` is
-    // sequence block n_kv-1-it.  Causal: only the 4 (qb + 1) tiles up to the item's diagonal.
-    const int n_kv = (MASK && args.causal) ? 4 * (qb + 1) : args.n_kv_blocks;
-    // ---- first requests of the walk: K(0), then Q (all S(0) needs); the rest follows in the prologue
-    if (!(ABL & 16)) {
-#pragma unroll
-        for (int j = 0; j < DMA_PER_WAVE; ++j)
-            glds16_sv(tile_at(Kg, n_kv - 1), k_off[j], smem_base + (wave + NWAVES * j) * 1024);
-    }
 
-    vec8 Qr[QT][KS];  // Q of the current item (AGPRs), filled through LDS (request_q / read_q below)
+        vec8 Qr[QT][KS];  // Q of the current item (AGPRs), filled through LDS (request_q / read_q below)
 
-    f32x16 O[QT][DTILES];
-    float m[QT];
+        f32x16 O[QT][DTILES];
+        float m[QT];
 #pragma unroll
-    for (int qt = 0; qt < QT; ++qt) m[qt] = -__builtin_inff();
-    // O = 0 by eight MFMAs on a zero operand (16 registers apiece; 128 v_accvgpr_write otherwise)
-    auto zero_o = [&]() {
-        if constexpr (MASK) {  // (the causal variant has no four registers to spare at the seam)
+        for (int qt = 0; qt < QT; ++qt) m[qt] = -__builtin_inff();
+        // O = 0 by eight MFMAs on a zero operand (16 registers apiece; 128 v_accvgpr_write otherwise)
+        auto zero_o = [&]() {
+            if constexpr (MASK) {  // (the causal variant has no four registers to spare at the seam)
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+                    for (int t = 0; t < DTILES; ++t)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) O[qt][t][r] = 0.0f;
+                return;
+            }
+            typename E::vec8 zz = __builtin_bit_cast(typename E::vec8, u32x4{0u, 0u, 0u, 0u});
+            asm volatile("s_nop 3" : "+v"(zz));  // VALU write -> MFMA operand read
 #pragma unroll
             for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
-                for (int t = 0; t < DTILES; ++t)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) O[qt][t][r] = 0.0f;
-            return;
-        }
-        typename E::vec8 zz = __builtin_bit_cast(typename E::vec8, u32x4{0u, 0u, 0u, 0u});
-        asm volatile("s_nop 3" : "+v"(zz));  // VALU write -> MFMA operand read
-#pragma unroll
-        for (int qt = 0; qt < QT; ++qt)
-#pragma unroll
-            for (int t = 0; t < DTILES; ++t) E::mfma_zero_a(O[qt][t], zz);
-        asm volatile("s_nop 7" ::"v"(zz));  // operand registers stay allocated until the last one has read them
-    };
-    zero_o();
+                for (int t = 0; t < DTILES; ++t) E::mfma_zero_a(O[qt][t], zz);
+            asm volatile("s_nop 7" ::"v"(zz));  // operand registers stay allocated until the last one has read them
+        };
+        zero_o();
 
-    {
-        // ---- 64 rows per wave, one wave per SIMD, hand-placed registers and order ----------
-        // Each K / V operand read from LDS feeds TWO MFMAs (the wave's two 32-row Q tiles), which
-        // halves LDS traffic, DMA issue and barriers per MFMA.  512 registers per lane, by file:
-        //   AGPR  O (128) | Q (64)
-        //   VGPR  two S tiles (128) | P (32) | operand ring (16) | softmax temporaries
-        // All MFMAs are inline asm so that O and Q never leave the accumulator file; hipcc does
-        // not schedule or hazard-pad them, so the stream is pinned gap by gap (one MFMA + its
-        // fillers, then sched_barrier(0)) and the wait states are kept by distance:
-        //   * S(it+1) is accumulated in phase 1 and first read (row max) >= 2 MFMAs later;
-        //   * a packed P operand is consumed >= 2 gaps after its v_cvt_pk;
-        //   * O is read by VALU only in the rare rescale and in the epilogue, behind s_nop pads.
-        // One wave per SIMD hides about five single-issue instructions per 32-cycle MFMA
-        // (MI355X_MICROARCH.md, per-instruction constants), so the softmax of tile `it` is cut
-        // into 32 two-element units {2 fma, 2 exp2, 2 add, 1 pack} and dealt over the gaps by
-        // a compile-time plan (Plan64):
-        //   phase 1 (32 MFMAs, S(it+1) = K(it+1) Q^T): K operand reads, most of the units
-        //   phase 2 (32 MFMAs, O += V(it) P(it)):      V operand reads, the other units, the row max
-        //            of S(it+1), the 8 DMA pieces of the tiles three visits ahead, the m / rescale test
-        // K and V each ring through 4 LDS stages (128 KB; the 512-register waves allow one
-        // workgroup per CU anyway).  A tile is requested three visits before it is read and must have
-        // landed two visits after the request: the wait in front of the per-visit barrier is
-        // COUNTED (vmcnt(8): the youngest visit's pieces stay in flight), so an HBM-latency fetch
-        // does not stall the matrix pipe, and the barrier publishes a tile one visit early, which
-        // lets the last gaps of a visit prefetch the next visit's first operands.
-        //
-        // Rescaling is lazy: O and l stay relative to a reference max m that is only moved (and
-        // O, l multiplied by 2^((m_old - m_new) c)) when some row's max rose by more than
-        // TAU / c logit units, so P <= 2^TAU.  The result is the same real number as the
-        // reference's eager rescale (softmax.cuh:36-49); only the rounding point of P differs,
-        // with the same relative error.  With O in the accumulator file a rescale costs ~200
-        // issue slots per Q tile, and for random data some row of 32 finds a new max in most tiles.
-        static_assert(DMA && D == 128 && BC == 64 && NT == 2 && NWAVES == 4, "64-row pinned schedule");
-        static_assert(TR::kStages == 4, "ring depth");
-        constexpr float TAU = 8.0f;
-        constexpr Plan64 plan = make_plan64(((ABL >> 8) & 3) | (MASK ? 4 : 0) | (FAST ? 8 : 0) | ((ABL & 8192) ? 16 : 0),
-                                            (ABL & 1024) ? 20 : ((ABL & 16384) ? 23 : 22));
-        static_assert(plan64_ok(plan), "filler plan violates a wait-state distance");
-        f32x16 Sa[2][NT], Sb[2][NT];
-        u32x4 Pw[2][4] = {};     // P[qt][16-key slice]: B operand of O^T += V^T P^T
-        float neg_msc[2];        // -(m c)
-        float thr[2];            // m + TAU / c: a row max above it moves the reference max
-        // running row sums (fp32 P, before rounding: softmax.cuh:66-83), two chains per Q tile; l = their
-        // sum, taken in the epilogue (the reference adds a per-tile sum to l: same terms, other order)
-        float rs[2][2] = {{0.0f, 0.0f}, {0.0f, 0.0f}};
-        float m_pend[2];         // candidate reference max found during the previous visit
-        unsigned resc_any = 0;   // bit qt: Q tile qt moves its reference max at the next visit's top
-        auto k_frag = [&](const char *kt, int step) -> vec8 {  // step = 2*ks + nt
-            const int ks = step >> 1, nt = step & 1;
-            return *(const vec8 *)(kt + nt * 32 * ROWB + ka_base + (((2 * ks + hi) ^ ka_swz) << 4));
-        };
-        auto v_frag = [&](const char *vt, int step) -> vec8 {  // step = 4*s16 + t
-            const int s16 = step >> 2, t = step & 3;
-            const char *vp = vt + va_base + s16 * (DSUB * 1024) + t * 512;
-            s16x8 av;
-            av.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((FA_LDS(s16x4) *)(vp));
-            av.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((FA_LDS(s16x4) *)(vp + DSUB * 512));
-            return __builtin_bit_cast(vec8, av);
-        };
-        auto qk_mfma = [&](auto &S, int step, int qt, vec8 a) {
-            const int ks = step >> 1, nt = step & 1;
-            if (ks == 0) E::mfma_acc_v_q0(S[qt][nt], a, Qr[qt][ks]);
-            else E::mfma_acc_v_q(S[qt][nt], a, Qr[qt][ks]);
-        };
-        // ---- persistent walk over items; the K / V tile stream runs on across item seams --------
-        // This workgroup serves items blockIdx.x, + gridDim.x, ...  Tiles are numbered along the
-        // walk: visit index j of the current item for j < n_kv, visit index j - n_kv of the NEXT item
-        // beyond (n_kv % 4 == 0, so a tile's ring stage is j & 3 either way).  The last visits of an
-        // item therefore request the next item's first tiles, its last visit forms the next item's
-        // S(0) with the next item's Q (brought into the spare Q set during the item's first visits), and a
-        // seam costs the O epilogue and the reset of the item state only.  After the last item the "next" item is the item itself:
-        // the re-fetched tiles land in stages nobody reads.
-        int item = (int)blockIdx.x + ord * (int)gridDim.x;
-        int ord_n = -1;  // ordinal of the next item of this pass, or -1
-        const uint16_t *Kc = Kg, *Vc = Vg;   // current item
-        uint16_t *Oc = Og;
-        int qb_c = qb;
-        const uint16_t *Kn = Kg, *Vn = Vg, *Qn = Qg;  // next item (set per item below)
-        uint16_t *On = Og;
-        int qb_n = qb;
-        bool has_next = false;
-        // causal (MASK variants): an item visits the tiles up to its diagonal only, 4 (qb + 1) of them
-        // -- still a multiple of the ring depth, so the stage arithmetic along the walk holds
-        const bool causal = MASK && args.causal;
-        int nkc = n_kv, nkn = n_kv;  // tiles of the current / next item
-        auto tile_g = [&](const uint16_t *cur, const uint16_t *nxt, int j) {
-            return j < nkc ? tile_at(cur, nkc - 1 - j) : tile_at(nxt, nkn - 1 - (j - nkc));
-        };
-        // MASK: logits above the causal diagonal become -inf.  `tile` counts from the start of the
-        // sequence, `qb_rows` is the Q block whose rows the S tile belongs to.  A wave's 64 rows meet
-        // the diagonal in exactly one 64-key tile; tiles beyond it are masked whole.
-        auto mask_tile = [&](auto &S, int tile, int qb_rows) {
-            if constexpr (RAG) {
-                const int r0 = 64 * tile < args.seq_len - 64 ? 64 * tile : args.seq_len - 64;  // first key of the window
-                const int delta = 64 * tile - r0;  // keys of the window in front of the tile's own first key
-                if (delta > 0) {  // wave-uniform: the last tiles of a sequence only
-                    const int lim = delta - 4 * hi;
+        {
+            // ---- 64 rows per wave, one wave per SIMD, hand-placed registers and order ----------
+            // Each K / V operand read from LDS feeds TWO MFMAs (the wave's two 32-row Q tiles), which
+            // halves LDS traffic, DMA issue and barriers per MFMA.  512 registers per lane, by file:
+            //   AGPR  O (128) | Q (64)
+            //   VGPR  two S tiles (128) | P (32) | operand ring (16) | softmax temporaries
+            // All MFMAs are inline asm so that O and Q never leave the accumulator file; hipcc does
+            // not schedule or hazard-pad them, so the stream is pinned gap by gap (one MFMA + its
+            // fillers, then sched_barrier(0)) and the wait states are kept by distance:
+            //   * S(it+1) is accumulated in phase 1 and first read (row max) >= 2 MFMAs later;
+            //   * a packed P operand is consumed >= 2 gaps after its v_cvt_pk;
+            //   * O is read by VALU only in the rare rescale and in the epilogue, behind s_nop pads.
+            // One wave per SIMD hides about five single-issue instructions per 32-cycle MFMA
+            // (MI355X_MICROARCH.md, per-instruction constants), so the softmax of tile `it` is cut
+            // into 32 two-element units {2 fma, 2 exp2, 2 add, 1 pack} and dealt over the gaps by
+            // a compile-time plan (Plan64):
+            //   phase 1 (32 MFMAs, S(it+1) = K(it+1) Q^T): K operand reads, most of the units
+            //   phase 2 (32 MFMAs, O += V(it) P(it)):      V operand reads, the other units, the row max
+            //            of S(it+1), the 8 DMA pieces of the tiles three visits ahead, the m / rescale test
+            // K and V each ring through 4 LDS stages (128 KB; the 512-register waves allow one
+            // workgroup per CU anyway).  A tile is requested three visits before it is read and must have
+            // landed two visits after the request: the wait in front of the per-visit barrier is
+            // COUNTED (vmcnt(8): the youngest visit's pieces stay in flight), so an HBM-latency fetch
+            // does not stall the matrix pipe, and the barrier publishes a tile one visit early, which
+            // lets the last gaps of a visit prefetch the next visit's first operands.
+            //
+            // Rescaling is lazy: O and l stay relative to a reference max m that is only moved (and
+            // O, l multiplied by 2^((m_old - m_new) c)) when some row's max rose by more than
+            // TAU / c logit units, so P <= 2^TAU.  The result is the same real number as the
+            // reference's eager rescale (softmax.cuh:36-49); only the rounding point of P differs,
+            // with the same relative error.  With O in the accumulator file a rescale costs ~200
+            // issue slots per Q tile, and for random data some row of 32 finds a new max in most tiles.
+            static_assert(DMA && D == 128 && BC == 64 && NT == 2 && NWAVES == 4, "64-row pinned schedule");
+            static_assert(TR::kStages == 4, "ring depth");
+            constexpr float TAU = 8.0f;
+            constexpr Plan64 plan = make_plan64(((ABL >> 8) & 3) | (MASK ? 4 : 0) | (FAST ? 8 : 0) | ((ABL & 8192) ? 16 : 0),
+                                                (ABL & 1024) ? 20 : ((ABL & 16384) ? 23 : 22));
+            static_assert(plan64_ok(plan), "filler plan violates a wait-state distance");
+            f32x16 Sa[2][NT], Sb[2][NT];
+            u32x4 Pw[2][4] = {};     // P[qt][16-key slice]: B operand of O^T += V^T P^T
+            float neg_msc[2];        // -(m c)
+            float thr[2];            // m + TAU / c: a row max above it moves the reference max
+            // running row sums (fp32 P, before rounding: softmax.cuh:66-83), two chains per Q tile; l = their
+            // sum, taken in the epilogue (the reference adds a per-tile sum to l: same terms, other order)
+            float rs[2][2] = {{0.0f, 0.0f}, {0.0f, 0.0f}};
+            float m_pend[2];         // candidate reference max found during the previous visit
+            unsigned resc_any = 0;   // bit qt: Q tile qt moves its reference max at the next visit's top
+            auto k_frag = [&](const char *kt, int step) -> vec8 {  // step = 2*ks + nt
+                const int ks = step >> 1, nt = step & 1;
+                return *(const vec8 *)(kt + nt * 32 * ROWB + ka_base + (((2 * ks + hi) ^ ka_swz) << 4));
+            };
+            auto v_frag = [&](const char *vt, int step) -> vec8 {  // step = 4*s16 + t
+                const int s16 = step >> 2, t = step & 3;
+                const char *vp = vt + va_base + s16 * (DSUB * 1024) + t * 512;
+                s16x8 av;
+                av.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((FA_LDS(s16x4) *)(vp));
+                av.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((FA_LDS(s16x4) *)(vp + DSUB * 512));
+                return __builtin_bit_cast(vec8, av);
+            };
+            auto qk_mfma = [&](auto &S, int step, int qt, vec8 a) {
+                const int ks = step >> 1, nt = step & 1;
+                if (ks == 0) E::mfma_acc_v_q0(S[qt][nt], a, Qr[qt][ks]);
+                else E::mfma_acc_v_q(S[qt][nt], a, Qr[qt][ks]);
+            };
+            // ---- persistent walk over items; the K / V tile stream runs on across item seams --------
+            // This workgroup serves items blockIdx.x, + gridDim.x, ...  Tiles are numbered along the
+            // walk: visit index j of the current item for j < n_kv, visit index j - n_kv of the NEXT item
+            // beyond (n_kv % 4 == 0, so a tile's ring stage is j & 3 either way).  The last visits of an
+            // item therefore request the next item's first tiles, its last visit forms the next item's
+            // S(0) with the next item's Q (brought into the spare Q set during the item's first visits), and a
+            // seam costs the O epilogue and the reset of the item state only.  After the last item the "next" item is the item itself:
+            // the re-fetched tiles land in stages nobody reads.
+            int item = (int)blockIdx.x + ord * (int)gridDim.x;
+            int ord_n = -1;  // ordinal of the next item of this pass, or -1
+            const uint16_t *Kc = Kg, *Vc = Vg;   // current item
+            uint16_t *Oc = Og;
+            int qb_c = qb;
+            const uint16_t *Kn = Kg, *Vn = Vg, *Qn = Qg;  // next item (set per item below)
+            uint16_t *On = Og;
+            int qb_n = qb;
+            bool has_next = false;
+            // causal (MASK variants): an item visits the tiles up to its diagonal only, 4 (qb + 1) of them
+            // -- still a multiple of the ring depth, so the stage arithmetic along the walk holds
+            const bool causal = MASK && args.causal;
+            int nkc = n_kv, nkn = n_kv;  // tiles of the current / next item
+            auto tile_g = [&](const uint16_t *cur, const uint16_t *nxt, int j) {
+                return j < nkc ? tile_at(cur, nkc - 1 - j) : tile_at(nxt, nkn - 1 - (j - nkc));
+            };
+            // MASK: logits above the causal diagonal become -inf.  `tile` counts from the start of the
+            // sequence, `qb_rows` is the Q block whose rows the S tile belongs to.  A wave's 64 rows meet
+            // the diagonal in exactly one 64-key tile; tiles beyond it are masked whole.
+            auto mask_tile = [&](auto &S, int tile, int qb_rows) {
+                if constexpr (RAG) {
+                    const int r0 = 64 * tile < args.seq_len - 64 ? 64 * tile : args.seq_len - 64;  // first key of the window
+                    const int delta = 64 * tile - r0;  // keys of the window in front of the tile's own first key
+                    if (delta > 0) {  // wave-uniform: the last tiles of a sequence only
+                        const int lim = delta - 4 * hi;
 #pragma unroll
-                    for (int qt = 0; qt < 2; ++qt)
+                        for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
-                        for (int nt = 0; nt < NT; ++nt)
+                            for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                            for (int r = 0; r < 16; ++r)
-                                S[qt][nt][r] = (32 * nt + (r & 3) + 8 * (r >> 2) < lim) ? -__builtin_inff() : S[qt][nt][r];
+                                for (int r = 0; r < 16; ++r)
+                                    S[qt][nt][r] = (32 * nt + (r & 3) + 8 * (r >> 2) < lim) ? -__builtin_inff() : S[qt][nt][r];
+                    }
+                    const int row_min = 256 * qb_rows + 64 * wave;  // this wave's first row
+                    if (causal && r0 + 63 > row_min) {  // wave-uniform: some key of the window lies above some row's diagonal
+#pragma unroll
+                        for (int qt = 0; qt < 2; ++qt) {
+                            const int lim = row_min + 32 * qt + r31 - r0 - 4 * hi;  // key-in-window > lim: above the diagonal
+#pragma unroll
+                            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                                for (int r = 0; r < 16; ++r)
+                                    S[qt][nt][r] = (32 * nt + (r & 3) + 8 * (r >> 2) > lim) ? -__builtin_inff() : S[qt][nt][r];
+                        }
+                    }
+                } else if constexpr (MASK) {
+                    const int d = tile - (4 * qb_rows + wave);
+                    if (causal && d >= 0) {  // wave-uniform
+#pragma unroll
+                        for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+                            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                                for (int r = 0; r < 16; ++r) {
+                                    const int key = 32 * nt + (r & 3) + 8 * (r >> 2) + 4 * hi, row = 32 * qt + r31;
+                                    S[qt][nt][r] = (d > 0 || key > row) ? -__builtin_inff() : S[qt][nt][r];
+                                }
+                    }
                 }
-                const int row_min = 256 * qb_rows + 64 * wave;  // this wave's first row
-                if (causal && r0 + 63 > row_min) {  // wave-uniform: some key of the window lies above some row's diagonal
+            };
+            auto dma_k = [&](const uint16_t *src, int stage) {
+#pragma unroll
+                for (int j = 0; j < DMA_PER_WAVE; ++j)
+                    glds16_sv_m0(src, k_off[j], smem_base + stage * TILE + (wave + NWAVES * j) * 1024);
+            };
+            auto dma_v = [&](const uint16_t *src, int stage) {
+#pragma unroll
+                for (int j = 0; j < DMA_PER_WAVE; ++j)
+                    glds16_sv_m0(src, v_off[j], smem_base + V_BASE + stage * TILE + (wave + NWAVES * j) * 1024);
+            };
+            const uint16_t *kq = nullptr, *vq = nullptr;  // next K / V tile to request (set per item below)
+            // operand ring: slot u % RS holds operand u; the loads of operands step + LA, step + LA + 1 are issued
+            // at (even) step `step`, into the slots of the two operands whose MFMAs have just issued.  RS = 4:
+            // two steps (4 MFMAs, ~170 cycles) between a load and its use -- less than the LDS latency with four
+            // waves reading operands and the DMA writing: tools/trace64.hip (-DFA_TRACE=2) shows the wait in front
+            // of every fourth MFMA stall 25-50 cycles.  RS = 8: six steps.
+            constexpr int RS = FA_RING_SLOTS, LA = RS - 2;
+            vec8 ring[RS];
+            vec8 Qr2[2][KS];  // the next item's Q (AGPRs), requested during the item's first visit
+            float mraw[2];   // row max of the S tile formed by the last visit (the next item's S(0))
+            // the first two visits after a seam: the epilogue's row stores are in flight in front of the pieces
+            // the counted waits allow -- 16 of them, or fewer (RAG: a wave whose rows reach beyond the sequence
+            // skips stores; counted down to a multiple of 8, which only waits for more)
+            int seam_st = 0;
+            // ---- the next item's Q, through LDS -------------------------------------------------------
+            // The MFMA wants a lane to hold one Q row's 16-byte chunk; fetched like that from global memory
+            // a wave-instruction touches 32 rows (32 cache lines for 1 KiB), and 16 of them in a burst cost
+            // each wave 0.7-3 k cycles of queueing in the address path (tools/trace64.hip).  So a 32-row Q
+            // tile travels like a K tile: 8 coalesced 1-KiB LDS-DMA pieces (4 whole rows each) into this
+            // wave's O staging area (idle between seams), XOR-swizzled, then 8 conflict-free ds_read_b128
+            // straight into the spare Q set.  One tile per round: tile 0 is requested at the seam (or at
+            // the end of the prologue), read behind the barrier of visit 1, where tile 1 is requested,
+            // which is read behind the barrier of visit 2 -- all on the slow path that the sync point of
+            // an item's first three visits takes anyway, so the steady state carries none of it.
+            const unsigned q_stage = smem_base + 2 * TR::kStages * TILE + wave * 8192;
+            auto lane_now = [&]() {  // volatile: anything derived from threadIdx would be kept live across the walk
+                int l_;
+                asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l_));
+                return l_;
+            };
+            auto request_q = [&](const uint16_t *Qh, int qblk, int qt, unsigned stage) {  // rows 32 qt .. 32 qt + 31 of this wave's rows
+                const int l_ = lane_now();
+                // piece i: rows 4i .. 4i+3; this lane: row 4i + l/16, chunk (l % 16) ^ (row & 15)
+                //   = ((l % 16) ^ (l / 16)) ^ 4 (i & 3): one lane offset, 64 (i & 3) XORed in per piece
+                const unsigned off = (unsigned)(((int64_t)(l_ >> 4) * ss) * 2) + ((((unsigned)l_ & 15) ^ ((unsigned)l_ >> 4)) << 4);
+                if constexpr (RAG) {
+                    const int row_b = qblk * TR::kBr + wave * TR::kRowsPerWave + 32 * qt;
+                    if (row_b + 31 >= args.seq_len) {  // wave-uniform: rows beyond the sequence are fetched from its last row
+                        const unsigned chunk_b = (((unsigned)l_ & 15) ^ ((unsigned)l_ >> 4)) << 4;
+                        const int row_s = row_b < args.seq_len - 32 ? row_b : args.seq_len - 32;  // scalar base row (seq_len >= 64)
+                        const uint16_t *rows_s = Qh + (int64_t)row_s * ss;
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            int rg = row_b + 4 * i + (l_ >> 4);
+                            rg = rg < args.seq_len - 1 ? rg : args.seq_len - 1;
+                            glds16_sv_m0(rows_s, (unsigned)(rg - row_s) * (unsigned)(ss * 2) + (chunk_b ^ (64u * (i & 3))), stage + i * 1024);
+                        }
+                        return;
+                    }
+                }
+                const uint16_t *rows0 = Qh + ((int64_t)qblk * TR::kBr + wave * TR::kRowsPerWave + 32 * qt) * ss;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) glds16_sv_m0(rows0 + (int64_t)(4 * i) * ss, off ^ (64u * (i & 3)), stage + i * 1024);
+            };
+            auto read_q = [&](vec8 (&dst)[KS], unsigned stage) {  // this lane's chunks: row l % 32, chunk (2 ks + l/32) ^ (row & 15)
+                const int l_ = lane_now();
+                const unsigned base = stage + (l_ & 31) * 256, x = (unsigned)((l_ >> 5) ^ (l_ & 15));
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks)
+                    asm volatile("ds_read_b128 %0, %1" : "=a"(dst[ks]) : "v"(base + ((x ^ (2 * ks)) << 4)) : "memory");
+            };
+            auto request_next_q = [&](int qt) { request_q(Qn, qb_n, qt, q_stage); };
+            auto read_next_q = [&](vec8 (&dst)[KS]) { read_q(dst, q_stage); };
+            auto visit = [&](int it, auto &S_cur, auto &S_nxt, auto r_tag) {
+                constexpr int R = decltype(r_tag)::value;  // it & 3
+#ifdef FA_TRACE
+                unsigned long long ts[20];
+                asm volatile("s_memtime %0" : "=s"(ts[0]));
+#endif
+                FA_TL();
+                // the visit's synchronisation point: K(it+2), V(it+1) landed (requested two visits ago;
+                // K(it+1), V(it) were published by the previous barrier), the 8 youngest pieces may fly
+                // on; behind it every wave has finished visit it-1, whose K / V stages the DMA of this
+                // visit overwrites.  In the default plan it sits two MFMAs into the visit, after the
+                // gap-0 lgkmcnt(0) that retires this wave's last LDS reads of visit it-1.
+                auto sync_point = [&]() {
+                    if (ABL & 8) return;
+                    // One compare and one branch on the common path.  The first three visits of an item take
+                    // the slow path: more may be in flight behind the pieces the barrier publishes -- in issue
+                    // order: [pieces(last visit of the previous item) | 16 epilogue stores] [Q tile 0: 8]
+                    // pieces(0) [Q tile 1: 8] pieces(1) pieces(2) -- and the next item's Q tiles are moved
+                    // into the spare Q set here (see request_next_q).
+                    if (it >= 3) {
+                        asm volatile("s_waitcnt vmcnt(" FA_VM8 ")\n\ts_barrier" ::: "memory");
+                        return;
+                    }
+                    const int q8 = has_next ? 8 : 0;
+                    const int allow = (it < 2) ? 8 + seam_st + q8 : 8 + q8;
+                    if (allow == 8) asm volatile("s_waitcnt vmcnt(" FA_VM8 ")\n\ts_barrier" ::: "memory");
+                    else if (allow == 16) asm volatile("s_waitcnt vmcnt(" FA_VM16 ")\n\ts_barrier" ::: "memory");
+                    else if (allow == 24) asm volatile("s_waitcnt vmcnt(" FA_VM24 ")\n\ts_barrier" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(" FA_VM32 ")\n\ts_barrier" ::: "memory");
+                    if constexpr (R == 1 || R == 2) {
+                        if (it == R && has_next) {
+                            asm volatile("s_waitcnt vmcnt(" FA_VM8 ")" ::: "memory");  // Q tile R-1 landed (only pieces(R-1) are younger)
+                            read_next_q(Qr2[R - 1]);
+                            if constexpr (R == 1) {
+                                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // ... and read: its image may be overwritten
+                                request_next_q(1);
+                            }
+                        }
+                    }
+                };
+                if constexpr (R == 3) {
+                    // last visit of an item forms the next item's S(0): swap the next item's Q in
+                    if (it + 1 == nkc && has_next) {
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the LDS reads into the spare set (visits 1, 2)
+#pragma unroll
+                        for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+                            for (int ks = 0; ks < KS; ++ks) {
+                                asm volatile("" : "+a"(Qr2[qt][ks]));  // value defined by the asm loads
+                                Qr[qt][ks] = Qr2[qt][ks];
+                            }
+                        asm volatile("s_nop 3" ::: "memory");  // accvgpr write -> MFMA operand
+                    }
+                }
+                if constexpr (plan.barrier[2] == 0) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    sync_point();
+                }
+                const unsigned kdst = smem_base + R * TILE + wave * 1024;                        // K(it+4) -> stage of K(it)
+                const unsigned vdst = smem_base + V_BASE + ((R + 3) & 3) * TILE + wave * 1024;   // V(it+3) -> stage of V(it-1)
+                if (!FAST && resc_any) {  // wave-uniform, rare: move the reference max of one or both Q tiles
+                    asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");  // MFMA D (O) -> VALU read
 #pragma unroll
                     for (int qt = 0; qt < 2; ++qt) {
-                        const int lim = row_min + 32 * qt + r31 - r0 - 4 * hi;  // key-in-window > lim: above the diagonal
+                        if (!(resc_any & (1u << qt))) continue;
+                        const float m_new = fmaxf(m[qt], m_pend[qt]);
+                        const float alpha = __builtin_amdgcn_exp2f((m[qt] - m_new) * c);
+                        m[qt] = m_new;
+                        neg_msc[qt] = -(finite_or_zero(m_new) * c);
+                        thr[qt] = m_new + TAU / c;
+                        rs[qt][0] *= alpha;
+                        rs[qt][1] *= alpha;
 #pragma unroll
-                        for (int nt = 0; nt < NT; ++nt)
+                        for (int t = 0; t < DTILES; ++t) {
+                            // RAG: the accumulator copies start here, behind the pads above, and end behind the
+                            // multiply: in that variant (and in trace builds) hipcc otherwise hoists the reads out of
+                            // this branch to the end of the previous visit, right behind the MFMAs that write the
+                            // tiles (tools/isa_lint64.py, finding AGPR); so it does in the second pass of the speculative
+                            // build.  The other variants do not need the pins
+                            // (the lint checks that) and measure 0.3 % faster without them, at 65 more VGPRs.
+                            if constexpr (RAG || SPEC || FA_RING_SLOTS > 4) asm volatile("" : "+a"(O[qt][t]));
 #pragma unroll
-                            for (int r = 0; r < 16; ++r)
-                                S[qt][nt][r] = (32 * nt + (r & 3) + 8 * (r >> 2) > lim) ? -__builtin_inff() : S[qt][nt][r];
-                    }
-                }
-            } else if constexpr (MASK) {
-                const int d = tile - (4 * qb_rows + wave);
-                if (causal && d >= 0) {  // wave-uniform
-#pragma unroll
-                    for (int qt = 0; qt < 2; ++qt)
-#pragma unroll
-                        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                            for (int r = 0; r < 16; ++r) {
-                                const int key = 32 * nt + (r & 3) + 8 * (r >> 2) + 4 * hi, row = 32 * qt + r31;
-                                S[qt][nt][r] = (d > 0 || key > row) ? -__builtin_inff() : S[qt][nt][r];
-                            }
-                }
-            }
-        };
-        auto dma_k = [&](const uint16_t *src, int stage) {
-#pragma unroll
-            for (int j = 0; j < DMA_PER_WAVE; ++j)
-                glds16_sv_m0(src, k_off[j], smem_base + stage * TILE + (wave + NWAVES * j) * 1024);
-        };
-        auto dma_v = [&](const uint16_t *src, int stage) {
-#pragma unroll
-            for (int j = 0; j < DMA_PER_WAVE; ++j)
-                glds16_sv_m0(src, v_off[j], smem_base + V_BASE + stage * TILE + (wave + NWAVES * j) * 1024);
-        };
-        const uint16_t *kq = nullptr, *vq = nullptr;  // next K / V tile to request (set per item below)
-        // operand ring: slot u % RS holds operand u; the loads of operands step + LA, step + LA + 1 are issued
-        // at (even) step `step`, into the slots of the two operands whose MFMAs have just issued.  RS = 4:
-        // two steps (4 MFMAs, ~170 cycles) between a load and its use -- less than the LDS latency with four
-        // waves reading operands and the DMA writing: tools/trace64.hip (-DFA_TRACE=2) shows the wait in front
-        // of every fourth MFMA stall 25-50 cycles.  RS = 8: six steps.
-        constexpr int RS = FA_RING_SLOTS, LA = RS - 2;
-        vec8 ring[RS];
-        vec8 Qr2[2][KS];  // the next item's Q (AGPRs), requested during the item's first visit
-        float mraw[2];   // row max of the S tile formed by the last visit (the next item's S(0))
-        // the first two visits after a seam: the epilogue's row stores are in flight in front of the pieces
-        // the counted waits allow -- 16 of them, or fewer (RAG: a wave whose rows reach beyond the sequence
-        // skips stores; counted down to a multiple of 8, which only waits for more)
-        int seam_st = 0;
-        // ---- the next item's Q, through LDS -------------------------------------------------------
-        // The MFMA wants a lane to hold one Q row's 16-byte chunk; fetched like that from global memory
-        // a wave-instruction touches 32 rows (32 cache lines for 1 KiB), and 16 of them in a burst cost
-        // each wave 0.7-3 k cycles of queueing in the address path (tools/trace64.hip).  So a 32-row Q
-        // tile travels like a K tile: 8 coalesced 1-KiB LDS-DMA pieces (4 whole rows each) into this
-        // wave's O staging area (idle between seams), XOR-swizzled, then 8 conflict-free ds_read_b128
-        // straight into the spare Q set.  One tile per round: tile 0 is requested at the seam (or at
-        // the end of the prologue), read behind the barrier of visit 1, where tile 1 is requested,
-        // which is read behind the barrier of visit 2 -- all on the slow path that the sync point of
-        // an item's first three visits takes anyway, so the steady state carries none of it.
-        const unsigned q_stage = smem_base + 2 * TR::kStages * TILE + wave * 8192;
-        auto lane_now = [&]() {  // volatile: anything derived from threadIdx would be kept live across the walk
-            int l_;
-            asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l_));
-            return l_;
-        };
-        auto request_q = [&](const uint16_t *Qh, int qblk, int qt, unsigned stage) {  // rows 32 qt .. 32 qt + 31 of this wave's rows
-            const int l_ = lane_now();
-            // piece i: rows 4i .. 4i+3; this lane: row 4i + l/16, chunk (l % 16) ^ (row & 15)
-            //   = ((l % 16) ^ (l / 16)) ^ 4 (i & 3): one lane offset, 64 (i & 3) XORed in per piece
-            const unsigned off = (unsigned)(((int64_t)(l_ >> 4) * ss) * 2) + ((((unsigned)l_ & 15) ^ ((unsigned)l_ >> 4)) << 4);
-            if constexpr (RAG) {
-                const int row_b = qblk * TR::kBr + wave * TR::kRowsPerWave + 32 * qt;
-                if (row_b + 31 >= args.seq_len) {  // wave-uniform: rows beyond the sequence are fetched from its last row
-                    const unsigned chunk_b = (((unsigned)l_ & 15) ^ ((unsigned)l_ >> 4)) << 4;
-                    const int row_s = row_b < args.seq_len - 32 ? row_b : args.seq_len - 32;  // scalar base row (seq_len >= 64)
-                    const uint16_t *rows_s = Qh + (int64_t)row_s * ss;
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        int rg = row_b + 4 * i + (l_ >> 4);
-                        rg = rg < args.seq_len - 1 ? rg : args.seq_len - 1;
-                        glds16_sv_m0(rows_s, (unsigned)(rg - row_s) * (unsigned)(ss * 2) + (chunk_b ^ (64u * (i & 3))), stage + i * 1024);
-                    }
-                    return;
-                }
-            }
-            const uint16_t *rows0 = Qh + ((int64_t)qblk * TR::kBr + wave * TR::kRowsPerWave + 32 * qt) * ss;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) glds16_sv_m0(rows0 + (int64_t)(4 * i) * ss, off ^ (64u * (i & 3)), stage + i * 1024);
-        };
-        auto read_q = [&](vec8 (&dst)[KS], unsigned stage) {  // this lane's chunks: row l % 32, chunk (2 ks + l/32) ^ (row & 15)
-            const int l_ = lane_now();
-            const unsigned base = stage + (l_ & 31) * 256, x = (unsigned)((l_ >> 5) ^ (l_ & 15));
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks)
-                asm volatile("ds_read_b128 %0, %1" : "=a"(dst[ks]) : "v"(base + ((x ^ (2 * ks)) << 4)) : "memory");
-        };
-        auto request_next_q = [&](int qt) { request_q(Qn, qb_n, qt, q_stage); };
-        auto read_next_q = [&](vec8 (&dst)[KS]) { read_q(dst, q_stage); };
-        auto visit = [&](int it, auto &S_cur, auto &S_nxt, auto r_tag) {
-            constexpr int R = decltype(r_tag)::value;  // it & 3
-#ifdef FA_TRACE
-            unsigned long long ts[20];
-            asm volatile("s_memtime %0" : "=s"(ts[0]));
-#endif
-            FA_TL();
-            // the visit's synchronisation point: K(it+2), V(it+1) landed (requested two visits ago;
-            // K(it+1), V(it) were published by the previous barrier), the 8 youngest pieces may fly
-            // on; behind it every wave has finished visit it-1, whose K / V stages the DMA of this
-            // visit overwrites.  In the default plan it sits two MFMAs into the visit, after the
-            // gap-0 lgkmcnt(0) that retires this wave's last LDS reads of visit it-1.
-            auto sync_point = [&]() {
-                if (ABL & 8) return;
-                // One compare and one branch on the common path.  The first three visits of an item take
-                // the slow path: more may be in flight behind the pieces the barrier publishes -- in issue
-                // order: [pieces(last visit of the previous item) | 16 epilogue stores] [Q tile 0: 8]
-                // pieces(0) [Q tile 1: 8] pieces(1) pieces(2) -- and the next item's Q tiles are moved
-                // into the spare Q set here (see request_next_q).
-                if (it >= 3) {
-                    asm volatile("s_waitcnt vmcnt(" FA_VM8 ")\n\ts_barrier" ::: "memory");
-                    return;
-                }
-                const int q8 = has_next ? 8 : 0;
-                const int allow = (it < 2) ? 8 + seam_st + q8 : 8 + q8;
-                if (allow == 8) asm volatile("s_waitcnt vmcnt(" FA_VM8 ")\n\ts_barrier" ::: "memory");
-                else if (allow == 16) asm volatile("s_waitcnt vmcnt(" FA_VM16 ")\n\ts_barrier" ::: "memory");
-                else if (allow == 24) asm volatile("s_waitcnt vmcnt(" FA_VM24 ")\n\ts_barrier" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(" FA_VM32 ")\n\ts_barrier" ::: "memory");
-                if constexpr (R == 1 || R == 2) {
-                    if (it == R && has_next) {
-                        asm volatile("s_waitcnt vmcnt(" FA_VM8 ")" ::: "memory");  // Q tile R-1 landed (only pieces(R-1) are younger)
-                        read_next_q(Qr2[R - 1]);
-                        if constexpr (R == 1) {
-                            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // ... and read: its image may be overwritten
-                            request_next_q(1);
+                            for (int r = 0; r < 16; ++r) O[qt][t][r] *= alpha;
+                            if constexpr (RAG || SPEC || FA_RING_SLOTS > 4) asm volatile("" : "+a"(O[qt][t]));
                         }
                     }
                 }
-            };
-            if constexpr (R == 3) {
-                // last visit of an item forms the next item's S(0): swap the next item's Q in
-                if (it + 1 == nkc && has_next) {
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the LDS reads into the spare set (visits 1, 2)
-#pragma unroll
-                    for (int qt = 0; qt < 2; ++qt)
-#pragma unroll
-                        for (int ks = 0; ks < KS; ++ks) {
-                            asm volatile("" : "+a"(Qr2[qt][ks]));  // value defined by the asm loads
-                            Qr[qt][ks] = Qr2[qt][ks];
-                        }
-                    asm volatile("s_nop 3" ::: "memory");  // accvgpr write -> MFMA operand
-                }
-            }
-            if constexpr (plan.barrier[2] == 0) {
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                sync_point();
-            }
-            const unsigned kdst = smem_base + R * TILE + wave * 1024;                        // K(it+4) -> stage of K(it)
-            const unsigned vdst = smem_base + V_BASE + ((R + 3) & 3) * TILE + wave * 1024;   // V(it+3) -> stage of V(it-1)
-            if (!FAST && resc_any) {  // wave-uniform, rare: move the reference max of one or both Q tiles
-                asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");  // MFMA D (O) -> VALU read
-#pragma unroll
-                for (int qt = 0; qt < 2; ++qt) {
-                    if (!(resc_any & (1u << qt))) continue;
-                    const float m_new = fmaxf(m[qt], m_pend[qt]);
-                    const float alpha = __builtin_amdgcn_exp2f((m[qt] - m_new) * c);
-                    m[qt] = m_new;
-                    neg_msc[qt] = -(finite_or_zero(m_new) * c);
-                    thr[qt] = m_new + TAU / c;
-                    rs[qt][0] *= alpha;
-                    rs[qt][1] *= alpha;
-#pragma unroll
-                    for (int t = 0; t < DTILES; ++t) {
-                        // RAG: the accumulator copies start here, behind the pads above, and end behind the
-                        // multiply: in that variant (and in trace builds) hipcc otherwise hoists the reads out of
-                        // this branch to the end of the previous visit, right behind the MFMAs that write the
-                        // tiles (tools/isa_lint64.py, finding AGPR); so it does in the second pass of the speculative
-                        // build.  The other variants do not need the pins
-                        // (the lint checks that) and measure 0.3 % faster without them, at 65 more VGPRs.
-                        if constexpr (RAG || SPEC || FA_RING_SLOTS > 4) asm volatile("" : "+a"(O[qt][t]));
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) O[qt][t][r] *= alpha;
-                        if constexpr (RAG || SPEC || FA_RING_SLOTS > 4) asm volatile("" : "+a"(O[qt][t]));
-                    }
-                }
-            }
-            const char *kt = smem + ((R + 1) & 3) * TILE;
-            const char *vt = smem + V_BASE + R * TILE;
-            float vm[2][2];
-            unsigned any01 = 0;
-            auto exp_unit = [&](int u) {  // u = 8*s16 + 2*j + qt: in the order P.V consumes P
-                if constexpr (ABL & 2) return;
-                const int qt = u & 1, j = (u >> 1) & 3, s16 = u >> 3, r = 8 * (s16 & 1) + 2 * j;
-                // exp2(s c - m c), softmax.cuh:51-64.  Scalar f32 forms on purpose: v_pk_fma_f32 /
-                // v_pk_add_f32 here measured -6 % / -12 %; splitting the unit into stages over three
-                // gaps (no dependent pair inside a gap) measured -1.5 %.
-                float p0, p1;
-                if constexpr (ABL & 2048) {  // (timing only: what a pre-scaled Q with -m c fed through the MFMA's C operand would save)
-                    p0 = S_cur[qt][s16 >> 1][r];
-                    p1 = S_cur[qt][s16 >> 1][r + 1];
-                } else {
-                    p0 = __builtin_fmaf(S_cur[qt][s16 >> 1][r], c, neg_msc[qt]);
-                    p1 = __builtin_fmaf(S_cur[qt][s16 >> 1][r + 1], c, neg_msc[qt]);
-                }
-                if (!(ABL & 1)) {
-                    p0 = __builtin_amdgcn_exp2f(p0);
-                    p1 = __builtin_amdgcn_exp2f(p1);
-                }
-                rs[qt][0] += p0;  // fp32 P, before rounding (softmax.cuh:66-83)
-                rs[qt][1] += p1;
-                // pin the adds to this gap: hipcc otherwise sinks the whole row-sum chain (and keeps
-                // every p alive) to the first use of l, behind the next visit's barrier
-                asm volatile("" : "+v"(rs[qt][0]), "+v"(rs[qt][1]));
-                unsigned pk = E::pack2(p0, p1);
-                // ... and the pack: sunk below a branch of the stream it would sit right in front of the
-                // MFMA that reads it, which hipcc does not pad (the MFMAs are opaque asm)
-                asm volatile("" : "+v"(pk));
-                Pw[qt][s16][j] = pk;
-            };
-            auto max_unit = [&](int u) {  // u = 0..31: tile (nt = u>>4, qt = (u>>3)&1), elements 2(u&7), +1
-                const int nt = u >> 4, qt = (u >> 3) & 1, e = 2 * (u & 7), a = u & 1;  // two chains per Q tile
-                if constexpr (ABL & 2) { vm[qt][a] = 0.0f; return; }
-                if constexpr (ABL & 4096) return;  // (timing only: no per-tile row max)
-                // asm forms: fmaxf() on MFMA results makes hipcc canonicalise both inputs first
-                // volatile: pinned to its gap (S_nxt is rewritten next visit).  Not an empty "+v" asm behind
-                // it: hipcc pads an asm that reads what the asm right before it wrote with an s_nop
-                if ((u & 7) < 2 && nt == 0)
-                    asm volatile("v_max_f32 %0, %1, %2" : "=v"(vm[qt][a]) : "v"(S_nxt[qt][nt][e]), "v"(S_nxt[qt][nt][e + 1]));
-                else
-                    asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(vm[qt][a]) : "v"(S_nxt[qt][nt][e]), "v"(S_nxt[qt][nt][e + 1]));
-            };
-            auto lane_pair_max = [&](float x) {
-                auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-                float d;
-                asm volatile("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(__uint_as_float(r[0])), "v"(__uint_as_float(r[1])));
-                return d;
-            };
-            auto tail_unit = [&](int k) {
-                if constexpr (FAST || (ABL & 4096)) { if (k < 8) return; }
-                if (k == 1) {
-                    asm volatile("v_max_f32 %0, %0, %1" : "+v"(vm[0][0]) : "v"(vm[0][1]));
-                    asm volatile("v_max_f32 %0, %0, %1" : "+v"(vm[1][0]) : "v"(vm[1][1]));
-                }
-                if (k == 2) vm[0][0] = lane_pair_max(vm[0][0]);
-                if (k == 3) vm[1][0] = lane_pair_max(vm[1][0]);
-                if (k == 4) {
-                    mraw[0] = m_pend[0] = vm[0][0];
-                    mraw[1] = m_pend[1] = vm[1][0];
-                    asm volatile("" : "+v"(m_pend[0]), "+v"(m_pend[1]));
-                }
-                if (k == 6 || k == 7) {
-                    const int qt = k - 6;
-                    any01 |= (__ballot(m_pend[qt] > thr[qt]) != 0 ? 1u : 0u) << qt;
-                }
-                if (k == 8) {
-                    if constexpr (!FAST) resc_any = any01;
-                    if constexpr (RAG) {  // (a window per tile: no pointer chain)
-                        kq = tile_g(Kc, Kn, it + 5);
-                        vq = tile_g(Vc, Vn, it + 4);
+                const char *kt = smem + ((R + 1) & 3) * TILE;
+                const char *vt = smem + V_BASE + R * TILE;
+                float vm[2][2];
+                unsigned any01 = 0;
+                auto exp_unit = [&](int u) {  // u = 8*s16 + 2*j + qt: in the order P.V consumes P
+                    if constexpr (ABL & 2) return;
+                    const int qt = u & 1, j = (u >> 1) & 3, s16 = u >> 3, r = 8 * (s16 & 1) + 2 * j;
+                    // exp2(s c - m c), softmax.cuh:51-64.  Scalar f32 forms on purpose: v_pk_fma_f32 /
+                    // v_pk_add_f32 here measured -6 % / -12 %; splitting the unit into stages over three
+                    // gaps (no dependent pair inside a gap) measured -1.5 %.
+                    float p0, p1;
+                    if constexpr (ABL & 2048) {  // (timing only: what a pre-scaled Q with -m c fed through the MFMA's C operand would save)
+                        p0 = S_cur[qt][s16 >> 1][r];
+                        p1 = S_cur[qt][s16 >> 1][r + 1];
                     } else {
-                        kq = (it + 5 == nkc) ? Kn + (int64_t)(nkn - 1) * tile_stride : kq - tile_stride;
-                        vq = (it + 4 == nkc) ? Vn + (int64_t)(nkn - 1) * tile_stride : vq - tile_stride;
+                        p0 = __builtin_fmaf(S_cur[qt][s16 >> 1][r], c, neg_msc[qt]);
+                        p1 = __builtin_fmaf(S_cur[qt][s16 >> 1][r + 1], c, neg_msc[qt]);
                     }
-                    if constexpr (R == 1) seam_st = 0;
-                }
-            };
-            auto tail_step = [&](int k) {  // plan step: 1..8 one unit each; 10..14 the masked plan's merged steps
-                if (k < 10) tail_unit(k);
-                if (k == 10) tail_unit(1);
-                if (k == 11) { tail_unit(2); tail_unit(3); }
-                if (k == 12) { tail_unit(4); tail_unit(5); }
-                if (k == 13) { tail_unit(6); tail_unit(7); }
-                if (k == 14) tail_unit(8);
-            };
-            // operand u of the visit: 16 K fragments, 16 V fragments, then the first LA K fragments
-            // of the NEXT visit (its tile was published by this visit's barrier), so that no LDS
-            // latency is exposed at the visit seam
-            const char *kt_next = smem + ((R + 2) & 3) * TILE;
-            auto operand = [&](int u) -> vec8 {
-                if constexpr (ABL & 4) return __builtin_bit_cast(vec8, Pw[u & 1][(u >> 1) & 3]);
-                return u < 16 ? k_frag(kt, u) : (u < 32 ? v_frag(vt, u - 16) : k_frag(kt_next, u - 32));
-            };
-            static_for<0, 64>([&](auto gap_tag) {
-                constexpr int g = decltype(gap_tag)::value;
-                constexpr int step = g >> 1, qt = g & 1;
-                // An MFMA reads its A / B registers for a few cycles after it issues, and hipcc -- to
-                // which the MFMAs are opaque asm -- is free to hand a register that just died to the very
-                // next VALU instruction (seen: the pair-max temporary landing in the A operand of the
-                // MFMA in front of it; one-ulp run-to-run differences that an s_nop 7 behind every MFMA
-                // removed).  So every operand is kept alive until the NEXT MFMA has issued: an empty asm
-                // that names it, placed behind that MFMA (volatile asm statements keep their order).
-                vec8 prev_a = ring[(step + RS - 1) % RS];  // A operand of the previous step (its slot is reloaded below)
-                if constexpr (qt == 0 && (step & 1) == 0) {  // operands in pairs: one counted wait per two steps
-                    // operands step, step + 1 landed; the LDS reads of operands step + 2 ... step + LA - 1 (one per
-                    // K fragment, two per V fragment; LDS returns in order) may still fly
-                    constexpr int fly = [] { int n = 0; for (int u = step + 2; u < step + LA; ++u) n += (u >= 16 && u < 32) ? 2 : 1; return n; }();
+                    if (!(ABL & 1)) {
+                        p0 = __builtin_amdgcn_exp2f(p0);
+                        p1 = __builtin_amdgcn_exp2f(p1);
+                    }
+                    rs[qt][0] += p0;  // fp32 P, before rounding (softmax.cuh:66-83)
+                    rs[qt][1] += p1;
+                    // pin the adds to this gap: hipcc otherwise sinks the whole row-sum chain (and keeps
+                    // every p alive) to the first use of l, behind the next visit's barrier
+                    asm volatile("" : "+v"(rs[qt][0]), "+v"(rs[qt][1]));
+                    unsigned pk = E::pack2(p0, p1);
+                    // ... and the pack: sunk below a branch of the stream it would sit right in front of the
+                    // MFMA that reads it, which hipcc does not pad (the MFMAs are opaque asm)
+                    asm volatile("" : "+v"(pk));
+                    Pw[qt][s16][j] = pk;
+                };
+                auto max_unit = [&](int u) {  // u = 0..31: tile (nt = u>>4, qt = (u>>3)&1), elements 2(u&7), +1
+                    const int nt = u >> 4, qt = (u >> 3) & 1, e = 2 * (u & 7), a = u & 1;  // two chains per Q tile
+                    if constexpr (ABL & 2) { vm[qt][a] = 0.0f; return; }
+                    if constexpr (ABL & 4096) return;  // (timing only: no per-tile row max)
+                    // asm forms: fmaxf() on MFMA results makes hipcc canonicalise both inputs first
+                    // volatile: pinned to its gap (S_nxt is rewritten next visit).  Not an empty "+v" asm behind
+                    // it: hipcc pads an asm that reads what the asm right before it wrote with an s_nop
+                    if ((u & 7) < 2 && nt == 0)
+                        asm volatile("v_max_f32 %0, %1, %2" : "=v"(vm[qt][a]) : "v"(S_nxt[qt][nt][e]), "v"(S_nxt[qt][nt][e + 1]));
+                    else
+                        asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(vm[qt][a]) : "v"(S_nxt[qt][nt][e]), "v"(S_nxt[qt][nt][e + 1]));
+                };
+                auto lane_pair_max = [&](float x) {
+                    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+                    float d;
+                    asm volatile("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(__uint_as_float(r[0])), "v"(__uint_as_float(r[1])));
+                    return d;
+                };
+                auto tail_unit = [&](int k) {
+                    if constexpr (FAST || (ABL & 4096)) { if (k < 8) return; }
+                    if (k == 1) {
+                        asm volatile("v_max_f32 %0, %0, %1" : "+v"(vm[0][0]) : "v"(vm[0][1]));
+                        asm volatile("v_max_f32 %0, %0, %1" : "+v"(vm[1][0]) : "v"(vm[1][1]));
+                    }
+                    if (k == 2) vm[0][0] = lane_pair_max(vm[0][0]);
+                    if (k == 3) vm[1][0] = lane_pair_max(vm[1][0]);
+                    if (k == 4) {
+                        mraw[0] = m_pend[0] = vm[0][0];
+                        mraw[1] = m_pend[1] = vm[1][0];
+                        asm volatile("" : "+v"(m_pend[0]), "+v"(m_pend[1]));
+                    }
+                    if (k == 6 || k == 7) {
+                        const int qt = k - 6;
+                        any01 |= (__ballot(m_pend[qt] > thr[qt]) != 0 ? 1u : 0u) << qt;
+                    }
+                    if (k == 8) {
+                        if constexpr (!FAST) resc_any = any01;
+                        if constexpr (RAG) {  // (a window per tile: no pointer chain)
+                            kq = tile_g(Kc, Kn, it + 5);
+                            vq = tile_g(Vc, Vn, it + 4);
+                        } else {
+                            kq = (it + 5 == nkc) ? Kn + (int64_t)(nkn - 1) * tile_stride : kq - tile_stride;
+                            vq = (it + 4 == nkc) ? Vn + (int64_t)(nkn - 1) * tile_stride : vq - tile_stride;
+                        }
+                        if constexpr (R == 1) seam_st = 0;
+                    }
+                };
+                auto tail_step = [&](int k) {  // plan step: 1..8 one unit each; 10..14 the masked plan's merged steps
+                    if (k < 10) tail_unit(k);
+                    if (k == 10) tail_unit(1);
+                    if (k == 11) { tail_unit(2); tail_unit(3); }
+                    if (k == 12) { tail_unit(4); tail_unit(5); }
+                    if (k == 13) { tail_unit(6); tail_unit(7); }
+                    if (k == 14) tail_unit(8);
+                };
+                // operand u of the visit: 16 K fragments, 16 V fragments, then the first LA K fragments
+                // of the NEXT visit (its tile was published by this visit's barrier), so that no LDS
+                // latency is exposed at the visit seam
+                const char *kt_next = smem + ((R + 2) & 3) * TILE;
+                auto operand = [&](int u) -> vec8 {
+                    if constexpr (ABL & 4) return __builtin_bit_cast(vec8, Pw[u & 1][(u >> 1) & 3]);
+                    return u < 16 ? k_frag(kt, u) : (u < 32 ? v_frag(vt, u - 16) : k_frag(kt_next, u - 32));
+                };
+                static_for<0, 64>([&](auto gap_tag) {
+                    constexpr int g = decltype(gap_tag)::value;
+                    constexpr int step = g >> 1, qt = g & 1;
+                    // An MFMA reads its A / B registers for a few cycles after it issues, and hipcc -- to
+                    // which the MFMAs are opaque asm -- is free to hand a register that just died to the very
+                    // next VALU instruction (seen: the pair-max temporary landing in the A operand of the
+                    // MFMA in front of it; one-ulp run-to-run differences that an s_nop 7 behind every MFMA
+                    // removed).  So every operand is kept alive until the NEXT MFMA has issued: an empty asm
+                    // that names it, placed behind that MFMA (volatile asm statements keep their order).
+                    vec8 prev_a = ring[(step + RS - 1) % RS];  // A operand of the previous step (its slot is reloaded below)
+                    if constexpr (qt == 0 && (step & 1) == 0) {  // operands in pairs: one counted wait per two steps
+                        // operands step, step + 1 landed; the LDS reads of operands step + 2 ... step + LA - 1 (one per
+                        // K fragment, two per V fragment; LDS returns in order) may still fly
+                        constexpr int fly = [] { int n = 0; for (int u = step + 2; u < step + LA; ++u) n += (u >= 16 && u < 32) ? 2 : 1; return n; }();
 #ifdef FA_TRACE
-                    __builtin_amdgcn_s_waitcnt(0xC07F);      // (s_memtime returns out of order: no counting)
+                        __builtin_amdgcn_s_waitcnt(0xC07F);      // (s_memtime returns out of order: no counting)
 #else
-                    __builtin_amdgcn_s_waitcnt(0xC07F | (fly << 8));
+                        __builtin_amdgcn_s_waitcnt(0xC07F | (fly << 8));
 #endif
 #if defined(FA_TRACE) && FA_TRACE == 1
-                    asm volatile("s_memtime %0" : "=s"(ts[2 + step / 2]));
+                        asm volatile("s_memtime %0" : "=s"(ts[2 + step / 2]));
 #endif
-                    ring[(step + LA) % RS] = operand(step + LA);
-                    ring[(step + LA + 1) % RS] = operand(step + LA + 1);
-                }
-                if constexpr (g < 32) {
-                    qk_mfma(S_nxt, step, qt, ring[step % RS]);
-                } else {
-                    constexpr int s2 = step - 16, s16 = s2 >> 2, t = s2 & 3;
-                    E::mfma_acc_a_p(O[qt][t], ring[step % RS], Pw[qt][s16]);
-                }
+                        ring[(step + LA) % RS] = operand(step + LA);
+                        ring[(step + LA + 1) % RS] = operand(step + LA + 1);
+                    }
+                    if constexpr (g < 32) {
+                        qk_mfma(S_nxt, step, qt, ring[step % RS]);
+                    } else {
+                        constexpr int s2 = step - 16, s16 = s2 >> 2, t = s2 & 3;
+                        E::mfma_acc_a_p(O[qt][t], ring[step % RS], Pw[qt][s16]);
+                    }
 #if defined(FA_TRACE) && FA_TRACE == 2
-                if constexpr (g >= 48) asm volatile("s_memtime %0" : "=s"(ts[2 + g - 48]));  // fine trace of the visit's last 16 gaps
+                    if constexpr (g >= 48) asm volatile("s_memtime %0" : "=s"(ts[2 + g - 48]));  // fine trace of the visit's last 16 gaps
 #endif
-                if constexpr (qt == 0) asm volatile("" ::"v"(prev_a));
-                if constexpr (g >= 33) {
-                    constexpr int pg = g - 1, ps2 = (pg >> 1) - 16;
-                    asm volatile("" ::"v"(Pw[pg & 1][ps2 >> 2]));  // B operand of the previous P.V MFMA
-                }
-                if constexpr (g == 0) asm volatile("" ::"v"(Pw[1][3]));  // ... of the previous visit's last one
-                if constexpr (plan.barrier[g] != 0) sync_point();
-                if constexpr (MASK && g == 34) {
-                    // S(it+1) is complete (last written at gap 31): causal mask, before its row max.
-                    // The last visit's S tile is the NEXT item's S(0).
-                    if (it + 1 < nkc) mask_tile(S_nxt, nkc - 2 - it, qb_c);
-                    else mask_tile(S_nxt, nkn - 1, qb_n);
-                }
-                if constexpr (g < 63 && plan.dma[g + 1] >= 0 && !(ABL & 16)) {
-                    // M0 (LDS destination) of the DMA piece of the NEXT gap: the write needs one instruction
-                    // between it and the DMA, and that gap's MFMA is one (hipcc itself never touches M0 here)
-                    constexpr int j = plan.dma[g + 1] >> 1;
-                    asm volatile("s_mov_b32 m0, %0" ::"s"((plan.dma[g + 1] & 1) == 0 ? kdst + NWAVES * j * 1024
-                                                                                      : vdst + NWAVES * j * 1024));
-                }
-                if constexpr (plan.dma[g] >= 0 && !(ABL & 16)) {  // one 1-KiB DMA piece (its M0 was set one gap ago)
-                    constexpr int j = plan.dma[g] >> 1;
-                    static_assert(g > 0 && plan.dma[g - 1] < 0, "a DMA piece needs the gap before it for its M0");
-                    // per-piece lane offsets: 6 more VGPRs than one offset + a scalar piece stride (piece j
-                    // of a wave starts 16 rows below piece j-1), but 16 fewer SALU instructions per
-                    // visit (+0.5 %)
-                    if constexpr ((plan.dma[g] & 1) == 0) glds16_issue(kq, k_off[j]);
-                    else glds16_issue(vq, v_off[j]);
-                }
-                static_for<0, plan.exp_n[g]>([&](auto i) { exp_unit(plan.exp_first[g] + decltype(i)::value); });
-                static_for<0, plan.max_n[g]>([&](auto i) { max_unit(plan.max_first[g] + decltype(i)::value); });
-                if constexpr (plan.tail[g] > 0) tail_step(plan.tail[g]);
-                __builtin_amdgcn_sched_barrier(0);
-            });
-#ifdef FA_TRACE
-            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts[18])::"memory");
-            if (item == args.trace_block && it == args.trace_visit && lane == 0) {
-#pragma unroll
-                for (int i = 0; i < 19; ++i) args.trace[wave * 24 + i] = ts[i];
-            }
-#endif
-        };
-        // ---- first item: prologue -------------------------------------------------------------
-        // causal: an item costs ~(qb + 1), and along the walk a workgroup would meet the same Q-block
-        // position of a head again and again (round r: slot w + G r of the XCD's item list).  So
-        // odd rounds run their G-slot window of a head (or their whole heads, if a head is shorter than
-        // the window) in reverse: still every Q block of every head exactly once, and two consecutive
-        // rounds sum to the same work for every workgroup.  Needs windows and rounds to line up
-        // (Q blocks per head and workgroups per XCD both powers of two, as a rule); otherwise the walk
-        // stays in order -- correct, just less balanced.
-        auto walk_qb = [&](int it_, int pos) {
-            const int G = (args.n_bh & 7) == 0 ? (int)gridDim.x >> 3 : (int)gridDim.x;
-            const int W = nq < G ? nq : G;
-            if (W <= 0 || G % W != 0 || nq % W != 0) return pos;
-            const int in_w = pos % W;
-            return (pos / W) * W + (((it_ / (int)gridDim.x) & 1) ? W - 1 - in_w : in_w);
-        };
-        auto set_next = [&]() {  // coordinates of the item after `item` (or `item` again)
-            ord_n = next_ord(ord);
-            has_next = ord_n >= 0;
-            const int nitem = (int)blockIdx.x + ord_n * (int)gridDim.x;
-            int bh_n;
-            item_coords(has_next ? nitem : item, bh_n, qb_n);
-            if (causal) {
-                qb_n = walk_qb(has_next ? nitem : item, qb_n);
-                nkn = 4 * (qb_n + 1);
-            }
-            const int b_n = bh_n / args.n_heads, h_n = bh_n % args.n_heads;
-            const int64_t off_n = (int64_t)b_n * args.batch_stride + (int64_t)h_n * args.head_stride;
-            Qn = (const uint16_t *)args.q + off_n;
-            Kn = (const uint16_t *)args.k + off_n;
-            Vn = (const uint16_t *)args.v + off_n;
-            On = (uint16_t *)args.o + off_n;
-        };
-        set_next();
-        // Every CU starts at once and the first requests return at ~11 B/cycle per CU, in issue order:
-        // K(0) (common code above) and Q -- all S(0) needs -- go first.  Q travels like the next item's Q
-        // does later (coalesced LDS-DMA pieces, then ds_read_b128 into the Q registers; fetched row-per-lane
-        // a wave-instruction touches 32 cache lines and the 16 of them took ~9 k cycles to issue): tile 0
-        // through this wave's staging area, tile 1 through its quarter of K stage 3 / V stage 3, which
-        // are idle until K(3) / V(2) are requested behind the barrier below.  Then K(1), V(0) here and
-        // K(2), V(1) | K(3), V(2) under S(0), in the order the counted waits assume.
-        FA_TLP(0);  // K(0) requested, next item known
-        request_q(Qg, qb, 0, q_stage);
-        request_q(Qg, qb, 1, smem_base + (wave < 2 ? 3 * TILE : V_BASE + 3 * TILE) + (wave & 1) * 8192);
-        dma_k(tile_g(Kc, Kn, 1), 1);
-        dma_v(tile_g(Vc, Vn, 0), 0);
-        FA_TLP(1);  // Q, K(1), V(0) requested
-        if (!(ABL & 8)) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // K(0), Q landed: K(1), V(0) fly on
-        FA_TLP(2);  // K(0), Q landed
-        read_q(Qr[0], q_stage);
-        read_q(Qr[1], smem_base + (wave < 2 ? 3 * TILE : V_BASE + 3 * TILE) + (wave & 1) * 8192);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        barrier();  // K(0) is visible, and every wave has read its Q tile out of stages 3
-        FA_TLP(3);  // Q read, barrier passed
-        {
-            // S(0) and its row max, which becomes the first reference max (O = l = 0)
-            const char *kt = smem;
-            vec8 a_all[16];  // every operand stays allocated until the last MFMA has issued (see visit())
-#pragma unroll
-            for (int step = 0; step < 16; ++step) a_all[step] = k_frag(kt, step);
-            static_for<0, 16>([&](auto step_tag) {
-                constexpr int step = decltype(step_tag)::value;
-                qk_mfma(Sa, step, 0, a_all[step]);
-                qk_mfma(Sa, step, 1, a_all[step]);
-            });
-            // the rest of the first requests, issued while the matrix pipe works through S(0): a CU keeps
-            // only ~32 KB of requests in flight, so asking for all 176 KB up front held the waves at the
-            // issue of the last pieces (~11 k cycles) long after K(0) and Q had landed
-            dma_k(tile_g(Kc, Kn, 2), 2);
-            dma_v(tile_g(Vc, Vn, 1), 1);
-            dma_k(tile_g(Kc, Kn, 3), 3);
-            dma_v(tile_g(Vc, Vn, 2), 2);
-            kq = tile_g(Kc, Kn, 4);
-            vq = tile_g(Vc, Vn, 3);
-            if (has_next) request_next_q(0);
-            FA_TLP(4);  // S(0) MFMAs and the remaining requests issued
-            asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // MFMA D -> VALU read
-#pragma unroll
-            for (int step = 0; step < 16; ++step) asm volatile("" ::"v"(a_all[step]));
-            mask_tile(Sa, nkc - 1, qb_c);
-#pragma unroll
-            for (int qt = 0; qt < 2; ++qt) {
-                float v = Sa[qt][0][0];
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) v = fmaxf(v, Sa[qt][nt][r]);
-                m[qt] = pair_max(v);
-                neg_msc[qt] = -(finite_or_zero(m[qt]) * c);
-                thr[qt] = m[qt] + TAU / c;
-                m_pend[qt] = m[qt];
-            }
-            if (!(ABL & 8)) {  // K(1) landed (under S(0))
-                if (has_next) asm volatile("s_waitcnt vmcnt(28)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
-            }
-            FA_TLP(5);  // row max done, K(1) landed
-            barrier();
-            FA_TLF();
-            FA_TL();  // S(0) formed, K(1) landed
-#pragma unroll
-            for (int u = 0; u < LA; ++u) ring[u] = k_frag(smem + TILE, u);  // first operands of visit 0: K(1)
-        }
-        // O of one item: finish l, normalise, RNE to 16 bit (final_softmax_normalization
-        // softmax.cuh:107-128; forward_kernel.cuh:186-203), through this wave's 8-KB LDS staging
-        // area one 32-row Q tile at a time so that the global stores are whole 256-B rows (16 B per
-        // lane, 4 rows per wave-instruction).  Wave-private: no barrier.  The 16-B chunk index is
-        // XORed with (row & 15) so the 8-B writes and the 16-B reads are bank-conflict free.
-        auto store_item = [&]() {
-            asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // last P.V -> VALU reads of O
-            char *stage_o = smem + 2 * TR::kStages * TILE + wave * (32 * ROWB);
-            // lane-derived indices recomputed here from a volatile v_mbcnt: values derived from
-            // threadIdx at kernel entry would stay live (and get spilled) across the whole item loop
-            int lane;
-            asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
-            const int r31 = lane & 31, hi = lane >> 5;
-            const int rsub = lane / CPR, chunk = lane & (CPR - 1);
-#pragma unroll
-            for (int qt = 0; qt < 2; ++qt) {
-                const float l_row = pair_sum(rs[qt][0] + rs[qt][1]);
-                if constexpr (FAST) {
-                    // every P of the row is <= l: below the limit nothing overflowed on the way (fp32 exp2, the
-                    // 16-bit P, fp32 O); NaN fails the compare too.  A failed item is stored all the same (its
-                    // rows are rewritten by the second pass).
-                    constexpr float kLimit = DT == 5 ? 32768.0f : 1.2676506e30f;  // 2^15 (fp16 P < 65504) / 2^100
-                    if (__ballot(!(l_row < kLimit)) != 0) failed |= 1ull << (ord < 63 ? ord : 63);
-                }
-                const float inv = 1.0f / l_row;
-                char *wp = stage_o + r31 * ROWB + hi * 8;
-#pragma unroll
-                for (int t = 0; t < DTILES; ++t) {
-                    // (the tile's accumulator copies start here: hipcc otherwise reads all 128 up front and spills)
-                    asm volatile("" : "+a"(O[qt][t]));
-                    // regs 4rq..4rq+3 : d = 32t + 8rq + 4hi + 0..3  -> chunk 4t + rq, half hi.  Converted in
-                    // pairs (one v_cvt_pk per two values; a per-element convert costs three instructions per pair)
-#pragma unroll
-                    for (int rq = 0; rq < 4; ++rq) {
-                        typedef float f32x2 __attribute__((ext_vector_type(2)));
-                        const f32x2 lo2 = f32x2{O[qt][t][4 * rq], O[qt][t][4 * rq + 1]} * inv;  // v_pk_mul_f32
-                        const f32x2 hi2 = f32x2{O[qt][t][4 * rq + 2], O[qt][t][4 * rq + 3]} * inv;
-                        u32x2 w;
-                        w[0] = E::pack2(lo2[0], lo2[1]);
-                        w[1] = E::pack2(hi2[0], hi2[1]);
-                        *(u32x2 *)(wp + (((4 * t + rq) ^ swz_of(r31)) << 4)) = w;
+                    if constexpr (qt == 0) asm volatile("" ::"v"(prev_a));
+                    if constexpr (g >= 33) {
+                        constexpr int pg = g - 1, ps2 = (pg >> 1) - 16;
+                        asm volatile("" ::"v"(Pw[pg & 1][ps2 >> 2]));  // B operand of the previous P.V MFMA
                     }
-                    __builtin_amdgcn_sched_barrier(0);  // one d tile at a time: S(0) of the next item is live
-                }
-                // rows RPP i + rsub of the tile: a scalar row base per store, one 32-bit lane offset for all;
-                // all reads first (the waits then count down), and the read address is one XOR per row
-                // group: row = RPP i + rsub, so chunk ^ swz_of(row) = (chunk ^ rsub) ^ (RPP i & 15)
-                static_assert(D == 128 && RPP == 4, "epilogue address split");
-                const uint16_t *rows0 = Oc + ((int64_t)qb_c * TR::kBr + wave * TR::kRowsPerWave + qt * 32) * ss;
-                const unsigned lane_off = (unsigned)rsub * (unsigned)ss * 2u + (unsigned)chunk * 16u;
-                const unsigned rd0 = (unsigned)rsub * ROWB + ((unsigned)(chunk ^ rsub) << 4);
-                s16x8 v[32 / RPP];
-#pragma unroll
-                for (int i = 0; i < 32 / RPP; ++i)
-                    v[i] = *(const s16x8 *)(stage_o + RPP * i * ROWB + (rd0 ^ (((RPP * i) & 15u) << 4)));
-#pragma unroll
-                for (int i = 0; i < 32 / RPP; ++i) {
-                    // non-temporal: O is written once and not read again by this kernel (+1.3...2.8 % at
-                    // seq_len <= 1024, where the store-issue-bound epilogue is a visible share).
-                    // asm: scalar row base + 32-bit lane offset (hipcc builds a 64-bit address per lane and store)
-                    if constexpr (RAG) {  // rows beyond the sequence are not stored
-                        if (qb_c * TR::kBr + wave * TR::kRowsPerWave + qt * 32 + RPP * i + rsub >= args.seq_len) continue;
+                    if constexpr (g == 0) asm volatile("" ::"v"(Pw[1][3]));  // ... of the previous visit's last one
+                    if constexpr (plan.barrier[g] != 0) sync_point();
+                    if constexpr (MASK && g == 34) {
+                        // S(it+1) is complete (last written at gap 31): causal mask, before its row max.
+                        // The last visit's S tile is the NEXT item's S(0).
+                        if (it + 1 < nkc) mask_tile(S_nxt, nkc - 2 - it, qb_c);
+                        else mask_tile(S_nxt, nkn - 1, qb_n);
                     }
-                    asm volatile("global_store_dwordx4 %0, %1, %2 nt" ::"v"(lane_off), "v"(v[i]), "s"(rows0 + (int64_t)(RPP * i) * ss));
+                    if constexpr (g < 63 && plan.dma[g + 1] >= 0 && !(ABL & 16)) {
+                        // M0 (LDS destination) of the DMA piece of the NEXT gap: the write needs one instruction
+                        // between it and the DMA, and that gap's MFMA is one (hipcc itself never touches M0 here)
+                        constexpr int j = plan.dma[g + 1] >> 1;
+                        asm volatile("s_mov_b32 m0, %0" ::"s"((plan.dma[g + 1] & 1) == 0 ? kdst + NWAVES * j * 1024
+                                                                                          : vdst + NWAVES * j * 1024));
+                    }
+                    if constexpr (plan.dma[g] >= 0 && !(ABL & 16)) {  // one 1-KiB DMA piece (its M0 was set one gap ago)
+                        constexpr int j = plan.dma[g] >> 1;
+                        static_assert(g > 0 && plan.dma[g - 1] < 0, "a DMA piece needs the gap before it for its M0");
+                        // per-piece lane offsets: 6 more VGPRs than one offset + a scalar piece stride (piece j
+                        // of a wave starts 16 rows below piece j-1), but 16 fewer SALU instructions per
+                        // visit (+0.5 %)
+                        if constexpr ((plan.dma[g] & 1) == 0) glds16_issue(kq, k_off[j]);
+                        else glds16_issue(vq, v_off[j]);
+                    }
+                    static_for<0, plan.exp_n[g]>([&](auto i) { exp_unit(plan.exp_first[g] + decltype(i)::value); });
+                    static_for<0, plan.max_n[g]>([&](auto i) { max_unit(plan.max_first[g] + decltype(i)::value); });
+                    if constexpr (plan.tail[g] > 0) tail_step(plan.tail[g]);
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+#ifdef FA_TRACE
+                asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts[18])::"memory");
+                if (item == args.trace_block && it == args.trace_visit && lane == 0) {
+#pragma unroll
+                    for (int i = 0; i < 19; ++i) args.trace[wave * 24 + i] = ts[i];
                 }
-            }
-        };
-        // seq_len is a multiple of B_r = 256, so n_kv = seq_len / 64 is a multiple of 4 = ring depth
-        for (;;) {
-            for (int it = 0; it < nkc; it += 4) {
-                visit(it, Sa, Sb, IntTag<0>{});
-                visit(it + 1, Sb, Sa, IntTag<1>{});
-                visit(it + 2, Sa, Sb, IntTag<2>{});
-                visit(it + 3, Sb, Sa, IntTag<3>{});
-            }
-#ifdef FA_TRACE
-            unsigned long long te0, te1, te2;
-            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(te0)::"memory");
 #endif
-            store_item();
-#ifdef FA_TRACE
-            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(te1)::"memory");
-#endif
-            if (!has_next) break;
-            // ---- seam: the last visit left the next item's S(0) in Sa and its row max in mraw; its
-            // first tiles are landed or in flight, its first operands sit in the ring
-            const int qb_st = qb_c;  // the item just stored
-            (void)qb_st;
-            ord = ord_n;
-            item = (int)blockIdx.x + ord * (int)gridDim.x;
-            Kc = Kn; Vc = Vn; Oc = On; qb_c = qb_n;
-            nkc = nkn;
+            };
+            // ---- first item: prologue -------------------------------------------------------------
+            // causal: an item costs ~(qb + 1), and along the walk a workgroup would meet the same Q-block
+            // position of a head again and again (round r: slot w + G r of the XCD's item list).  So
+            // odd rounds run their G-slot window of a head (or their whole heads, if a head is shorter than
+            // the window) in reverse: still every Q block of every head exactly once, and two consecutive
+            // rounds sum to the same work for every workgroup.  Needs windows and rounds to line up
+            // (Q blocks per head and workgroups per XCD both powers of two, as a rule); otherwise the walk
+            // stays in order -- correct, just less balanced.
+            auto walk_qb = [&](int it_, int pos) {
+                const int G = (args.n_bh & 7) == 0 ? (int)gridDim.x >> 3 : (int)gridDim.x;
+                const int W = nq < G ? nq : G;
+                if (W <= 0 || G % W != 0 || nq % W != 0) return pos;
+                const int in_w = pos % W;
+                return (pos / W) * W + (((it_ / (int)gridDim.x) & 1) ? W - 1 - in_w : in_w);
+            };
+            auto set_next = [&]() {  // coordinates of the item after `item` (or `item` again)
+                ord_n = next_ord(ord);
+                has_next = ord_n >= 0;
+                const int nitem = (int)blockIdx.x + ord_n * (int)gridDim.x;
+                int bh_n;
+                item_coords(has_next ? nitem : item, bh_n, qb_n);
+                if (causal) {
+                    qb_n = walk_qb(has_next ? nitem : item, qb_n);
+                    nkn = 4 * (qb_n + 1);
+                }
+                const int b_n = bh_n / args.n_heads, h_n = bh_n % args.n_heads;
+                const int64_t off_n = (int64_t)b_n * args.batch_stride + (int64_t)h_n * args.head_stride;
+                Qn = (const uint16_t *)args.q + off_n;
+                Kn = (const uint16_t *)args.k + off_n;
+                Vn = (const uint16_t *)args.v + off_n;
+                On = (uint16_t *)args.o + off_n;
+            };
             set_next();
-            kq = tile_g(Kc, Kn, 4);  // visit 0 requests K(4), V(3) (for n_kv == 4 that is already the item after)
-            vq = tile_g(Vc, Vn, 3);
-            if (has_next) request_next_q(0);  // (the staging area is free again: store_item's reads have retired)
-            seam_st = 16;
-            if constexpr (RAG) {  // stores the epilogue above issued: one per four rows inside the sequence (16 per 64 rows)
-                const int rows_in = args.seq_len - (qb_st * TR::kBr + wave * TR::kRowsPerWave);
-                seam_st = rows_in >= 64 ? 16 : (rows_in >= 32 ? 8 : 0);
-            }
-            resc_any = 0;
-            if constexpr (FAST) {
-                // the row max of the S tile the last visit formed (the next item's S(0)): the speculative
-                // schedule has no row-max units, this is the only one an item needs (behind store_item's pads)
+            // Every CU starts at once and the first requests return at ~11 B/cycle per CU, in issue order:
+            // K(0) (common code above) and Q -- all S(0) needs -- go first.  Q travels like the next item's Q
+            // does later (coalesced LDS-DMA pieces, then ds_read_b128 into the Q registers; fetched row-per-lane
+            // a wave-instruction touches 32 cache lines and the 16 of them took ~9 k cycles to issue): tile 0
+            // through this wave's staging area, tile 1 through its quarter of K stage 3 / V stage 3, which
+            // are idle until K(3) / V(2) are requested behind the barrier below.  Then K(1), V(0) here and
+            // K(2), V(1) | K(3), V(2) under S(0), in the order the counted waits assume.
+            FA_TLP(0);  // K(0) requested, next item known
+            request_q(Qg, qb, 0, q_stage);
+            request_q(Qg, qb, 1, smem_base + (wave < 2 ? 3 * TILE : V_BASE + 3 * TILE) + (wave & 1) * 8192);
+            dma_k(tile_g(Kc, Kn, 1), 1);
+            dma_v(tile_g(Vc, Vn, 0), 0);
+            FA_TLP(1);  // Q, K(1), V(0) requested
+            if (!(ABL & 8)) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // K(0), Q landed: K(1), V(0) fly on
+            FA_TLP(2);  // K(0), Q landed
+            read_q(Qr[0], q_stage);
+            read_q(Qr[1], smem_base + (wave < 2 ? 3 * TILE : V_BASE + 3 * TILE) + (wave & 1) * 8192);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            barrier();  // K(0) is visible, and every wave has read its Q tile out of stages 3
+            FA_TLP(3);  // Q read, barrier passed
+            {
+                // S(0) and its row max, which becomes the first reference max (O = l = 0)
+                const char *kt = smem;
+                vec8 a_all[16];  // every operand stays allocated until the last MFMA has issued (see visit())
+#pragma unroll
+                for (int step = 0; step < 16; ++step) a_all[step] = k_frag(kt, step);
+                static_for<0, 16>([&](auto step_tag) {
+                    constexpr int step = decltype(step_tag)::value;
+                    qk_mfma(Sa, step, 0, a_all[step]);
+                    qk_mfma(Sa, step, 1, a_all[step]);
+                });
+                // the rest of the first requests, issued while the matrix pipe works through S(0): a CU keeps
+                // only ~32 KB of requests in flight, so asking for all 176 KB up front held the waves at the
+                // issue of the last pieces (~11 k cycles) long after K(0) and Q had landed
+                dma_k(tile_g(Kc, Kn, 2), 2);
+                dma_v(tile_g(Vc, Vn, 1), 1);
+                dma_k(tile_g(Kc, Kn, 3), 3);
+                dma_v(tile_g(Vc, Vn, 2), 2);
+                kq = tile_g(Kc, Kn, 4);
+                vq = tile_g(Vc, Vn, 3);
+                if (has_next) request_next_q(0);
+                FA_TLP(4);  // S(0) MFMAs and the remaining requests issued
+                asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // MFMA D -> VALU read
+#pragma unroll
+                for (int step = 0; step < 16; ++step) asm volatile("" ::"v"(a_all[step]));
+                mask_tile(Sa, nkc - 1, qb_c);
 #pragma unroll
                 for (int qt = 0; qt < 2; ++qt) {
-                    float v0 = vmax2(Sa[qt][0][0], Sa[qt][0][1]), v1 = vmax2(Sa[qt][1][0], Sa[qt][1][1]);
+                    float v = Sa[qt][0][0];
 #pragma unroll
-                    for (int r = 2; r < 16; r += 2) {
-                        v0 = vmax3(v0, Sa[qt][0][r], Sa[qt][0][r + 1]);
-                        v1 = vmax3(v1, Sa[qt][1][r], Sa[qt][1][r + 1]);
-                    }
-                    mraw[qt] = pair_max(vmax2(v0, v1));
+                    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) v = fmaxf(v, Sa[qt][nt][r]);
+                    m[qt] = pair_max(v);
+                    neg_msc[qt] = -(finite_or_zero(m[qt]) * c);
+                    thr[qt] = m[qt] + TAU / c;
+                    m_pend[qt] = m[qt];
                 }
-            }
+                if (!(ABL & 8)) {  // K(1) landed (under S(0))
+                    if (has_next) asm volatile("s_waitcnt vmcnt(28)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+                }
+                FA_TLP(5);  // row max done, K(1) landed
+                barrier();
+                FA_TLF();
+                FA_TL();  // S(0) formed, K(1) landed
 #pragma unroll
-            for (int qt = 0; qt < 2; ++qt) {
-                m[qt] = mraw[qt];
-                neg_msc[qt] = -(finite_or_zero(m[qt]) * c);
-                thr[qt] = m[qt] + TAU / c;
-                m_pend[qt] = m[qt];
-                rs[qt][0] = rs[qt][1] = 0.0f;
+                for (int u = 0; u < LA; ++u) ring[u] = k_frag(smem + TILE, u);  // first operands of visit 0: K(1)
             }
-            zero_o();
+            // O of one item: finish l, normalise, RNE to 16 bit (final_softmax_normalization
+            // softmax.cuh:107-128; forward_kernel.cuh:186-203), through this wave's 8-KB LDS staging
+            // area one 32-row Q tile at a time so that the global stores are whole 256-B rows (16 B per
+            // lane, 4 rows per wave-instruction).  Wave-private: no barrier.  The 16-B chunk index is
+            // XORed with (row & 15) so the 8-B writes and the 16-B reads are bank-conflict free.
+            auto store_item = [&]() {
+                asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // last P.V -> VALU reads of O
+                char *stage_o = smem + 2 * TR::kStages * TILE + wave * (32 * ROWB);
+                // lane-derived indices recomputed here from a volatile v_mbcnt: values derived from
+                // threadIdx at kernel entry would stay live (and get spilled) across the whole item loop
+                int lane;
+                asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
+                const int r31 = lane & 31, hi = lane >> 5;
+                const int rsub = lane / CPR, chunk = lane & (CPR - 1);
+#pragma unroll
+                for (int qt = 0; qt < 2; ++qt) {
+                    const float l_row = pair_sum(rs[qt][0] + rs[qt][1]);
+                    if constexpr (FAST) {
+                        // every P of the row is <= l: below the limit nothing overflowed on the way (fp32 exp2, the
+                        // 16-bit P, fp32 O); NaN fails the compare too.  A failed item is stored all the same (its
+                        // rows are rewritten by the second pass).
+                        constexpr float kLimit = DT == 5 ? 32768.0f : 1.2676506e30f;  // 2^15 (fp16 P < 65504) / 2^100
+                        if (__ballot(!(l_row < kLimit)) != 0) failed |= 1ull << (ord < 63 ? ord : 63);
+                    }
+                    const float inv = 1.0f / l_row;
+                    char *wp = stage_o + r31 * ROWB + hi * 8;
+#pragma unroll
+                    for (int t = 0; t < DTILES; ++t) {
+                        // (the tile's accumulator copies start here: hipcc otherwise reads all 128 up front and spills)
+                        asm volatile("" : "+a"(O[qt][t]));
+                        // regs 4rq..4rq+3 : d = 32t + 8rq + 4hi + 0..3  -> chunk 4t + rq, half hi.  Converted in
+                        // pairs (one v_cvt_pk per two values; a per-element convert costs three instructions per pair)
+#pragma unroll
+                        for (int rq = 0; rq < 4; ++rq) {
+                            typedef float f32x2 __attribute__((ext_vector_type(2)));
+                            const f32x2 lo2 = f32x2{O[qt][t][4 * rq], O[qt][t][4 * rq + 1]} * inv;  // v_pk_mul_f32
+                            const f32x2 hi2 = f32x2{O[qt][t][4 * rq + 2], O[qt][t][4 * rq + 3]} * inv;
+                            u32x2 w;
+                            w[0] = E::pack2(lo2[0], lo2[1]);
+                            w[1] = E::pack2(hi2[0], hi2[1]);
+                            *(u32x2 *)(wp + (((4 * t + rq) ^ swz_of(r31)) << 4)) = w;
+                        }
+                        __builtin_amdgcn_sched_barrier(0);  // one d tile at a time: S(0) of the next item is live
+                    }
+                    // rows RPP i + rsub of the tile: a scalar row base per store, one 32-bit lane offset for all;
+                    // all reads first (the waits then count down), and the read address is one XOR per row
+                    // group: row = RPP i + rsub, so chunk ^ swz_of(row) = (chunk ^ rsub) ^ (RPP i & 15)
+                    static_assert(D == 128 && RPP == 4, "epilogue address split");
+                    const uint16_t *rows0 = Oc + ((int64_t)qb_c * TR::kBr + wave * TR::kRowsPerWave + qt * 32) * ss;
+                    const unsigned lane_off = (unsigned)rsub * (unsigned)ss * 2u + (unsigned)chunk * 16u;
+                    const unsigned rd0 = (unsigned)rsub * ROWB + ((unsigned)(chunk ^ rsub) << 4);
+                    s16x8 v[32 / RPP];
+#pragma unroll
+                    for (int i = 0; i < 32 / RPP; ++i)
+                        v[i] = *(const s16x8 *)(stage_o + RPP * i * ROWB + (rd0 ^ (((RPP * i) & 15u) << 4)));
+#pragma unroll
+                    for (int i = 0; i < 32 / RPP; ++i) {
+                        // non-temporal: O is written once and not read again by this kernel (+1.3...2.8 % at
+                        // seq_len <= 1024, where the store-issue-bound epilogue is a visible share).
+                        // asm: scalar row base + 32-bit lane offset (hipcc builds a 64-bit address per lane and store)
+                        if constexpr (RAG) {  // rows beyond the sequence are not stored
+                            if (qb_c * TR::kBr + wave * TR::kRowsPerWave + qt * 32 + RPP * i + rsub >= args.seq_len) continue;
+                        }
+                        asm volatile("global_store_dwordx4 %0, %1, %2 nt" ::"v"(lane_off), "v"(v[i]), "s"(rows0 + (int64_t)(RPP * i) * ss));
+                    }
+                }
+            };
+            // seq_len is a multiple of B_r = 256, so n_kv = seq_len / 64 is a multiple of 4 = ring depth
+            for (;;) {
+                for (int it = 0; it < nkc; it += 4) {
+                    visit(it, Sa, Sb, IntTag<0>{});
+                    visit(it + 1, Sb, Sa, IntTag<1>{});
+                    visit(it + 2, Sa, Sb, IntTag<2>{});
+                    visit(it + 3, Sb, Sa, IntTag<3>{});
+                }
 #ifdef FA_TRACE
-            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(te2)::"memory");
-            if (item == args.trace_block + (int)gridDim.x && lane == 0) {
-                args.trace[wave * 24 + 21] = te0;
-                args.trace[wave * 24 + 22] = te1;
-                args.trace[wave * 24 + 23] = te2;
-            }
+                unsigned long long te0, te1, te2;
+                asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(te0)::"memory");
 #endif
+                store_item();
+#ifdef FA_TRACE
+                asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(te1)::"memory");
+#endif
+                if (!has_next) break;
+                // ---- seam: the last visit left the next item's S(0) in Sa and its row max in mraw; its
+                // first tiles are landed or in flight, its first operands sit in the ring
+                const int qb_st = qb_c;  // the item just stored
+                (void)qb_st;
+                ord = ord_n;
+                item = (int)blockIdx.x + ord * (int)gridDim.x;
+                Kc = Kn; Vc = Vn; Oc = On; qb_c = qb_n;
+                nkc = nkn;
+                set_next();
+                kq = tile_g(Kc, Kn, 4);  // visit 0 requests K(4), V(3) (for n_kv == 4 that is already the item after)
+                vq = tile_g(Vc, Vn, 3);
+                if (has_next) request_next_q(0);  // (the staging area is free again: store_item's reads have retired)
+                seam_st = 16;
+                if constexpr (RAG) {  // stores the epilogue above issued: one per four rows inside the sequence (16 per 64 rows)
+                    const int rows_in = args.seq_len - (qb_st * TR::kBr + wave * TR::kRowsPerWave);
+                    seam_st = rows_in >= 64 ? 16 : (rows_in >= 32 ? 8 : 0);
+                }
+                resc_any = 0;
+                if constexpr (FAST) {
+                    // the row max of the S tile the last visit formed (the next item's S(0)): the speculative
+                    // schedule has no row-max units, this is the only one an item needs (behind store_item's pads)
+#pragma unroll
+                    for (int qt = 0; qt < 2; ++qt) {
+                        float v0 = vmax2(Sa[qt][0][0], Sa[qt][0][1]), v1 = vmax2(Sa[qt][1][0], Sa[qt][1][1]);
+#pragma unroll
+                        for (int r = 2; r < 16; r += 2) {
+                            v0 = vmax3(v0, Sa[qt][0][r], Sa[qt][0][r + 1]);
+                            v1 = vmax3(v1, Sa[qt][1][r], Sa[qt][1][r + 1]);
+                        }
+                        mraw[qt] = pair_max(vmax2(v0, v1));
+                    }
+                }
+#pragma unroll
+                for (int qt = 0; qt < 2; ++qt) {
+                    m[qt] = mraw[qt];
+                    neg_msc[qt] = -(finite_or_zero(m[qt]) * c);
+                    thr[qt] = m[qt] + TAU / c;
+                    m_pend[qt] = m[qt];
+                    rs[qt][0] = rs[qt][1] = 0.0f;
+                }
+                zero_o();
+#ifdef FA_TRACE
+                asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(te2)::"memory");
+                if (item == args.trace_block + (int)gridDim.x && lane == 0) {
+                    args.trace[wave * 24 + 21] = te0;
+                    args.trace[wave * 24 + 22] = te1;
+                    args.trace[wave * 24 + 23] = te2;
+                }
+#endif
+            }
+            dma_wait();  // nothing may still be landing in the LDS when the workgroup retires (or the next pass starts)
+            FA_TL();
+            return failed;
         }
-        dma_wait();  // nothing may still be landing in the LDS when the workgroup retires (or the next pass starts)
-        FA_TL();
-        return failed;
-    }
     };  // walk
 
     if constexpr (SPEC) {
