@@ -142,6 +142,27 @@ def test_output_buffer_ownership_and_determinism():
     assert torch.equal(out2, first) and ms > 0
 
 
+@pytest.mark.parametrize("S", [64, 128, 192, 256, 512])
+def test_shortest_sequences_every_variant(S):
+    """One to eight K/V tiles per item: prologue-only and single-visit loops, the key-split merge with one
+    tile per key group, the speculative check right behind the first tile, the persistent walk with four
+    tiles per item -- every device variant whose tiles divide S, against fp32 eager."""
+    n = 0
+    for cfg in VARIANTS:
+        if S % cfg.B_r or S % cfg.B_c:
+            continue
+        n += 1
+        dtype = cfg.dtype.to_torch_dtype()
+        gen = torch.Generator(device=DEV).manual_seed(S)
+        q, k, v = (torch.randn((3, S, 5, 128), dtype=dtype, device=DEV, generator=gen) for _ in range(3))
+        out = flash_attention.forward(cfg, q, k, v)
+        ref = ut.py_flash_attention(q, k, v, upcast=True).float()
+        assert torch.isfinite(out.float()).all(), str(cfg)
+        assert ((out.float() - ref).abs() <= TOL[dtype] * (1 + ref.abs())).all(), str(cfg)
+        assert torch.equal(flash_attention.forward(cfg, q, k, v), out), str(cfg)
+    assert n >= (10 if S < 256 else 40)
+
+
 def test_launch_is_capturable_into_a_hip_graph():
     """fa_fwd_launch is one plain asynchronous kernel launch on the caller's stream (persistent variants
     included: no cooperative launch, no host round trip), so a forward can be captured into a hipGraph and
