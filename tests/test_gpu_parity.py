@@ -416,6 +416,37 @@ def test_speculative_softmax_on_the_32_row_kernels_starts_over():
             assert torch.equal(flash_attention.forward(spec, q, k, v), out)
 
 
+def test_speculative_softmax_fuzz():
+    """Seeded fuzz over shapes, spike positions and magnitudes: logits that rise by 0 ... thousands of
+    binades anywhere along the visit order, in any number of rows and heads, on the persistent kernel and
+    on the one-item kernels (speculative builds): always finite, always within tolerance of fp32 eager,
+    always bitwise repeatable."""
+    import random
+    rng = random.Random(2024)
+    shapes = [(128, 64, 4, True), (64, 64, 4, True), (64, 32, 4, False), (256, 64, 4, True), (256, 64, 4, True),
+              (256, 64, 4, True)]
+    for trial in range(36):
+        B_r, B_c, nw, buf = shapes[trial % len(shapes)]
+        dtype, name = ((torch.bfloat16, kc.DType.BF16), (torch.float16, kc.DType.FP16))[trial & 1]
+        cfg = kc.FlashForwardKernelConfig(name, 128, B_r, B_c, nw, True, True, True, 0, 0, 0, buf, True)
+        B, H = rng.choice([1, 2, 5]), rng.choice([1, 3, 8])
+        S = B_r * rng.choice([1, 2, 3, 4, 8] if B_r == 256 else [1, 2, 4, 9, 16])
+        gen = torch.Generator(device=DEV).manual_seed(trial)
+        q, k, v = (torch.randn((B, S, H, 128), dtype=dtype, device=DEV, generator=gen) for _ in range(3))
+        for _ in range(rng.choice([0, 1, 1, 2, 4])):
+            b_, h_ = rng.randrange(B), rng.randrange(H)
+            key, row, n_rows = rng.randrange(S), rng.randrange(S), rng.choice([1, 3, 40])
+            a = rng.choice([0.6, 1.1, 2.0, 6.0, 30.0])       # q.k c = a^2 * 128 c: 6 ... 16 000 binades
+            u = _sign_vector(rng.randrange(1000)).to(dtype)
+            k[b_, key, h_] = a * u
+            q[b_, row:row + n_rows, h_] = a * u
+        out = flash_attention.forward(cfg, q, k, v)
+        ref = ut.py_flash_attention(q, k, v, upcast=True).float()
+        assert torch.isfinite(out.float()).all(), (trial, str(cfg))
+        assert ((out.float() - ref).abs() <= TOL[dtype] * (1 + ref.abs())).all(), (trial, str(cfg), B, H, S)
+        assert torch.equal(flash_attention.forward(cfg, q, k, v), out), (trial, str(cfg))
+
+
 def test_speculative_softmax_second_pass_beyond_ordinal_63():
     """A workgroup records failed items in a 64-bit mask of walk ordinals; ordinals >= 63 share the
     last bit (the second pass then redoes all of them).  130 * 128 items of one Q block each on 256
