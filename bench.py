@@ -17,7 +17,9 @@ One JSON line on rank 0:
              the launch stream around the K timed launches (and after every launch: the
              per-launch distribution); peak = 2500 TFLOP/s (MI355X dense bf16 MFMA,
              /opt/skills/guides/MI355X_MICROARCH.md); traffic = HBM bytes per launch from
-             rocprofv3 PMC passes over this same command (FETCH_SIZE x 2 + WRITE_SIZE)
+             rocprofv3 PMC passes over this same command (FETCH_SIZE x 2 + WRITE_SIZE);
+             pipe_counters = matrix-pipe busy fraction, instructions per MFMA and the
+             GRBM_GUI_ACTIVE-derived effective clock from a third pass
   clocks     shader / memory clock and socket power sampled from the GPU's hwmon files
              during the timed region (SURVEY.md 8d asks for them: the chip clocks to its
              power budget)
@@ -191,12 +193,10 @@ def committed_traffic(kernel_short_form, workload):
     return rec.get("hbm_bytes_per_launch") if rec.get("kernel") == kernel_short_form else None
 
 
-def measure_traffic(argv_tail, timeout_s=150):
-    """Run `bench.py --traffic-child <same workload>` under rocprofv3 twice (FETCH_SIZE and WRITE_SIZE
-    each take more than half of the TCC counter slots: separate passes, counters only with
-    --kernel-trace) and return HBM bytes per launch of the dominant kernel:
-    2 * FETCH_SIZE + WRITE_SIZE, both reported in KiB (MI355X_MICROARCH.md, HBM section: gfx950
-    tallies a 128-B read request as 64 B).  None if rocprofv3 is missing or a pass fails."""
+def rocprof_pass(counters, argv_tail, timeout_s=150):
+    """One `rocprofv3 --kernel-trace --pmc <counters>` pass (counters only: no other trace domain) over
+    `bench.py --traffic-child <same workload>`; -> ({counter: mean over the kernel's dispatches,
+    "duration_ns": mean dispatch duration in that pass}, None) or (None, reason)."""
     import csv
     import shutil
     import tempfile
@@ -204,30 +204,68 @@ def measure_traffic(argv_tail, timeout_s=150):
     prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(prof):
         return None, "rocprofv3 not found"
+    out_dir = tempfile.mkdtemp(prefix="fa_pmc_", dir="/tmp")
+    cmd = [prof, "--kernel-trace", "--pmc"] + list(counters) + ["--output-format", "csv", "-d", out_dir, "-o", "p", "--",
+                                                                sys.executable, os.path.abspath(__file__), "--traffic-child"] + argv_tail
+    try:
+        subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), timeout=timeout_s,
+                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
+    except (subprocess.SubprocessError, OSError) as exc:
+        shutil.rmtree(out_dir, ignore_errors=True)
+        return None, f"rocprofv3 --pmc {' '.join(counters)}: {type(exc).__name__}"
+    vals, durations = {c: [] for c in counters}, {}
+    for path in glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"), recursive=True):
+        with open(path) as f:
+            for row in csv.DictReader(f):
+                if "fa_fwd" in row.get("Kernel_Name", "") and row.get("Counter_Name") in vals:
+                    vals[row["Counter_Name"]].append(float(row["Counter_Value"]))
+                    durations[row["Dispatch_Id"]] = int(row["End_Timestamp"]) - int(row["Start_Timestamp"])
+    shutil.rmtree(out_dir, ignore_errors=True)
+    if any(not v for v in vals.values()):
+        return None, "no rows for the kernel: " + ", ".join(c for c, v in vals.items() if not v)
+    out = {c: statistics.mean(v) for c, v in vals.items()}
+    out["duration_ns"] = statistics.mean(durations.values())
+    return out, None
+
+
+def measure_traffic(argv_tail):
+    """HBM bytes per launch of the dominant kernel, measured: FETCH_SIZE and WRITE_SIZE each take more than
+    half of the TCC counter slots, so two passes; 2 * FETCH_SIZE + WRITE_SIZE, both reported in KiB
+    (MI355X_MICROARCH.md, HBM section: gfx950 tallies a 128-B read request as 64 B).  (None, reason) if
+    rocprofv3 is missing or a pass fails."""
     kib = {}
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-        out_dir = tempfile.mkdtemp(prefix="fa_pmc_", dir="/tmp")
-        cmd = [prof, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out_dir, "-o", "p", "--",
-               sys.executable, os.path.abspath(__file__), "--traffic-child"] + argv_tail
-        env = dict(os.environ, TMPDIR="/tmp")
-        try:
-            subprocess.run(cmd, cwd="/tmp", env=env, timeout=timeout_s, stdout=subprocess.DEVNULL,
-                           stderr=subprocess.DEVNULL, check=True)
-        except (subprocess.SubprocessError, OSError) as exc:
-            shutil.rmtree(out_dir, ignore_errors=True)
-            return None, f"rocprofv3 --pmc {counter}: {type(exc).__name__}"
-        vals = []
-        for path in glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"), recursive=True):
-            with open(path) as f:
-                for row in csv.DictReader(f):
-                    if "fa_fwd" in row.get("Kernel_Name", "") and row.get("Counter_Name") == counter:
-                        vals.append(float(row["Counter_Value"]))
-        shutil.rmtree(out_dir, ignore_errors=True)
-        if not vals:
-            return None, f"no {counter} rows for the kernel"
-        kib[counter] = statistics.mean(vals)
+        got, why = rocprof_pass([counter], argv_tail)
+        if got is None:
+            return None, why
+        kib[counter] = got[counter]
     return (2 * kib["FETCH_SIZE"] + kib["WRITE_SIZE"]) * 1024.0, \
         "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over this workload in this run; 2*FETCH+WRITE KiB"
+
+
+def measure_pipe_counters(argv_tail, n_xcd=8):
+    """A third pass: how busy the matrix pipe was and at which clock, from the SQ / GRBM counters of the
+    same launches (MI355X_MICROARCH.md: SQ_WAVE_CYCLES counts quad-cycles, SQ_VALU_MFMA_BUSY_CYCLES cycles;
+    effective clock = GRBM_GUI_ACTIVE per XCD / kernel time).  None if the pass fails."""
+    counters = ["GRBM_GUI_ACTIVE", "SQ_WAVE_CYCLES", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_INSTS_VALU", "SQ_INSTS_MFMA",
+                "SQ_INSTS_LDS", "SQ_INSTS_SALU", "SQ_WAVES"]
+    got, why = rocprof_pass(counters, argv_tail)
+    if got is None:
+        return {"error": why}
+    mfma = got["SQ_INSTS_MFMA"]
+    return {
+        "source": "rocprofv3 --kernel-trace --pmc " + " ".join(counters) + " over this workload in this run (profiled "
+                  "launches clock a few % lower than the timed ones)",
+        "kernel_us_profiled": got["duration_ns"] * 1e-3,
+        "effective_clock_mhz": got["GRBM_GUI_ACTIVE"] / n_xcd / got["duration_ns"] * 1e3,
+        "mfma_busy_frac_of_wave_time": got["SQ_VALU_MFMA_BUSY_CYCLES"] / (4.0 * got["SQ_WAVE_CYCLES"]),
+        "wave_cycles_per_mfma": 4.0 * got["SQ_WAVE_CYCLES"] / mfma,
+        "valu_insts_per_mfma": (got["SQ_INSTS_VALU"] - mfma) / mfma,   # SQ_INSTS_VALU counts the MFMAs too
+        "lds_insts_per_mfma": got["SQ_INSTS_LDS"] / mfma,
+        "salu_insts_per_mfma": got["SQ_INSTS_SALU"] / mfma,
+        "mfma_insts": mfma,
+        "waves": got["SQ_WAVES"],
+    }
 
 
 # ---- CPU baseline -----------------------------------------------------------------------------
@@ -381,7 +419,8 @@ def main():
     ap.add_argument("--kernel", default="", help="short-form config; default = best_config(dtype)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-traffic", action="store_true",
-                    help="skip the two rocprofv3 PMC passes that measure HBM bytes per launch (~1 min)")
+                    help="skip the three rocprofv3 PMC passes (HBM bytes per launch; matrix-pipe occupancy, "
+                         "instruction mix and effective clock) (~1 min)")
     ap.add_argument("--precondition-ms", type=float, default=400.0,
                     help="untimed launches of the same step for this long BEFORE the W warm-up steps: the chip's "
                          "clock governor needs a few hundred ms of load to leave its idle state (a cold 20-step "
@@ -597,6 +636,7 @@ def main():
             else:
                 line["roofline"]["traffic"] = traffic
                 line["roofline"]["traffic_source"] = how
+                line["roofline"]["pipe_counters"] = measure_pipe_counters(tail)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(dtype, batch, heads, seq, d)
         print(json.dumps(line), flush=True)
