@@ -45,10 +45,13 @@ int main(int argc, char **argv) {
     a.batch_stride = (int64_t)S * H * D; a.seq_stride = H * D; a.head_stride = D;
     a.seq_len = S; a.n_heads = H; a.n_bh = B * H; a.n_q_blocks = S / 256; a.n_kv_blocks = S / 64; a.causal = 0;
     a.trace = tr; a.trace_block = -1; a.trace_visit = -1;
+#ifndef TRACE_ABL
+#define TRACE_ABL 0
+#endif
 #ifndef TRACE_SPEC
 #define TRACE_SPEC 1  // 1: the speculative-softmax build (the default kernel), 0: the lazy-rescale build
 #endif
-    auto kern = fa::fa_fwd_kernel64<15, false, 0, false, TRACE_SPEC != 0>;
+    auto kern = fa::fa_fwd_kernel64<15, false, TRACE_ABL, false, TRACE_SPEC != 0>;
     CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
     hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
     for (int mode = 0; mode < 2; ++mode) {  // 0: warm caches, back to back; 1: cache flushed before the launch
@@ -104,7 +107,13 @@ int main(int argc, char **argv) {
     a.batch_stride = (int64_t)S * H * D; a.seq_stride = H * D; a.head_stride = D;
     a.seq_len = S; a.n_heads = H; a.n_bh = B * H; a.n_q_blocks = S / 256; a.n_kv_blocks = S / 64; a.causal = 0;
     a.trace = tr;
-    auto kern = fa::fa_fwd_kernel64<15, false, 0>;
+#ifndef TRACE_ABL
+#define TRACE_ABL 0
+#endif
+#ifndef TRACE_SPEC
+#define TRACE_SPEC 1
+#endif
+    auto kern = fa::fa_fwd_kernel64<15, false, TRACE_ABL, false, TRACE_SPEC != 0>;
     CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
     // persistent kernel: workgroup w serves items w, w + 256, ...; trace the second item of two workgroups
     const int items[2] = {256 + 100, 256 + 203};

@@ -1,0 +1,76 @@
+// valu_cost.hip -- issue cost (cycles per wave-instruction, one wave per SIMD, 64 independent instructions
+// between two s_memtime stamps) of the vector instructions the softmax stream is made of, alone and beside
+// MFMAs.  Build: hipcc --offload-arch=gfx950 -O3 valu_cost.hip -o valu_cost
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s line %d\n", hipGetErrorString(e_), __LINE__); exit(2); } } while (0)
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+#define REP8(x) x x x x x x x x
+#define REP64(x) REP8(REP8(x))
+// 64 independent instructions: 8 destination registers round robin, sources never written in the block
+#define BLOCK(name, ins)                                                                                         \
+    __global__ void __launch_bounds__(256, 1) k_##name(unsigned long long *out, float seed) {                    \
+        float a0 = seed, a1 = seed + 1, a2 = seed + 2, a3 = seed + 3, d0, d1, d2, d3, d4, d5, d6, d7;               \
+        d0 = d1 = d2 = d3 = d4 = d5 = d6 = d7 = seed;                                                              \
+        unsigned long long t0, t1;                                                                                \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0));        \
+        asm volatile(REP8(ins) : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(d4), "+v"(d5), "+v"(d6), "+v"(d7)   \
+                     : "v"(a0), "v"(a1), "v"(a2), "v"(a3));                                                        \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1));                                          \
+        if (threadIdx.x == 0 && blockIdx.x == 0) out[0] = t1 - t0;                                                 \
+        if (d0 + d1 + d2 + d3 + d4 + d5 + d6 + d7 == 12345.0f) out[1] = 1;                                         \
+    }
+#define I8(op, tail) op " %0, " tail "\n\t" op " %1, " tail "\n\t" op " %2, " tail "\n\t" op " %3, " tail "\n\t" op " %4, " tail "\n\t" op " %5, " tail "\n\t" op " %6, " tail "\n\t" op " %7, " tail "\n\t"
+BLOCK(fma, I8("v_fma_f32", "%8, %9, %10"))
+BLOCK(add, I8("v_add_f32", "%8, %9"))
+BLOCK(exp, I8("v_exp_f32", "%8"))
+BLOCK(exp_legacy, I8("v_exp_legacy_f32", "%8"))
+BLOCK(exp_f16, I8("v_exp_f16", "%8"))
+BLOCK(log, I8("v_log_f32", "%8"))
+BLOCK(rcp, I8("v_rcp_f32", "%8"))
+BLOCK(cvt_pk, I8("v_cvt_pk_bf16_f32", "%8, %9"))
+BLOCK(max3, I8("v_max3_f32", "%8, %9, %10"))
+BLOCK(ldexp, I8("v_ldexp_f32", "%8, %9"))
+BLOCK(exp_then_fma, "v_exp_f32 %0, %8\n\tv_fma_f32 %1, %8, %9, %10\n\tv_exp_f32 %2, %9\n\tv_fma_f32 %3, %8, %9, %10\n\tv_exp_f32 %4, %10\n\tv_fma_f32 %5, %8, %9, %10\n\tv_exp_f32 %6, %11\n\tv_fma_f32 %7, %8, %9, %10\n\t")
+
+// beside MFMAs: 8 x { v_mfma ; N fillers } -- cycles per MFMA gap
+#define MBLOCK(name, fill)                                                                                       \
+    __global__ void __launch_bounds__(256, 1) m_##name(unsigned long long *out, float seed, const bf16x8 *ab) {   \
+        float a0 = seed, a1 = seed + 1, a2 = seed + 2, d0, d1, d2, d3, d4, d5, d6, d7;                              \
+        d0 = d1 = d2 = d3 = d4 = d5 = d6 = d7 = seed;                                                              \
+        bf16x8 a = ab[threadIdx.x & 63], b = ab[64 + (threadIdx.x & 63)];                                          \
+        f32x16 c0 = {}, c1 = {};                                                                                  \
+        unsigned long long t0, t1;                                                                                \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0));        \
+        asm volatile(REP8("v_mfma_f32_32x32x16_bf16 %8, %10, %11, %8\n\t" fill "v_mfma_f32_32x32x16_bf16 %9, %10, %11, %9\n\t" fill) \
+                     : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(d4), "+v"(d5), "+v"(d6), "+v"(d7), "+v"(c0), "+v"(c1) \
+                     : "v"(a), "v"(b), "v"(a0), "v"(a1), "v"(a2));                                                 \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1));                                          \
+        if (threadIdx.x == 0 && blockIdx.x == 0) out[0] = t1 - t0;                                                 \
+        if (d0 + d1 + d2 + d3 + d4 + d5 + d6 + d7 + c0[0] + c1[1] == 12345.0f) out[1] = 1;                         \
+    }
+MBLOCK(bare, "")
+MBLOCK(fma4, "v_fma_f32 %0, %12, %13, %14\n\tv_fma_f32 %1, %12, %13, %14\n\tv_fma_f32 %2, %12, %13, %14\n\tv_fma_f32 %3, %12, %13, %14\n\t")
+MBLOCK(fma6, "v_fma_f32 %0, %12, %13, %14\n\tv_fma_f32 %1, %12, %13, %14\n\tv_fma_f32 %2, %12, %13, %14\n\tv_fma_f32 %3, %12, %13, %14\n\tv_fma_f32 %4, %12, %13, %14\n\tv_fma_f32 %5, %12, %13, %14\n\t")
+MBLOCK(exp1, "v_exp_f32 %0, %12\n\t")
+MBLOCK(exp2, "v_exp_f32 %0, %12\n\tv_exp_f32 %1, %13\n\t")
+MBLOCK(exp1_fma3, "v_exp_f32 %0, %12\n\tv_fma_f32 %1, %12, %13, %14\n\tv_fma_f32 %2, %12, %13, %14\n\tv_fma_f32 %3, %12, %13, %14\n\t")
+MBLOCK(exp2_fma5, "v_exp_f32 %0, %12\n\tv_exp_f32 %1, %13\n\tv_fma_f32 %2, %12, %13, %14\n\tv_fma_f32 %3, %12, %13, %14\n\tv_fma_f32 %4, %12, %13, %14\n\tv_fma_f32 %5, %12, %13, %14\n\tv_fma_f32 %6, %12, %13, %14\n\t")
+MBLOCK(expf16_2_fma5, "v_exp_f16 %0, %12\n\tv_exp_f16 %1, %13\n\tv_fma_f32 %2, %12, %13, %14\n\tv_fma_f32 %3, %12, %13, %14\n\tv_fma_f32 %4, %12, %13, %14\n\tv_fma_f32 %5, %12, %13, %14\n\tv_fma_f32 %6, %12, %13, %14\n\t")
+
+int main() {
+    unsigned long long *out; CHECK(hipMalloc(&out, 64));
+    bf16x8 *ab; CHECK(hipMalloc(&ab, 128 * 16)); CHECK(hipMemset(ab, 0x3c, 128 * 16));
+    unsigned long long h[2];
+#define RUN(name, n) do { for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(k_##name, dim3(256), dim3(256), 0, 0, out, 1.5f); CHECK(hipDeviceSynchronize()); \
+        CHECK(hipMemcpy(h, out, 16, hipMemcpyDeviceToHost)); printf("%-28s %6.2f cycles per instruction (%llu / %d)\n", #name, (double)h[0] / (n), h[0], n); } while (0)
+    RUN(fma, 64); RUN(add, 64); RUN(exp, 64); RUN(exp_legacy, 64); RUN(exp_f16, 64); RUN(log, 64); RUN(rcp, 64); RUN(cvt_pk, 64); RUN(max3, 64); RUN(ldexp, 64);
+    RUN(exp_then_fma, 64);
+#define MRUN(name) do { for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(m_##name, dim3(256), dim3(256), 0, 0, out, 1.5f, ab); CHECK(hipDeviceSynchronize()); \
+        CHECK(hipMemcpy(h, out, 16, hipMemcpyDeviceToHost)); printf("MFMA + %-21s %6.2f cycles per MFMA gap (%llu / 16)\n", #name, (double)h[0] / 16, h[0]); } while (0)
+    MRUN(bare); MRUN(fma4); MRUN(fma6); MRUN(exp1); MRUN(exp2); MRUN(exp1_fma3); MRUN(exp2_fma5); MRUN(expf16_2_fma5);
+    return 0;
+}
