@@ -61,6 +61,34 @@ MBLOCK(exp1_fma3, "v_exp_f32 %0, %12\n\tv_fma_f32 %1, %12, %13, %14\n\tv_fma_f32
 MBLOCK(exp2_fma5, "v_exp_f32 %0, %12\n\tv_exp_f32 %1, %13\n\tv_fma_f32 %2, %12, %13, %14\n\tv_fma_f32 %3, %12, %13, %14\n\tv_fma_f32 %4, %12, %13, %14\n\tv_fma_f32 %5, %12, %13, %14\n\tv_fma_f32 %6, %12, %13, %14\n\t")
 MBLOCK(expf16_2_fma5, "v_exp_f16 %0, %12\n\tv_exp_f16 %1, %13\n\tv_fma_f32 %2, %12, %13, %14\n\tv_fma_f32 %3, %12, %13, %14\n\tv_fma_f32 %4, %12, %13, %14\n\tv_fma_f32 %5, %12, %13, %14\n\tv_fma_f32 %6, %12, %13, %14\n\t")
 
+// row sums on the matrix pipe: v_mfma_f32_4x4x4_16b_bf16 with A = ones adds a lane's four packed values into its accumulator
+#define M4BLOCK(name, fill)                                                                                      \
+    __global__ void __launch_bounds__(256, 1) m_##name(unsigned long long *out, float seed, const bf16x8 *ab) {   \
+        typedef float f32x4_ __attribute__((ext_vector_type(4)));                                                  \
+        typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));                                               \
+        float a0 = seed, a1 = seed + 1, a2 = seed + 2, d0, d1, d2, d3, d4, d5, d6, d7;                              \
+        d0 = d1 = d2 = d3 = d4 = d5 = d6 = d7 = seed;                                                              \
+        bf16x8 a = ab[threadIdx.x & 63], b = ab[64 + (threadIdx.x & 63)];                                          \
+        f32x16 c0 = {}, c1 = {};                                                                                  \
+        f32x4_ s0 = {}, s1 = {};                                                                                  \
+        u32x2_ ones = {0x3f803f80u, 0x3f803f80u}, pk = {0x3e003e00u, 0x3d003d00u};                                 \
+        unsigned long long t0, t1;                                                                                \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0));        \
+        asm volatile(REP8("v_mfma_f32_32x32x16_bf16 %8, %12, %13, %8\n\t" fill "v_mfma_f32_32x32x16_bf16 %9, %12, %13, %9\n\t" fill) \
+                     : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(d4), "+v"(d5), "+v"(d6), "+v"(d7), "+v"(c0), "+v"(c1), "+v"(s0), "+v"(s1) \
+                     : "v"(a), "v"(b), "v"(a0), "v"(a1), "v"(a2), "v"(ones), "v"(pk));                             \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1));                                          \
+        if (threadIdx.x == 0 && blockIdx.x == 0) out[0] = t1 - t0;                                                 \
+        if (d0 + d1 + d2 + d3 + d4 + d5 + d6 + d7 + c0[0] + c1[1] + s0[0] + s1[1] == 12345.0f) out[1] = 1;        \
+    }
+// operands: %8 %9 big accumulators, %10 %11 = s0 s1, %12 %13 = a b, %14 %15 %16 = a0 a1 a2, %17 ones, %18 pk
+#undef MFMA_BIG
+M4BLOCK(sum4_only, "v_mfma_f32_4x4x4_16b_bf16 %10, %17, %18, %10\n\t")
+M4BLOCK(sum4_x2, "v_mfma_f32_4x4x4_16b_bf16 %10, %17, %18, %10\n\tv_mfma_f32_4x4x4_16b_bf16 %11, %17, %18, %11\n\t")
+M4BLOCK(unit_adds, "v_exp_f32 %0, %14\n\tv_exp_f32 %1, %15\n\tv_fma_f32 %2, %14, %15, %16\n\tv_fma_f32 %3, %14, %15, %16\n\tv_add_f32 %4, %14, %15\n\tv_add_f32 %5, %14, %16\n\tv_cvt_pk_bf16_f32 %6, %14, %15\n\t")
+M4BLOCK(unit_noadds, "v_exp_f32 %0, %14\n\tv_exp_f32 %1, %15\n\tv_fma_f32 %2, %14, %15, %16\n\tv_fma_f32 %3, %14, %15, %16\n\tv_cvt_pk_bf16_f32 %6, %14, %15\n\t")
+M4BLOCK(unit_sum4, "v_exp_f32 %0, %14\n\tv_exp_f32 %1, %15\n\tv_fma_f32 %2, %14, %15, %16\n\tv_fma_f32 %3, %14, %15, %16\n\tv_cvt_pk_bf16_f32 %6, %14, %15\n\tv_mfma_f32_4x4x4_16b_bf16 %10, %17, %18, %10\n\t")
+
 int main() {
     unsigned long long *out; CHECK(hipMalloc(&out, 64));
     bf16x8 *ab; CHECK(hipMalloc(&ab, 128 * 16)); CHECK(hipMemset(ab, 0x3c, 128 * 16));
@@ -71,6 +99,7 @@ int main() {
     RUN(exp_then_fma, 64);
 #define MRUN(name) do { for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(m_##name, dim3(256), dim3(256), 0, 0, out, 1.5f, ab); CHECK(hipDeviceSynchronize()); \
         CHECK(hipMemcpy(h, out, 16, hipMemcpyDeviceToHost)); printf("MFMA + %-21s %6.2f cycles per MFMA gap (%llu / 16)\n", #name, (double)h[0] / 16, h[0]); } while (0)
+    MRUN(sum4_only); MRUN(sum4_x2); MRUN(unit_adds); MRUN(unit_noadds); MRUN(unit_sum4);
     MRUN(bare); MRUN(fma4); MRUN(fma6); MRUN(exp1); MRUN(exp2); MRUN(exp1_fma3); MRUN(exp2_fma5); MRUN(expf16_2_fma5);
     return 0;
 }
