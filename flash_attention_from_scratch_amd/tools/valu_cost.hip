@@ -89,6 +89,22 @@ M4BLOCK(unit_adds, "v_exp_f32 %0, %14\n\tv_exp_f32 %1, %15\n\tv_fma_f32 %2, %14,
 M4BLOCK(unit_noadds, "v_exp_f32 %0, %14\n\tv_exp_f32 %1, %15\n\tv_fma_f32 %2, %14, %15, %16\n\tv_fma_f32 %3, %14, %15, %16\n\tv_cvt_pk_bf16_f32 %6, %14, %15\n\t")
 M4BLOCK(unit_sum4, "v_exp_f32 %0, %14\n\tv_exp_f32 %1, %15\n\tv_fma_f32 %2, %14, %15, %16\n\tv_fma_f32 %3, %14, %15, %16\n\tv_cvt_pk_bf16_f32 %6, %14, %15\n\tv_mfma_f32_4x4x4_16b_bf16 %10, %17, %18, %10\n\t")
 
+// the unit with its two row-sum adds as ONE v_pk_add_f32 on register pairs (physical registers named in the asm)
+__global__ void __launch_bounds__(256, 1) m_unit_pkadd(unsigned long long *out, float seed, const bf16x8 *ab) {
+    float a0 = seed, a1 = seed + 1, a2 = seed + 2;
+    bf16x8 a = ab[threadIdx.x & 63], b = ab[64 + (threadIdx.x & 63)];
+    f32x16 c0 = {}, c1 = {};
+    unsigned long long t0, t1;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0));
+#define UNIT_PK "v_exp_f32 v200, %4\n\tv_exp_f32 v201, %5\n\tv_fma_f32 v204, %4, %5, %6\n\tv_fma_f32 v205, %4, %5, %6\n\tv_pk_add_f32 v[202:203], v[202:203], v[200:201]\n\tv_cvt_pk_bf16_f32 v206, v200, v201\n\t"
+    asm volatile(REP8("v_mfma_f32_32x32x16_bf16 %0, %2, %3, %0\n\t" UNIT_PK "v_mfma_f32_32x32x16_bf16 %1, %2, %3, %1\n\t" UNIT_PK)
+                 : "+v"(c0), "+v"(c1) : "v"(a), "v"(b), "v"(a0), "v"(a1), "v"(a2)
+                 : "v200", "v201", "v202", "v203", "v204", "v205", "v206");
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1));
+    if (threadIdx.x == 0 && blockIdx.x == 0) out[0] = t1 - t0;
+    if (c0[0] + c1[1] == 12345.0f) out[1] = 1;
+}
+
 int main() {
     unsigned long long *out; CHECK(hipMalloc(&out, 64));
     bf16x8 *ab; CHECK(hipMalloc(&ab, 128 * 16)); CHECK(hipMemset(ab, 0x3c, 128 * 16));
@@ -99,7 +115,7 @@ int main() {
     RUN(exp_then_fma, 64);
 #define MRUN(name) do { for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(m_##name, dim3(256), dim3(256), 0, 0, out, 1.5f, ab); CHECK(hipDeviceSynchronize()); \
         CHECK(hipMemcpy(h, out, 16, hipMemcpyDeviceToHost)); printf("MFMA + %-21s %6.2f cycles per MFMA gap (%llu / 16)\n", #name, (double)h[0] / 16, h[0]); } while (0)
-    MRUN(sum4_only); MRUN(sum4_x2); MRUN(unit_adds); MRUN(unit_noadds); MRUN(unit_sum4);
+    MRUN(sum4_only); MRUN(sum4_x2); MRUN(unit_adds); MRUN(unit_noadds); MRUN(unit_sum4); MRUN(unit_pkadd);
     MRUN(bare); MRUN(fma4); MRUN(fma6); MRUN(exp1); MRUN(exp2); MRUN(exp1_fma3); MRUN(exp2_fma5); MRUN(expf16_2_fma5);
     return 0;
 }
