@@ -836,29 +836,31 @@ fa_fwd_kernel64(const KernelArgs args) {
             dma_k(tile_g(Kc, Kn, 1), 1);
             dma_v(tile_g(Vc, Vn, 0), 0);
             FA_TLP(1);  // Q, K(1), V(0) requested
-            if (!(ABL & 8)) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // K(0), Q landed: K(1), V(0) fly on
-            FA_TLP(2);  // K(0), Q landed
+            // S(0) of the wave's first 32 rows needs only K(0) and Q tile 0, which land ~1.5 k cycles before Q tile 1
+            // (the requests return in issue order at the CU's start-up rate): start on them, take tile 1 when it is in
+            if (!(ABL & 8)) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");  // K(0), Q tile 0 landed: Q tile 1, K(1), V(0) fly on
+            FA_TLP(2);  // K(0), Q tile 0 landed
             read_q(Qr[0], q_stage);
-            read_q(Qr[1], smem_base + (wave < 2 ? 3 * TILE : V_BASE + 3 * TILE) + (wave & 1) * 8192);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            barrier();  // K(0) is visible, and every wave has read its Q tile out of stages 3
-            FA_TLP(3);  // Q read, barrier passed
+            barrier();  // K(0) is visible
+            FA_TLP(3);  // Q tile 0 read, barrier passed
             {
                 // S(0) and its row max, which becomes the first reference max (O = l = 0)
                 const char *kt = smem;
                 vec8 a_all[16];  // every operand stays allocated until the last MFMA has issued (see visit())
 #pragma unroll
                 for (int step = 0; step < 16; ++step) a_all[step] = k_frag(kt, step);
-                static_for<0, 16>([&](auto step_tag) {
-                    constexpr int step = decltype(step_tag)::value;
-                    qk_mfma(Sa, step, 0, a_all[step]);
-                    qk_mfma(Sa, step, 1, a_all[step]);
-                });
+                static_for<0, 16>([&](auto step_tag) { qk_mfma(Sa, decltype(step_tag)::value, 0, a_all[decltype(step_tag)::value]); });
+                if (!(ABL & 8)) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // Q tile 1 landed: K(1), V(0) fly on
+                read_q(Qr[1], smem_base + (wave < 2 ? 3 * TILE : V_BASE + 3 * TILE) + (wave & 1) * 8192);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                static_for<0, 16>([&](auto step_tag) { qk_mfma(Sa, decltype(step_tag)::value, 1, a_all[decltype(step_tag)::value]); });
                 // the rest of the first requests, issued while the matrix pipe works through S(0): a CU keeps
                 // only ~32 KB of requests in flight, so asking for all 176 KB up front held the waves at the
                 // issue of the last pieces (~11 k cycles) long after K(0) and Q had landed
                 dma_k(tile_g(Kc, Kn, 2), 2);
                 dma_v(tile_g(Vc, Vn, 1), 1);
+                barrier();  // every wave has read its Q tile 1 out of stages 3, which K(3) now overwrites
                 dma_k(tile_g(Kc, Kn, 3), 3);
                 dma_v(tile_g(Vc, Vn, 2), 2);
                 kq = tile_g(Kc, Kn, 4);
