@@ -331,12 +331,18 @@ def run_c2_sweep(args, device):
 
     per_s = {}
     hw = hwmon_dir(device.index or 0)
-    for seq, batch in C2_SWEEP:
+    sweep = [(s_, b_) for s_, b_ in C2_SWEEP if not args.c2_shape or s_ == args.c2_shape]
+    for seq, batch in sweep:
         cfg = kc.parse_kernel_name_into_config(args.kernel) if args.kernel else kc.best_config(kc.DType.BF16, seq)
         gen = torch.Generator(device=device).manual_seed(seq)
         q, k, v = (torch.randn((batch, seq, 16, 128), dtype=torch.bfloat16, device=device, generator=gen)
                    for _ in range(3))
         o = torch.empty_like(q)
+        if args.traffic_child:  # under rocprofv3: a few launches of this one shape, nothing else
+            for _ in range(3):
+                flash_attention.forward(cfg, q, k, v, o)
+            torch.cuda.synchronize(device)
+            return
         t_pre = time.perf_counter()  # wake the clocks (see --precondition-ms), per shape: allocation and randn idle the chip
         while (time.perf_counter() - t_pre) * 1e3 < args.precondition_ms:
             for _ in range(8):
@@ -356,7 +362,12 @@ def run_c2_sweep(args, device):
         clk = sampler.summary()
         per_s[seq] = {"tflops": mfma_flop(batch, 16, seq, 128) / sec / 1e12, "ms": sec * 1e3,
                       "batch": batch, "kernel": cfg.short_form(),
-                      "sclk_mhz": clk.get("sclk_mhz", {}).get("mean"), "power_w": clk.get("power_w", {}).get("mean")}
+                      "sclk_mhz": clk.get("sclk_mhz", {}).get("mean"), "power_w": clk.get("power_w", {}).get("mean"),
+                      "algorithmic_bytes": 4 * batch * seq * 16 * 128 * 2}
+        if not args.no_traffic:  # HBM bytes per launch of this shape, measured (two rocprofv3 PMC passes)
+            traffic, _how = measure_traffic(["--workload", "c2", "--c2-shape", str(seq)]
+                                            + (["--kernel", args.kernel] if args.kernel else []))
+            per_s[seq]["traffic"] = traffic
     value = statistics.harmonic_mean([r["tflops"] for r in per_s.values()])
     print(json.dumps({
         "metric": "bf16 TFLOPs, harmonic mean over seq_len {512..16384}, d_head=128", "value": value,
@@ -367,7 +378,12 @@ def run_c2_sweep(args, device):
                                "batch {16,16,16,16,8,4}, a step = one pass over all six shapes"},
         "per_seq_len": per_s,
         "roofline": {"bound": "mfma", "achieved": value, "peak": PEAK_TFLOPS["bf16"], "unit": "TFLOP/s",
-                     "frac": value / PEAK_TFLOPS["bf16"], "traffic": None},
+                     "frac": value / PEAK_TFLOPS["bf16"],
+                     "traffic": (sum(r["traffic"] for r in per_s.values())
+                                 if all(r.get("traffic") for r in per_s.values()) else None),
+                     "algorithmic_bytes": sum(r["algorithmic_bytes"] for r in per_s.values()),
+                     "traffic_source": "sum over the six shapes of 2*FETCH_SIZE + WRITE_SIZE per launch, rocprofv3 PMC passes "
+                                       "in this run (per shape under per_seq_len)"},
     }), flush=True)
 
 
@@ -428,6 +444,7 @@ def main():
     ap.add_argument("--hermetic", action="store_true",
                     help="every timed launch on its own behind a cache flush + idle spin (pt_bench protocol)")
     ap.add_argument("--traffic-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--c2-shape", type=int, default=0, help=argparse.SUPPRESS)  # traffic child of the c2 sweep: one seq_len
     ap.add_argument("--cpu-dry-run", action="store_true",
                     help="no GPU, no kernel: a step is a 2 ms sleep.  Exercises the launcher, the shard arithmetic, "
                          "the barrier-bracketed timing and the rank-0 line on a CPU-only box (tests/); the line says so")
