@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Event-timed kernel comparison -- the MI355X counterpart of the reference's
-tools/benchmark/pt_bench.py (benchmark_kernel :145-174, stats table :224-411).
+tools/benchmark/pt_bench.py (its timing protocol :145-174, its statistics table :224-411).
 
 Protocol kept from the reference: N warm-ups, then per repeat a cache flush (write a
 buffer larger than L2 + Infinity Cache: 512 MiB here vs the reference's 100 MB for
@@ -19,7 +19,6 @@ import csv
 import statistics
 import subprocess
 import sys
-from dataclasses import dataclass
 
 import torch
 
@@ -38,61 +37,62 @@ from flash_helpers.test.utils import (
     reference_forward_kernel_v2_timed,
 )
 
-_flush_buf = None
+class Hermetic:
+    """The between-repeat hygiene of the protocol: evict L2 + Infinity Cache by overwriting a 512-MiB
+    buffer, then let the chip idle for a fixed spin so every repeat starts from the same state."""
+
+    def __init__(self, device="cuda:0", nbytes=512 << 20, spin_cycles=1_000_000):
+        self.scratch = torch.empty(nbytes, dtype=torch.int8, device=device)
+        self.spin_cycles = spin_cycles
+
+    def __call__(self):
+        self.scratch.zero_()
+        torch.cuda._sleep(self.spin_cycles)
 
 
-def flush_cache():
-    global _flush_buf
-    if _flush_buf is None:
-        _flush_buf = torch.empty(512 * 1024 * 1024, dtype=torch.int8, device="cuda:0")
-    _flush_buf.zero_()
+class Timing:
+    """Milliseconds of the repeats of one kernel, and what the table prints about them."""
+
+    def __init__(self, ms):
+        self.ms = sorted(ms)
+
+    mean = property(lambda self: statistics.fmean(self.ms))
+    median = property(lambda self: statistics.median(self.ms))
+    min = property(lambda self: self.ms[0])
+    max = property(lambda self: self.ms[-1])
+    stddev = property(lambda self: statistics.stdev(self.ms) if len(self.ms) > 1 else 0.0)
+
+    def tflops(self, flop):
+        return flop / self.mean * 1e-9  # flop per ms -> TFLOP/s
+
+    def percent_of(self, other):
+        return 100.0 * other.mean / self.mean
 
 
-@dataclass
-class BenchmarkStats:
-    mean: float
-    median: float
-    min: float
-    max: float
-    stddev: float
-    attn_tflops: float
-    mfma_tflops: float
-
-    def relative_performance(self, baseline_mean: float) -> float:
-        return 100 * baseline_mean / self.mean
-
-
-def calculate_benchmark_stats(samples, attn_flops, mfma_flops) -> BenchmarkStats:
-    mean = statistics.mean(samples)
-    return BenchmarkStats(
-        mean=mean,
-        median=statistics.median(samples),
-        min=min(samples),
-        max=max(samples),
-        stddev=statistics.stdev(samples) if len(samples) > 1 else 0.0,
-        attn_tflops=attn_flops / (mean * 1e-3) / 1e12,
-        mfma_tflops=mfma_flops / (mean * 1e-3) / 1e12,
-    )
+_hygiene = None
 
 
 @torch.inference_mode()
-def benchmark_kernel(kernel, n_warmups=10, n_repeats=50, hermetic=True):
-    """-> list of ms. `kernel()` returns (out, ms) (in-extension events) or out."""
-    for _ in range(n_warmups):
+def time_kernel(kernel, warmups, repeats, hermetic=True) -> Timing:
+    """`kernel()` returns (out, ms) -- the extension's own event bracket, preferred -- or just out, in
+    which case a pair of events on the current stream times the call."""
+    global _hygiene
+    if hermetic and _hygiene is None:
+        _hygiene = Hermetic()
+    for _ in range(warmups):
         kernel()
-    runtimes = []
-    for _ in range(n_repeats):
+    ms = []
+    for _ in range(repeats):
         if hermetic:
-            flush_cache()
-            torch.cuda._sleep(1_000_000)
+            _hygiene()
         torch.cuda.synchronize()
-        start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        start.record()
-        out = kernel()
-        end.record()
-        torch.cuda.synchronize()
-        runtimes.append(out[1] if isinstance(out, tuple) else start.elapsed_time(end))
-    return runtimes
+        before, after = (torch.cuda.Event(enable_timing=True) for _ in range(2))
+        before.record()
+        result = kernel()
+        after.record()
+        after.synchronize()
+        ms.append(result[1] if isinstance(result, tuple) else before.elapsed_time(after))
+    return Timing(ms)
 
 
 def main(argv=None):
@@ -130,29 +130,25 @@ def main(argv=None):
             ref_mean = None
             if not args.no_ref:
                 q, k, v, o = data[torch.float16]
-                ref = calculate_benchmark_stats(
-                    benchmark_kernel(lambda: reference_forward_kernel_v2_timed(q, k, v, o),
-                                     args.num_warmups, max(4, args.num_repeats // 4), not args.noncu),
-                    attn_flops, mfma_flops)
+                ref = time_kernel(lambda: reference_forward_kernel_v2_timed(q, k, v, o),
+                                  args.num_warmups, max(4, args.num_repeats // 4), not args.noncu)
                 ref_mean = ref.mean
                 rows.append(("Reference (torch SDPA fp16)", ref))
             for cfg in get_kernel_configs():
                 if cfg.d_head != d_head or seq_len % cfg.B_r or seq_len % cfg.B_c:
                     continue
                 q, k, v, o = data[cfg.dtype.to_torch_dtype()]
-                samples = benchmark_kernel(
-                    lambda: flash_attention.forward_timed(kernel_cfg=cfg, q=q, k=k, v=v, o=o),
-                    args.num_warmups, args.num_repeats, not args.noncu)
-                st = calculate_benchmark_stats(samples, attn_flops, mfma_flops)
+                st = time_kernel(lambda: flash_attention.forward_timed(kernel_cfg=cfg, q=q, k=k, v=v, o=o),
+                                 args.num_warmups, args.num_repeats, not args.noncu)
                 rows.append((cfg.short_form(), st))
-                harmonic.setdefault(cfg.short_form(), []).append(st.mfma_tflops)
+                harmonic.setdefault(cfg.short_form(), []).append(st.tflops(mfma_flops))
             rows[1 if ref_mean else 0:] = sorted(rows[1 if ref_mean else 0:], key=lambda r: r[1].mean)
             for name, st in rows:
-                rel = f"{st.relative_performance(ref_mean):.2f}%" if ref_mean else ""
+                rel = f"{st.percent_of(ref):.2f}%" if ref_mean else ""
                 writer.writerow([name, d_head, seq_len, batch, f"{st.mean:.4f}", f"{st.median:.4f}",
                                  f"{st.min:.4f}", f"{st.max:.4f}", f"{st.stddev:.4f}", rel,
-                                 f"{st.attn_tflops:.2f}", f"{st.mfma_tflops:.2f}",
-                                 f"{100 * st.mfma_tflops / 2500:.1f}"])
+                                 f"{st.tflops(attn_flops):.2f}", f"{st.tflops(mfma_flops):.2f}",
+                                 f"{100 * st.tflops(mfma_flops) / 2500:.1f}"])
             sys.stdout.flush()
     n_seq = len(args.seq_lens.split(",")) * len(args.d_heads.split(","))
     if n_seq > 1:
