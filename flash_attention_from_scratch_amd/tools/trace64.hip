@@ -79,6 +79,17 @@ int main(int argc, char **argv) {
             for (int i = 8; i < cnt; ++i) printf(" %u", r[i] - r[i - 1]);
             printf("\n");
         }
+        {   // spread over the workgroups: how long each one ran, and when it entered / left relative to the first entry
+            unsigned e0 = ~0u; for (int w = 0; w < grid; ++w) e0 = t[w * 96] < e0 ? t[w * 96] : e0;
+            double tmin = 1e18, tmax = 0, emax = 0, xmin = 1e18, xmax = 0;
+            for (int w = 0; w < grid; ++w) {
+                const double tot = (double)(t[w * 96 + cnt - 1] - t[w * 96]), en = (double)(t[w * 96] - e0), ex = (double)(t[w * 96 + cnt - 1] - e0);
+                tmin = tot < tmin ? tot : tmin; tmax = tot > tmax ? tot : tmax; emax = en > emax ? en : emax;
+                xmin = ex < xmin ? ex : xmin; xmax = ex > xmax ? ex : xmax;
+            }
+            printf("spread: workgroup run time min %.0f max %.0f | last entry +%.0f | first exit +%.0f last exit +%.0f (cycles after the first entry)\n",
+                   tmin, tmax, emax, xmin, xmax);
+        }
         printf("mean  : total %7.0f |", [&] { double s_ = 0; for (int w = 0; w < grid; ++w) s_ += (double)(t[w * 96 + cnt - 1] - t[w * 96]); return s_ / grid; }());
         for (int i = 1; i < cnt; ++i) { double sum = 0; for (int w = 0; w < grid; ++w) sum += (double)(t[w * 96 + i] - t[w * 96 + i - 1]); printf(" %.0f", sum / grid); }
         printf("\n");
