@@ -107,7 +107,7 @@ constexpr bool plan64_ok(const Plan64 &p) {
 // per-lane clamp in the request path) and the keys in front of the tile's own first key are masked, which
 // masks a tile that lies beyond the sequence whole; Q rows beyond the sequence are fetched from its last
 // row and not stored.
-// SPEC (cfg.optimized_softmax; plain variant only): speculative softmax.  The per-tile row max exists
+// SPEC (cfg.optimized_softmax; plain variant and the causal form, not RAG): speculative softmax.  The per-tile row max exists
 // only to keep P = 2^((s - m) c) in range -- any reference m gives the same real result -- and its
 // end-of-visit chain (32 v_max3, a lane-pair exchange, two ballots) costs 15-20 % of the kernel
 // (tools/tune64.hip, knob 4096).  So an item is first run with m fixed at the row max of its FIRST tile,
@@ -120,7 +120,7 @@ __global__ void
 __launch_bounds__(256, 1)
 fa_fwd_kernel64(const KernelArgs args) {
     static_assert(!RAG || MASK, "the ragged form is a masked variant");
-    static_assert(!SPEC || !MASK, "the speculative softmax is built for the plain variant");
+    static_assert(!SPEC || !RAG, "the speculative softmax is built for the plain and the causal form");
     constexpr int QT = 2, NWAVES = 4, BC = 64, D = 128;
     constexpr bool SWZ = true, EAGER = true, PIPE = true, DMA = true;
 
@@ -782,6 +782,27 @@ fa_fwd_kernel64(const KernelArgs args) {
                     if constexpr (plan.tail[g] > 0) tail_step(plan.tail[g]);
                     __builtin_amdgcn_sched_barrier(0);
                 });
+                if constexpr (FAST && MASK) {
+                    // causal, speculative: a wave's reference is the row max of ITS diagonal tile -- tile 4 qb + wave,
+                    // the first one it visits that is not masked whole (visit 3 - wave; until then S = -inf gives
+                    // P = 0 against any finite reference, and m = -inf stands for "0").  That tile is the S tile
+                    // this visit formed (masked at gap 34) when it == 2 - wave; for wave 3 it is the item's S(0),
+                    // whose row max the prologue / the seam took.  Once per item and wave, behind the stream.
+                    if (causal && it + 1 < nkc && nkc - 2 - it == 4 * qb_c + wave) {
+                        asm volatile("s_nop 7" ::: "memory");
+#pragma unroll
+                        for (int qt = 0; qt < 2; ++qt) {
+                            float v0 = vmax2(S_nxt[qt][0][0], S_nxt[qt][0][1]), v1 = vmax2(S_nxt[qt][1][0], S_nxt[qt][1][1]);
+#pragma unroll
+                            for (int r = 2; r < 16; r += 2) {
+                                v0 = vmax3(v0, S_nxt[qt][0][r], S_nxt[qt][0][r + 1]);
+                                v1 = vmax3(v1, S_nxt[qt][1][r], S_nxt[qt][1][r + 1]);
+                            }
+                            m[qt] = pair_max(vmax2(v0, v1));
+                            neg_msc[qt] = -(finite_or_zero(m[qt]) * c);
+                        }
+                    }
+                }
 #ifdef FA_TRACE
                 asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts[18])::"memory");
                 if (item == args.trace_block && it == args.trace_visit && lane == 0) {

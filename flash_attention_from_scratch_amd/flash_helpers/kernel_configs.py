@@ -489,10 +489,10 @@ def best_config(dtype=DType.BF16, seq_len=4096, masked=False) -> FlashForwardKer
     profiles/r01/ragged_persistent.txt), otherwise 4 waves x 32 rows."""
     pad = (-seq_len) % 256
     if pad == 0 or (masked and seq_len >= 64 and pad * 8 <= seq_len):
-        # optimized_softmax = the speculative softmax (built for the plain form; the masked forms
-        # serve both flag values with the lazy-rescale schedule)
+        # optimized_softmax = the speculative softmax (plain and causal forms; the ragged form serves both
+        # flag values with the lazy-rescale schedule)
         return FlashForwardKernelConfig(
-            DType(dtype), 128, 256, 64, 4, True, True, True, 0, 0, 0, True, not masked
+            DType(dtype), 128, 256, 64, 4, True, True, True, 0, 0, 0, True, True
         )
     return FlashForwardKernelConfig(
         DType(dtype), 128, 128, 64, 4, True, True, True, 0, 0, 0, True, not masked

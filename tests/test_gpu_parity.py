@@ -416,6 +416,31 @@ def test_speculative_softmax_on_the_32_row_kernels_starts_over():
             assert torch.equal(flash_attention.forward(spec, q, k, v), out)
 
 
+def test_speculative_softmax_causal_second_pass():
+    """The causal form of the persistent kernel under optimized_softmax: a wave's reference is the row max
+    of its diagonal tile.  A key far below the diagonal with a huge logit (visited later) overflows the first
+    pass; the item is redone by the lazy-rescale schedule: bit-identical to the build without the flag for
+    that item, within tolerance of the masked fp32 eager result everywhere."""
+    for dtype, name in ((torch.bfloat16, kc.DType.BF16), (torch.float16, kc.DType.FP16)):
+        spec, safe = _persistent_cfg(name, True), _persistent_cfg(name, False)
+        for a in (30.0, 1.107):
+            gen = torch.Generator(device=DEV).manual_seed(41)
+            q, k, v = (torch.randn((2, 1024, 3, 128), dtype=dtype, device=DEV, generator=gen) for _ in range(3))
+            u = _sign_vector(8).to(dtype)
+            k[1, 10, 1] = a * u                 # key 10: below the diagonal of every later row
+            q[1, 700:708, 1] = a * u            # rows 700..707 (Q block 2, wave 2)
+            out = flash_attention.forward_ex(spec, q, k, v, causal=True)
+            out_safe = flash_attention.forward_ex(safe, q, k, v, causal=True)
+            assert torch.isfinite(out.float()).all()
+            if a > 2 or dtype == torch.float16:
+                assert torch.equal(out[1, 512:768, 1], out_safe[1, 512:768, 1]), (str(dtype), a)
+            for b_, h_ in ((1, 1), (0, 0)):
+                qs, ks, vs = (t[b_:b_ + 1, :, h_:h_ + 1].contiguous() for t in (q, k, v))
+                eager = fo.eager_attention_masked(qs.cpu(), ks.cpu(), vs.cpu(), True)
+                assert _rel_ok(out[b_:b_ + 1, :, h_:h_ + 1].cpu(), eager, dtype), (str(dtype), a, b_, h_)
+            assert torch.equal(flash_attention.forward_ex(spec, q, k, v, causal=True), out)
+
+
 def test_speculative_softmax_fuzz():
     """Seeded fuzz over shapes, spike positions and magnitudes: logits that rise by 0 ... thousands of
     binades anywhere along the visit order, in any number of rows and heads, on the persistent kernel and
@@ -657,6 +682,8 @@ def test_masked_variant_equals_plain_kernel_when_nothing_is_masked():
         gen = torch.Generator(device=DEV).manual_seed(3)
         q, k, v = (torch.randn((2, 1024, 4, 128), dtype=dtype, device=DEV, generator=gen) for _ in range(3))
         plain = replace(cfg, optimized_softmax=False) if kc.uses_speculative_softmax(cfg) else cfg
+        if kc.uses_lazy_rescale(cfg):
+            plain = cfg  # the persistent kernel's causal form is speculative under the flag too: the same arithmetic
         assert torch.equal(flash_attention.forward_ex(cfg, q, k, v), flash_attention.forward(plain, q, k, v)), str(cfg)
         if plain is not cfg:
             assert (flash_attention.forward(cfg, q, k, v).float() - flash_attention.forward(plain, q, k, v).float()).abs().max().item() <= TOL[dtype]
@@ -670,8 +697,9 @@ def test_persistent_walk_causal(shape):
     first tiles are masked whole (m = -inf until their diagonal tile).  Against fp32 eager with the
     mask, the masked 32-rows-per-wave kernel, and itself (bitwise)."""
     B, H, S = shape
-    for dtype, name in ((torch.bfloat16, kc.DType.BF16), (torch.float16, kc.DType.FP16)):
-        cfg = kc.FlashForwardKernelConfig(name, 128, 256, 64, 4, True, True, True, 0, 0, 0, True, False)
+    for dtype, name, opt in ((torch.bfloat16, kc.DType.BF16, False), (torch.float16, kc.DType.FP16, False),
+                             (torch.bfloat16, kc.DType.BF16, True), (torch.float16, kc.DType.FP16, True)):
+        cfg = kc.FlashForwardKernelConfig(name, 128, 256, 64, 4, True, True, True, 0, 0, 0, True, opt)
         other = kc.FlashForwardKernelConfig(name, 128, 128, 64, 4, True, True, True, 0, 0, 0, True, False)
         qc = ut.QKVConfig(n_heads=H, d_head=128, batch_size=B, seq_len=S, dtype=dtype, device=torch.device(DEV))
         q, k, v = ut.generate_qkv(qc, seed=B + S + 1)
