@@ -107,7 +107,7 @@ constexpr bool plan64_ok(const Plan64 &p) {
 // per-lane clamp in the request path) and the keys in front of the tile's own first key are masked, which
 // masks a tile that lies beyond the sequence whole; Q rows beyond the sequence are fetched from its last
 // row and not stored.
-// SPEC (cfg.optimized_softmax; plain variant and the causal form, not RAG): speculative softmax.  The per-tile row max exists
+// SPEC (cfg.optimized_softmax; every form): speculative softmax.  The per-tile row max exists
 // only to keep P = 2^((s - m) c) in range -- any reference m gives the same real result -- and its
 // end-of-visit chain (32 v_max3, a lane-pair exchange, two ballots) costs 15-20 % of the kernel
 // (tools/tune64.hip, knob 4096).  So an item is first run with m fixed at the row max of its FIRST tile,
@@ -120,7 +120,6 @@ __global__ void
 __launch_bounds__(256, 1)
 fa_fwd_kernel64(const KernelArgs args) {
     static_assert(!RAG || MASK, "the ragged form is a masked variant");
-    static_assert(!SPEC || !RAG, "the speculative softmax is built for the plain and the causal form");
     constexpr int QT = 2, NWAVES = 4, BC = 64, D = 128;
     constexpr bool SWZ = true, EAGER = true, PIPE = true, DMA = true;
 
@@ -783,12 +782,17 @@ fa_fwd_kernel64(const KernelArgs args) {
                     __builtin_amdgcn_sched_barrier(0);
                 });
                 if constexpr (FAST && MASK) {
-                    // causal, speculative: a wave's reference is the row max of ITS diagonal tile -- tile 4 qb + wave,
-                    // the first one it visits that is not masked whole (visit 3 - wave; until then S = -inf gives
-                    // P = 0 against any finite reference, and m = -inf stands for "0").  That tile is the S tile
-                    // this visit formed (masked at gap 34) when it == 2 - wave; for wave 3 it is the item's S(0),
-                    // whose row max the prologue / the seam took.  Once per item and wave, behind the stream.
-                    if (causal && it + 1 < nkc && nkc - 2 - it == 4 * qb_c + wave) {
+                    // masked forms, speculative: a wave's reference is the row max of the FIRST tile it visits that is
+                    // not masked whole -- causal: its diagonal tile 4 qb + wave; ragged: the last tile that holds keys
+                    // of the sequence (the rounded-up tiles beyond it are masked whole); both: the earlier of the two.
+                    // Until then S = -inf gives P = 0 against any finite reference, and m = -inf stands for "0".
+                    // When that tile is the S tile this visit formed (masked at gap 34) its row max is taken here;
+                    // when it is the item's S(0), the prologue / the seam took it.  Once per item and wave, behind
+                    // the stream.
+                    const int t_last = RAG ? (args.seq_len + 63) / 64 - 1 : nkc - 1;
+                    const int t_diag = 4 * qb_c + wave;
+                    const int t_ref = (causal && t_diag < t_last) ? t_diag : t_last;
+                    if (it + 1 < nkc && nkc - 2 - it == t_ref) {
                         asm volatile("s_nop 7" ::: "memory");
 #pragma unroll
                         for (int qt = 0; qt < 2; ++qt) {

@@ -39,8 +39,8 @@ constexpr KernelEntry make_entry() {
         static_assert(NWAVES == 4 && BC == 64 && SWZ && EAGER && DMA && D == 128, "64-row pinned schedule");
         if constexpr (MASK)
             return KernelEntry{DT, 64, 4, 64, 1, 1, OPT, 1, 1, 2, 128, TR::kThreads, TR::kLdsBytes, 1,
-                               (kernel_fn)&fa_fwd_kernel64<DT, true, 0, false, OPT>,   // causal form: speculative with opt_softmax
-                               (kernel_fn)&fa_fwd_kernel64<DT, true, 0, true>};         // ragged form: lazy rescale always
+                               (kernel_fn)&fa_fwd_kernel64<DT, true, 0, false, OPT>,   // causal form (opt_softmax: speculative softmax)
+                               (kernel_fn)&fa_fwd_kernel64<DT, true, 0, true, OPT>};    // ragged form
         else
             return KernelEntry{DT, 64, 4, 64, 1, 1, OPT, 1, 1, 0, 128, TR::kThreads, TR::kLdsBytes, 1,
                                (kernel_fn)&fa_fwd_kernel64<DT, false, 0, false, OPT>, nullptr};  // opt_softmax: speculative softmax

@@ -489,8 +489,7 @@ def best_config(dtype=DType.BF16, seq_len=4096, masked=False) -> FlashForwardKer
     profiles/r01/ragged_persistent.txt), otherwise 4 waves x 32 rows."""
     pad = (-seq_len) % 256
     if pad == 0 or (masked and seq_len >= 64 and pad * 8 <= seq_len):
-        # optimized_softmax = the speculative softmax (plain and causal forms; the ragged form serves both
-        # flag values with the lazy-rescale schedule)
+        # optimized_softmax = the speculative softmax (plain, causal and ragged forms)
         return FlashForwardKernelConfig(
             DType(dtype), 128, 256, 64, 4, True, True, True, 0, 0, 0, True, True
         )

@@ -441,6 +441,31 @@ def test_speculative_softmax_causal_second_pass():
             assert torch.equal(flash_attention.forward_ex(spec, q, k, v, causal=True), out)
 
 
+@pytest.mark.parametrize("S", [1000, 2500])
+def test_speculative_softmax_ragged_second_pass(S):
+    """The ragged form under optimized_softmax: the rounded-up tiles beyond the sequence are masked whole,
+    a wave's reference is the row max of the last tile that holds keys (causal: or its diagonal tile, the
+    earlier of the two).  A huge logit at a key visited later fails the check; the item is redone."""
+    for dtype, name in ((torch.bfloat16, kc.DType.BF16), (torch.float16, kc.DType.FP16)):
+        spec, safe = _persistent_cfg(name, True), _persistent_cfg(name, False)
+        for causal in (False, True):
+            gen = torch.Generator(device=DEV).manual_seed(S + causal)
+            q, k, v = (torch.randn((2, S, 3, 128), dtype=dtype, device=DEV, generator=gen) for _ in range(3))
+            u = _sign_vector(S).to(dtype)
+            k[1, 7, 2] = 30.0 * u
+            q[1, S - 20:S - 12, 2] = 30.0 * u
+            out = flash_attention.forward_ex(spec, q, k, v, causal=causal)
+            out_safe = flash_attention.forward_ex(safe, q, k, v, causal=causal)
+            assert torch.isfinite(out.float()).all()
+            blk = slice(((S - 20) // 256) * 256, min(S, ((S - 20) // 256) * 256 + 256))
+            assert torch.equal(out[1, blk, 2], out_safe[1, blk, 2]), (str(dtype), S, causal)
+            for b_, h_ in ((1, 2), (0, 1)):
+                qs, ks, vs = (t[b_:b_ + 1, :, h_:h_ + 1].contiguous() for t in (q, k, v))
+                eager = fo.eager_attention_masked(qs.cpu(), ks.cpu(), vs.cpu(), causal)
+                assert _rel_ok(out[b_:b_ + 1, :, h_:h_ + 1].cpu(), eager, dtype), (str(dtype), S, causal, b_, h_)
+            assert torch.equal(flash_attention.forward_ex(spec, q, k, v, causal=causal), out)
+
+
 def test_speculative_softmax_fuzz():
     """Seeded fuzz over shapes, spike positions and magnitudes: logits that rise by 0 ... thousands of
     binades anywhere along the visit order, in any number of rows and heads, on the persistent kernel and
@@ -725,8 +750,9 @@ def test_persistent_ragged_lengths(S):
     import ctypes
     lib = _capi.load()
     B, H = (3, 5) if S < 2048 else (2, 3)
-    for dtype, name in ((torch.bfloat16, kc.DType.BF16), (torch.float16, kc.DType.FP16)):
-        cfg = kc.FlashForwardKernelConfig(name, 128, 256, 64, 4, True, True, True, 0, 0, 0, True, False)
+    for dtype, name, opt in ((torch.bfloat16, kc.DType.BF16, False), (torch.float16, kc.DType.FP16, False),
+                             (torch.bfloat16, kc.DType.BF16, True), (torch.float16, kc.DType.FP16, True)):
+        cfg = kc.FlashForwardKernelConfig(name, 128, 256, 64, 4, True, True, True, 0, 0, 0, True, opt)
         other = kc.FlashForwardKernelConfig(name, 128, 128, 64, 4, True, True, True, 0, 0, 0, True, False)
         gen = torch.Generator(device=DEV).manual_seed(S)
         # q, k, v, o: the first S rows of (B, S + 8, H, 128) buffers (through the C ABI: the shim wants contiguous)
@@ -769,8 +795,8 @@ def test_ragged_item_seams_under_load(S):
     B, H = 6, 24
     n_qb = (S + 255) // 256
     assert B * H * n_qb > 4 * 256
-    for dtype, name in ((torch.bfloat16, kc.DType.BF16), (torch.float16, kc.DType.FP16)):
-        cfg = kc.FlashForwardKernelConfig(name, 128, 256, 64, 4, True, True, True, 0, 0, 0, True, False)
+    for dtype, name, opt in ((torch.bfloat16, kc.DType.BF16, False), (torch.float16, kc.DType.FP16, True)):
+        cfg = kc.FlashForwardKernelConfig(name, 128, 256, 64, 4, True, True, True, 0, 0, 0, True, opt)
         other = kc.FlashForwardKernelConfig(name, 128, 128, 64, 4, True, True, True, 0, 0, 0, True, False)
         gen = torch.Generator(device=DEV).manual_seed(S)
         q, k, v = (torch.randn((B, S, H, 128), dtype=dtype, device=DEV, generator=gen) for _ in range(3))
