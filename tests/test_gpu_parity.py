@@ -497,6 +497,33 @@ def test_speculative_softmax_fuzz():
         assert torch.equal(flash_attention.forward(cfg, q, k, v), out), (trial, str(cfg))
 
 
+def test_speculative_softmax_masked_fuzz():
+    """The same fuzz through forward_ex on the persistent kernel's masked forms: any seq_len >= 64, causal or
+    not, spikes anywhere (also at keys a causal row never sees, and in rows of the rounded-up tail)."""
+    import random
+    rng = random.Random(77)
+    for trial in range(28):
+        dtype, name = ((torch.bfloat16, kc.DType.BF16), (torch.float16, kc.DType.FP16))[trial & 1]
+        cfg = _persistent_cfg(name, True)
+        B, H = rng.choice([1, 2, 3]), rng.choice([1, 2, 5])
+        S = rng.choice([64, 100, 256, 300, 511, 512, 777, 1024, 1500, 2048, 2300])
+        causal = bool(rng.getrandbits(1))
+        gen = torch.Generator(device=DEV).manual_seed(1000 + trial)
+        q, k, v = (torch.randn((B, S, H, 128), dtype=dtype, device=DEV, generator=gen) for _ in range(3))
+        for _ in range(rng.choice([0, 1, 2, 3])):
+            b_, h_ = rng.randrange(B), rng.randrange(H)
+            key, row, n_rows = rng.randrange(S), rng.randrange(S), rng.choice([1, 5, 70])
+            a = rng.choice([0.8, 1.3, 3.0, 30.0])
+            u = _sign_vector(rng.randrange(1000)).to(dtype)
+            k[b_, key, h_] = a * u
+            q[b_, row:row + n_rows, h_] = a * u
+        out = flash_attention.forward_ex(cfg, q, k, v, causal=causal)
+        assert torch.isfinite(out.float()).all(), (trial, S, causal)
+        eager = fo.eager_attention_masked(q.cpu(), k.cpu(), v.cpu(), causal)
+        assert _rel_ok(out.cpu(), eager, dtype), (trial, str(dtype), B, H, S, causal)
+        assert torch.equal(flash_attention.forward_ex(cfg, q, k, v, causal=causal), out), (trial, S, causal)
+
+
 def test_speculative_softmax_second_pass_beyond_ordinal_63():
     """A workgroup records failed items in a 64-bit mask of walk ordinals; ordinals >= 63 share the
     last bit (the second pass then redoes all of them).  130 * 128 items of one Q block each on 256
