@@ -34,6 +34,8 @@ BLOCK(rcp, I8("v_rcp_f32", "%8"))
 BLOCK(cvt_pk, I8("v_cvt_pk_bf16_f32", "%8, %9"))
 BLOCK(max3, I8("v_max3_f32", "%8, %9, %10"))
 BLOCK(ldexp, I8("v_ldexp_f32", "%8, %9"))
+BLOCK(dot2, I8("v_dot2_f32_bf16", "%8, %9, %10"))
+BLOCK(dot2c, I8("v_dot2c_f32_bf16", "%8, %9"))
 BLOCK(exp_then_fma, "v_exp_f32 %0, %8\n\tv_fma_f32 %1, %8, %9, %10\n\tv_exp_f32 %2, %9\n\tv_fma_f32 %3, %8, %9, %10\n\tv_exp_f32 %4, %10\n\tv_fma_f32 %5, %8, %9, %10\n\tv_exp_f32 %6, %11\n\tv_fma_f32 %7, %8, %9, %10\n\t")
 
 // beside MFMAs: 8 x { v_mfma ; N fillers } -- cycles per MFMA gap
@@ -89,6 +91,10 @@ M4BLOCK(unit_adds, "v_exp_f32 %0, %14\n\tv_exp_f32 %1, %15\n\tv_fma_f32 %2, %14,
 M4BLOCK(unit_noadds, "v_exp_f32 %0, %14\n\tv_exp_f32 %1, %15\n\tv_fma_f32 %2, %14, %15, %16\n\tv_fma_f32 %3, %14, %15, %16\n\tv_cvt_pk_bf16_f32 %6, %14, %15\n\t")
 M4BLOCK(unit_sum4, "v_exp_f32 %0, %14\n\tv_exp_f32 %1, %15\n\tv_fma_f32 %2, %14, %15, %16\n\tv_fma_f32 %3, %14, %15, %16\n\tv_cvt_pk_bf16_f32 %6, %14, %15\n\tv_mfma_f32_4x4x4_16b_bf16 %10, %17, %18, %10\n\t")
 
+// row sums of the ROUNDED P by one v_dot2_f32_bf16 with a packed-ones operand per pair (reads the previous unit's pack)
+M4BLOCK(unit_dot2, "v_exp_f32 %0, %14\n\tv_exp_f32 %1, %15\n\tv_fma_f32 %2, %14, %15, %16\n\tv_fma_f32 %3, %14, %15, %16\n\tv_dot2_f32_bf16 %4, %6, %16, %4\n\tv_cvt_pk_bf16_f32 %6, %14, %15\n\t")
+M4BLOCK(unit_dot2c, "v_exp_f32 %0, %14\n\tv_exp_f32 %1, %15\n\tv_fma_f32 %2, %14, %15, %16\n\tv_fma_f32 %3, %14, %15, %16\n\tv_dot2c_f32_bf16 %4, %6, %16\n\tv_cvt_pk_bf16_f32 %6, %14, %15\n\t")
+
 // the unit with its two row-sum adds as ONE v_pk_add_f32 on register pairs (physical registers named in the asm)
 __global__ void __launch_bounds__(256, 1) m_unit_pkadd(unsigned long long *out, float seed, const bf16x8 *ab) {
     float a0 = seed, a1 = seed + 1, a2 = seed + 2;
@@ -111,11 +117,11 @@ int main() {
     unsigned long long h[2];
 #define RUN(name, n) do { for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(k_##name, dim3(256), dim3(256), 0, 0, out, 1.5f); CHECK(hipDeviceSynchronize()); \
         CHECK(hipMemcpy(h, out, 16, hipMemcpyDeviceToHost)); printf("%-28s %6.2f cycles per instruction (%llu / %d)\n", #name, (double)h[0] / (n), h[0], n); } while (0)
-    RUN(fma, 64); RUN(add, 64); RUN(exp, 64); RUN(exp_legacy, 64); RUN(exp_f16, 64); RUN(log, 64); RUN(rcp, 64); RUN(cvt_pk, 64); RUN(max3, 64); RUN(ldexp, 64);
+    RUN(fma, 64); RUN(add, 64); RUN(exp, 64); RUN(exp_legacy, 64); RUN(exp_f16, 64); RUN(log, 64); RUN(rcp, 64); RUN(cvt_pk, 64); RUN(max3, 64); RUN(ldexp, 64); RUN(dot2, 64); RUN(dot2c, 64);
     RUN(exp_then_fma, 64);
 #define MRUN(name) do { for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(m_##name, dim3(256), dim3(256), 0, 0, out, 1.5f, ab); CHECK(hipDeviceSynchronize()); \
         CHECK(hipMemcpy(h, out, 16, hipMemcpyDeviceToHost)); printf("MFMA + %-21s %6.2f cycles per MFMA gap (%llu / 16)\n", #name, (double)h[0] / 16, h[0]); } while (0)
-    MRUN(sum4_only); MRUN(sum4_x2); MRUN(unit_adds); MRUN(unit_noadds); MRUN(unit_sum4); MRUN(unit_pkadd);
+    MRUN(sum4_only); MRUN(sum4_x2); MRUN(unit_adds); MRUN(unit_noadds); MRUN(unit_sum4); MRUN(unit_pkadd); MRUN(unit_dot2); MRUN(unit_dot2c);
     MRUN(bare); MRUN(fma4); MRUN(fma6); MRUN(exp1); MRUN(exp2); MRUN(exp1_fma3); MRUN(exp2_fma5); MRUN(expf16_2_fma5);
     return 0;
 }
