@@ -619,6 +619,37 @@ def test_full_size_properties(name, dtype, B, H, S):
     assert (oo.float() - out.float()).abs().max().item() <= TOL[dtype]
 
 
+@pytest.mark.parametrize("shape", ["persistent", "32-row", "key-split", "16-row"])
+def test_whole_c4_job_on_one_device_offsets_beyond_4_gib(shape):
+    """BASELINE.json configs[3] unsharded: B=64 H=32 S=8192 d=128 bf16 -- every tensor is 4 GiB, so byte offsets of
+    the last samples need more than 32 bits (batch / head offsets are 64-bit in every kernel; only the offset inside
+    one sequence is 32-bit, which validate() bounds).  Each sample of the big launch must equal, bit for bit, the
+    same sample launched alone -- that is also the 8-GPU shard independence at the job's own size."""
+    B, H, S = 64, 32, 8192
+    free, _ = torch.cuda.mem_get_info(0)
+    if free < 24 << 30:
+        pytest.skip("needs 16 GiB of q/k/v/o")
+    cfg = {"persistent": kc.best_config(kc.DType.BF16),
+           "32-row": kc.FlashForwardKernelConfig(kc.DType.BF16, 128, 128, 64, 4, True, True, True, 0, 0, 0, True, True),
+           "key-split": kc.FlashForwardKernelConfig(kc.DType.BF16, 128, 64, 64, 4, True, True, True, 0, 0, 0, True, True),
+           "16-row": kc.FlashForwardKernelConfig(kc.DType.BF16, 128, 64, 32, 4, True, True, True, 0, 0, 0, False, False)}[shape]
+    gen = torch.Generator(device=DEV).manual_seed(64)
+    q, k, v = (torch.empty((B, S, H, 128), dtype=torch.bfloat16, device=DEV) for _ in range(3))
+    for t in (q, k, v):
+        for b in range(0, B, 8):                      # fill by slices: no 16-GiB fp32 temporary
+            t[b:b + 8].normal_(generator=gen)
+    assert q.numel() * q.element_size() == 1 << 32
+    out = flash_attention.forward(cfg, q, k, v)
+    for b in (0, 31, 32, 63):
+        alone = flash_attention.forward(cfg, q[b:b + 1], k[b:b + 1], v[b:b + 1])
+        assert torch.equal(alone[0], out[b]), (shape, b)
+    ref = ut.py_flash_attention(q[B - 1:B, :, H - 1:H].contiguous(), k[B - 1:B, :, H - 1:H].contiguous(),
+                                v[B - 1:B, :, H - 1:H].contiguous(), upcast=True)
+    assert (out[B - 1:B, :, H - 1:H].float() - ref.float()).abs().max().item() <= TOL[torch.bfloat16]
+    del q, k, v, out
+    torch.cuda.empty_cache()
+
+
 # BASELINE.json configs[2]: the bf16 seq_len sweep, batch from the reference's table
 # (py/flash_helpers/test/utils.py:9-17), heads 16 -- every shape at full size
 C2 = [(S, ut.BATCH_SIZE_FOR_SEQ_LEN[S]) for S in (512, 1024, 2048, 4096, 8192, 16384)]
