@@ -63,6 +63,26 @@ MBLOCK(exp1_fma3, "v_exp_f32 %0, %12\n\tv_fma_f32 %1, %12, %13, %14\n\tv_fma_f32
 MBLOCK(exp2_fma5, "v_exp_f32 %0, %12\n\tv_exp_f32 %1, %13\n\tv_fma_f32 %2, %12, %13, %14\n\tv_fma_f32 %3, %12, %13, %14\n\tv_fma_f32 %4, %12, %13, %14\n\tv_fma_f32 %5, %12, %13, %14\n\tv_fma_f32 %6, %12, %13, %14\n\t")
 MBLOCK(expf16_2_fma5, "v_exp_f16 %0, %12\n\tv_exp_f16 %1, %13\n\tv_fma_f32 %2, %12, %13, %14\n\tv_fma_f32 %3, %12, %13, %14\n\tv_fma_f32 %4, %12, %13, %14\n\tv_fma_f32 %5, %12, %13, %14\n\tv_fma_f32 %6, %12, %13, %14\n\t")
 
+#define MABLOCK(name, fill)                                                                                       \
+    __global__ void __launch_bounds__(256, 1) ma_##name(unsigned long long *out, float seed, const bf16x8 *ab) {   \
+        float a0 = seed, a1 = seed + 1, a2 = seed + 2, d0, d1, d2, d3, d4, d5, d6, d7;                              \
+        d0 = d1 = d2 = d3 = d4 = d5 = d6 = d7 = seed;                                                              \
+        bf16x8 a = ab[threadIdx.x & 63], b = ab[64 + (threadIdx.x & 63)];                                          \
+        f32x16 c0 = {}, c1 = {};                                                                                  \
+        unsigned long long t0, t1;                                                                                \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0));        \
+        asm volatile(REP8("v_mfma_f32_32x32x16_bf16 %8, %10, %11, %8\n\t" fill "v_mfma_f32_32x32x16_bf16 %9, %10, %11, %9\n\t" fill) \
+                     : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(d4), "+v"(d5), "+v"(d6), "+v"(d7), "+a"(c0), "+a"(c1) \
+                     : "v"(a), "v"(b), "v"(a0), "v"(a1), "v"(a2));                                                 \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1));                                          \
+        if (threadIdx.x == 0 && blockIdx.x == 0) out[0] = t1 - t0;                                                 \
+        if (d0 + d1 + d2 + d3 + d4 + d5 + d6 + d7 + c0[0] + c1[1] == 12345.0f) out[1] = 1;                         \
+    }
+MABLOCK(bare, "")
+MABLOCK(fma4, "v_fma_f32 %0, %12, %13, %14\n\tv_fma_f32 %1, %12, %13, %14\n\tv_fma_f32 %2, %12, %13, %14\n\tv_fma_f32 %3, %12, %13, %14\n\t")
+MABLOCK(fma6, "v_fma_f32 %0, %12, %13, %14\n\tv_fma_f32 %1, %12, %13, %14\n\tv_fma_f32 %2, %12, %13, %14\n\tv_fma_f32 %3, %12, %13, %14\n\tv_fma_f32 %4, %12, %13, %14\n\tv_fma_f32 %5, %12, %13, %14\n\t")
+MABLOCK(exp2_fma5, "v_exp_f32 %0, %12\n\tv_exp_f32 %1, %13\n\tv_fma_f32 %2, %12, %13, %14\n\tv_fma_f32 %3, %12, %13, %14\n\tv_fma_f32 %4, %12, %13, %14\n\tv_fma_f32 %5, %12, %13, %14\n\tv_fma_f32 %6, %12, %13, %14\n\t")
+
 // row sums on the matrix pipe: v_mfma_f32_4x4x4_16b_bf16 with A = ones adds a lane's four packed values into its accumulator
 #define M4BLOCK(name, fill)                                                                                      \
     __global__ void __launch_bounds__(256, 1) m_##name(unsigned long long *out, float seed, const bf16x8 *ab) {   \
@@ -123,5 +143,8 @@ int main() {
         CHECK(hipMemcpy(h, out, 16, hipMemcpyDeviceToHost)); printf("MFMA + %-21s %6.2f cycles per MFMA gap (%llu / 16)\n", #name, (double)h[0] / 16, h[0]); } while (0)
     MRUN(sum4_only); MRUN(sum4_x2); MRUN(unit_adds); MRUN(unit_noadds); MRUN(unit_sum4); MRUN(unit_pkadd); MRUN(unit_dot2); MRUN(unit_dot2c);
     MRUN(bare); MRUN(fma4); MRUN(fma6); MRUN(exp1); MRUN(exp2); MRUN(exp1_fma3); MRUN(exp2_fma5); MRUN(expf16_2_fma5);
+#define MARUN(name) do { for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(ma_##name, dim3(256), dim3(256), 0, 0, out, 1.5f, ab); CHECK(hipDeviceSynchronize()); \
+        CHECK(hipMemcpy(h, out, 16, hipMemcpyDeviceToHost)); printf("MFMA(acc in AGPR) + %-10s %6.2f cycles per MFMA gap (%llu / 16)\n", #name, (double)h[0] / 16, h[0]); } while (0)
+    MARUN(bare); MARUN(fma4); MARUN(fma6); MARUN(exp2_fma5);
     return 0;
 }
