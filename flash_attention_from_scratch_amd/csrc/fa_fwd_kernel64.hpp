@@ -196,6 +196,23 @@ fa_fwd_kernel64(const KernelArgs args) {
         }
     };
 #endif
+#if defined(FA_TRACE) && FA_TRACE >= 4
+    // item timeline (tools/trace64.hip -DFA_TRACE=4; 5 adds stamps inside the first seam, which slow every visit by ~5 %
+    // through their compares): stamps kept in ONE VGPR (lane n = stamp n: 0 kernel entry,
+    // 1 + ordinal = top of the item's first visit, 62 = S(0) of the first item formed, 63 = exit) and stored once at the
+    // end -- no memory operation is added to the walk, so the counted waits and the visits are the product kernel's
+    unsigned tlv = 0;
+    auto tl_at = [&](int slot) {
+        unsigned long long t_;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");
+        const unsigned lo_ = __builtin_amdgcn_readfirstlane((unsigned)t_);
+        tlv = (lane == slot) ? lo_ : tlv;
+    };
+    tl_at(0);
+#define FA_TL4(slot) tl_at(slot)
+#else
+#define FA_TL4(slot) ((void)0)
+#endif
 
     // ---- workgroup -> (batch*head, Q block); XCD-aware when n_bh % 8 == 0 --------
     const int nq = args.n_q_blocks;
@@ -532,11 +549,18 @@ fa_fwd_kernel64(const KernelArgs args) {
             auto read_next_q = [&](vec8 (&dst)[KS]) { read_q(dst, q_stage); };
             auto visit = [&](int it, auto &S_cur, auto &S_nxt, auto r_tag) {
                 constexpr int R = decltype(r_tag)::value;  // it & 3
-#ifdef FA_TRACE
+#if defined(FA_TRACE) && FA_TRACE < 4
                 unsigned long long ts[20];
                 asm volatile("s_memtime %0" : "=s"(ts[0]));
 #endif
                 FA_TL();
+#if defined(FA_TRACE) && FA_TRACE >= 4
+                if (it == 0) tl_at(1 + (ord < 60 ? ord : 60));
+                if constexpr (FA_TRACE == 5) {
+                    if (ord == 1 && it >= 1 && it <= 4) tl_at(55 + it);            // slots 56 .. 59: tops of visits 1 .. 4 behind the first seam
+                    if (ord == 0 && it + 2 >= nkc) tl_at(48 + (it + 2 - nkc));    // slots 48, 49: tops of the first item's last two visits
+                }
+#endif
                 // the visit's synchronisation point: K(it+2), V(it+1) landed (requested two visits ago;
                 // K(it+1), V(it) were published by the previous barrier), the 8 youngest pieces may fly
                 // on; behind it every wave has finished visit it-1, whose K / V stages the DMA of this
@@ -727,7 +751,7 @@ fa_fwd_kernel64(const KernelArgs args) {
                         // operands step, step + 1 landed; the LDS reads of operands step + 2 ... step + LA - 1 (one per
                         // K fragment, two per V fragment; LDS returns in order) may still fly
                         constexpr int fly = [] { int n = 0; for (int u = step + 2; u < step + LA; ++u) n += (u >= 16 && u < 32) ? 2 : 1; return n; }();
-#ifdef FA_TRACE
+#if defined(FA_TRACE) && FA_TRACE < 4
                         __builtin_amdgcn_s_waitcnt(0xC07F);      // (s_memtime returns out of order: no counting)
 #else
                         __builtin_amdgcn_s_waitcnt(0xC07F | (fly << 8));
@@ -807,7 +831,7 @@ fa_fwd_kernel64(const KernelArgs args) {
                         }
                     }
                 }
-#ifdef FA_TRACE
+#if defined(FA_TRACE) && FA_TRACE < 4
                 asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts[18])::"memory");
                 if (item == args.trace_block && it == args.trace_visit && lane == 0) {
 #pragma unroll
@@ -916,6 +940,7 @@ fa_fwd_kernel64(const KernelArgs args) {
                 barrier();
                 FA_TLF();
                 FA_TL();  // S(0) formed, K(1) landed
+                FA_TL4(62);
 #pragma unroll
                 for (int u = 0; u < LA; ++u) ring[u] = k_frag(smem + TILE, u);  // first operands of visit 0: K(1)
             }
@@ -994,12 +1019,19 @@ fa_fwd_kernel64(const KernelArgs args) {
                     visit(it + 2, Sa, Sb, IntTag<2>{});
                     visit(it + 3, Sb, Sa, IntTag<3>{});
                 }
-#ifdef FA_TRACE
+#if defined(FA_TRACE) && FA_TRACE < 4
                 unsigned long long te0, te1, te2;
                 asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(te0)::"memory");
 #endif
+#if defined(FA_TRACE) && FA_TRACE >= 4
+                const bool tl_seam = FA_TRACE == 5 && ord == 0;  // fine stamps of the first seam: slots 50 .. 55
+                if (tl_seam) tl_at(50);  // last visit done
+#endif
                 store_item();
-#ifdef FA_TRACE
+#if defined(FA_TRACE) && FA_TRACE >= 4
+                if (tl_seam) tl_at(51);  // epilogue issued
+#endif
+#if defined(FA_TRACE) && FA_TRACE < 4
                 asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(te1)::"memory");
 #endif
                 if (!has_next) break;
@@ -1012,6 +1044,9 @@ fa_fwd_kernel64(const KernelArgs args) {
                 Kc = Kn; Vc = Vn; Oc = On; qb_c = qb_n;
                 nkc = nkn;
                 set_next();
+#if defined(FA_TRACE) && FA_TRACE >= 4
+                if (tl_seam) tl_at(53);  // coordinates of the item after
+#endif
                 kq = tile_g(Kc, Kn, 4);  // visit 0 requests K(4), V(3) (for n_kv == 4 that is already the item after)
                 vq = tile_g(Vc, Vn, 3);
                 if (has_next) request_next_q(0);  // (the staging area is free again: store_item's reads have retired)
@@ -1021,6 +1056,9 @@ fa_fwd_kernel64(const KernelArgs args) {
                     seam_st = rows_in >= 64 ? 16 : (rows_in >= 32 ? 8 : 0);
                 }
                 resc_any = 0;
+#if defined(FA_TRACE) && FA_TRACE >= 4
+                if (tl_seam) tl_at(54);  // next Q tile 0 requested
+#endif
                 if constexpr (FAST) {
                     // the row max of the S tile the last visit formed (the next item's S(0)): the speculative
                     // schedule has no row-max units, this is the only one an item needs (behind store_item's pads)
@@ -1043,8 +1081,14 @@ fa_fwd_kernel64(const KernelArgs args) {
                     m_pend[qt] = m[qt];
                     rs[qt][0] = rs[qt][1] = 0.0f;
                 }
+#if defined(FA_TRACE) && FA_TRACE >= 4
+                if (tl_seam) tl_at(55);  // row max of S(0), softmax state reset
+#endif
                 zero_o();
-#ifdef FA_TRACE
+#if defined(FA_TRACE) && FA_TRACE >= 4
+                if (tl_seam) tl_at(52);  // O = 0 issued
+#endif
+#if defined(FA_TRACE) && FA_TRACE < 4
                 asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(te2)::"memory");
                 if (item == args.trace_block + (int)gridDim.x && lane == 0) {
                     args.trace[wave * 24 + 21] = te0;
@@ -1055,6 +1099,12 @@ fa_fwd_kernel64(const KernelArgs args) {
             }
             dma_wait();  // nothing may still be landing in the LDS when the workgroup retires (or the next pass starts)
             FA_TL();
+#if defined(FA_TRACE) && FA_TRACE >= 4
+            if constexpr (FAST || !SPEC) {
+                tl_at(63);
+                ((unsigned *)args.trace)[(wave * 256 + (int)blockIdx.x) * 64 + lane] = tlv;
+            }
+#endif
             return failed;
         }
     };  // walk

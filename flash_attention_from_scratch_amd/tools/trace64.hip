@@ -19,7 +19,83 @@
 #include <vector>
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(e_), __LINE__); exit(2); } } while (0)
 
-#if FA_TRACE == 3
+#if FA_TRACE >= 4
+// item timeline (-DFA_TRACE=4): trace64 [seq_len] [batch] [heads] -- the product kernel's walk with one stamp per item
+// (no memory operation added to the visits): per workgroup  entry | S(0) formed | top of each item's first visit | exit
+int main(int argc, char **argv) {
+    const int S = argc > 1 ? atoi(argv[1]) : 4096, B = argc > 2 ? atoi(argv[2]) : 4, H = argc > 3 ? atoi(argv[3]) : 16, D = 128;
+    const size_t n = (size_t)B * S * H * D;
+    std::vector<uint16_t> h(n);
+    uint16_t *q, *k, *v, *o; unsigned long long *tr;
+    CHECK(hipMalloc(&q, n * 2)); CHECK(hipMalloc(&k, n * 2)); CHECK(hipMalloc(&v, n * 2)); CHECK(hipMalloc(&o, n * 2));
+    const int grid = argc > 4 ? atoi(argv[4]) : 256;  // fewer workgroups (a multiple of 8): the same walk with a smaller chip-wide burst at the seams
+    CHECK(hipMalloc(&tr, 4 * 256 * 64 * 4));
+    srand(1);
+    for (int t = 0; t < 3; ++t) {
+        for (size_t i = 0; i < n; ++i) {
+            float x = ((rand() & 0xffff) / 65536.0f - 0.5f) * 3.4f;
+            uint32_t u; memcpy(&u, &x, 4); h[i] = (uint16_t)(u >> 16);
+        }
+        CHECK(hipMemcpy(t == 0 ? q : t == 1 ? k : v, h.data(), n * 2, hipMemcpyHostToDevice));
+    }
+    fa::KernelArgs a;
+    a.q = q; a.k = k; a.v = v; a.o = o;
+    a.batch_stride = (int64_t)S * H * D; a.seq_stride = H * D; a.head_stride = D;
+    a.seq_len = S; a.n_heads = H; a.n_bh = B * H; a.n_q_blocks = S / 256; a.n_kv_blocks = S / 64; a.causal = 0;
+    a.trace = tr; a.trace_block = -1; a.trace_visit = -1;
+#ifndef TRACE_SPEC
+#define TRACE_SPEC 1
+#endif
+    auto kern = fa::fa_fwd_kernel64<15, false, 0, false, TRACE_SPEC != 0>;
+    CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
+    hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    const int n_items = B * H * (S / 256), per_wg = (n_items + grid - 1) / grid, nkv = S / 64;
+    for (int rep = 0; rep < 3; ++rep) {
+        for (int warm = 0; warm < (rep ? 2000 : 5); ++warm) hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 163840, 0, a);  // rep > 0: clocks settled under load
+        CHECK(hipMemset(tr, 0, 4 * 256 * 64 * 4));
+        CHECK(hipEventRecord(e0));
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 163840, 0, a);
+        CHECK(hipEventRecord(e1));
+        CHECK(hipDeviceSynchronize());
+        float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+        std::vector<unsigned> t(4 * 256 * 64);
+        CHECK(hipMemcpy(t.data(), tr, t.size() * 4, hipMemcpyDeviceToHost));
+        printf("== S=%d B=%d H=%d grid %d: %d items per workgroup of %d visits; event %.1f us\n", S, B, H, grid, per_wg, nkv, ms * 1000);
+        // wave 0 of every workgroup; times in s_memtime ticks (100 MHz on this chip? the tool prints the ratio to the event below)
+        unsigned first = ~0u, last = 0;
+        for (int w = 0; w < grid; ++w) { const unsigned *r = t.data() + w * 64; if (r[0] < first) first = r[0]; if (r[63] - first > last - first) last = r[63]; }
+        printf("first entry -> last exit: %u ticks = %.4f ticks per ns of the event bracket\n", last - first, (last - first) / (ms * 1e6));
+        double pro = 0, run = 0, fin = 0, ent = 0, ext = 0; std::vector<double> item(per_wg, 0.0);
+        for (int w = 0; w < grid; ++w) {
+            const unsigned *r = t.data() + w * 64;
+            pro += r[1] - r[0]; run += r[63] - r[0]; ent += r[0] - first; ext += last - r[63];
+            for (int i = 0; i + 1 < per_wg; ++i) item[i] += r[2 + i] - r[1 + i];
+            fin += r[63] - r[per_wg];
+        }
+        printf("mean over workgroups: entry +%.0f | prologue (entry -> first visit) %.0f |", ent / grid, pro / grid);
+        for (int i = 0; i + 1 < per_wg; ++i) printf(" item %d (%d visits + seam) %.0f |", i, nkv, item[i] / grid);
+        printf(" last item (%d visits + epilogue) %.0f | total %.0f | exit before the last %.0f\n", nkv, fin / grid, run / grid, ext / grid);
+        const int show[4] = {0, 37 % grid, grid / 2, grid - 1};
+        for (int si = 0; si < 4; ++si) {
+            const unsigned *r = t.data() + show[si] * 64;
+            printf("wg %3d wave 0: entry +%u | S(0) formed +%u | first visit +%u |", show[si], r[0] - first, r[62] - r[0], r[1] - r[0]);
+            for (int i = 0; i + 1 < per_wg; ++i) printf(" %u", r[2 + i] - r[1 + i]);
+            printf(" | last %u | exit +%u\n", r[63] - r[per_wg], r[63] - first);
+        }
+        if (FA_TRACE == 5 && per_wg > 1) {  // the first seam in detail (mean over workgroups, wave 0)
+            const char *name[11] = {"visit n-2", "visit n-1 (forms the next S(0))", "epilogue (store_item)", "next coordinates", "Q tile 0 request",
+                                    "row max + state", "O = 0", "to the top of visit 0", "visit 0", "visit 1", "visit 2"};
+            const int a_[11] = {48, 49, 50, 51, 53, 54, 55, 52, 2, 56, 57}, b_[11] = {49, 50, 51, 53, 54, 55, 52, 2, 56, 57, 58};
+            printf("first seam:");
+            for (int i = 0; i < 11; ++i) { double sum = 0; for (int w = 0; w < grid; ++w) sum += (double)(t[w * 64 + b_[i]] - t[w * 64 + a_[i]]); printf(" %s %.0f |", name[i], sum / grid); }
+            { double sum = 0; for (int w = 0; w < grid; ++w) sum += (double)(t[w * 64 + 59] - t[w * 64 + 58]); printf(" visit 3 %.0f\n", sum / grid); }
+        }
+        // the four waves of one workgroup: skew at the exit
+        for (int wv = 0; wv < 4; ++wv) { const unsigned *r = t.data() + (wv * 256 + 5) * 64; printf("wg 5 wave %d: total %u%s", wv, r[63] - r[0], wv == 3 ? "\n" : " | "); }
+    }
+    return 0;
+}
+#elif FA_TRACE == 3
 // timeline mode (-DFA_TRACE=3): trace64 [seq_len] [batch] -- one launch, every workgroup's wave 0 stamps
 // entry | S(0) formed | visit tops ... | exit (a seam shows as a long visit)
 int main(int argc, char **argv) {
