@@ -110,6 +110,12 @@ template <int BEGIN, int END, class F> __device__ __forceinline__ void static_fo
 
 template <int DT> struct Elem;
 
+// Speculative softmax (optimized_softmax): a row of the first pass is accepted when its l = sum of P stays below this.
+// Every P of the row is <= l, so below the limit fp32 exp2 did not overflow, the 16-bit P is in range (fp16: P < 65504)
+// and the fp32 accumulators hold |O| <= l max|V| -- finite for every fp16 V, and for bf16 V up to 2^63.  bf16: 2^64
+// (~44 nats above the first visited tile's max), fp16: 2^15 (~10 nats).  !(l < limit) is also true for NaN and +inf.
+template <int DT> __device__ constexpr float spec_limit() { return DT == 5 ? 32768.0f : 18446744073709551616.0f; }
+
 template <> struct Elem<15> {  // bf16
     typedef bf16x8 vec8;
     static FA_DEV f32x16 mfma(vec8 a, vec8 b, f32x16 c) {
@@ -985,7 +991,7 @@ fa_fwd_kernel(const KernelArgs args) {
     if constexpr (FAST) {
         // every P of a row is <= its l: below the limit nothing overflowed (fp32 exp2, the 16-bit P, fp32 O);
         // NaN fails the compare too.  One verdict per workgroup, through the idle LDS.
-        constexpr float kLimit = DT == 5 ? 32768.0f : 1.2676506e30f;  // 2^15 (fp16 P < 65504) / 2^100
+        constexpr float kLimit = spec_limit<DT>();
         bool bad = false;
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) bad |= !(pair_sum(l[qt]) < kLimit);

@@ -264,7 +264,7 @@ fa_fwd_kernel16(const KernelArgs args) {
         }
         wg_barrier();  // every wave is done with the K/V stages
         if constexpr (FAST) {  // l >= every P of the row: below the limit nothing overflowed; one verdict per workgroup
-            constexpr float kLimit = DT == 5 ? 32768.0f : 1.2676506e30f;  // 2^15 (fp16 P < 65504) / 2^100
+            constexpr float kLimit = spec_limit<DT>();
             const int wave_bad = __ballot(!(quad_sum(l) < kLimit)) != 0 ? 1 : 0;
             if (lane == 0) *(int *)(smem + wave * 4) = wave_bad;
             wg_barrier();

@@ -965,7 +965,7 @@ fa_fwd_kernel64(const KernelArgs args) {
                         // every P of the row is <= l: below the limit nothing overflowed on the way (fp32 exp2, the
                         // 16-bit P, fp32 O); NaN fails the compare too.  A failed item is stored all the same (its
                         // rows are rewritten by the second pass).
-                        constexpr float kLimit = DT == 5 ? 32768.0f : 1.2676506e30f;  // 2^15 (fp16 P < 65504) / 2^100
+                        constexpr float kLimit = spec_limit<DT>();
                         if (__ballot(!(l_row < kLimit)) != 0) failed |= 1ull << (ord < 63 ? ord : 63);
                     }
                     const float inv = 1.0f / l_row;

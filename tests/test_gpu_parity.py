@@ -388,6 +388,37 @@ def test_speculative_softmax_second_pass(rise):
                 assert torch.equal(flash_attention.forward(spec, q, k, v), out)
 
 
+@pytest.mark.parametrize("family", ["persistent", "32-row", "16-row"])
+def test_speculative_softmax_limit_and_large_values(family):
+    """The bf16 limit of the first pass is l < 2^64 (spec_limit): a rise of ~50 binades above the first visited tile
+    stays in the first pass, ~75 binades takes the second -- there the rows equal the optimized_softmax = False build
+    bit for bit -- and with V scaled by 2^50 (|O| <= l max|V| = 2^114 < fp32 max in the first pass) both stay finite
+    and within relative tolerance of fp32 eager."""
+    cfg_of = {"persistent": lambda o: _persistent_cfg(kc.DType.BF16, o),
+              "32-row": lambda o: kc.FlashForwardKernelConfig(kc.DType.BF16, 128, 128, 64, 4, True, True, True, 0, 0, 0, True, o),
+              "16-row": lambda o: kc.FlashForwardKernelConfig(kc.DType.BF16, 128, 64, 32, 4, True, True, True, 0, 0, 0, False, o)}[family]
+    spec, safe = cfg_of(True), cfg_of(False)
+    B, H, S, b_, h_ = 2, 3, 1024, 1, 2
+    for binades, second in ((50.0, False), (75.0, True)):
+        a = (binades / (128 * 1.4426950408889634 / 128 ** 0.5)) ** 0.5   # q.k c = a^2 128 c binades above an N(0, 1) tile
+        qc = ut.QKVConfig(n_heads=H, d_head=128, batch_size=B, seq_len=S, dtype=torch.bfloat16, device=torch.device(DEV))
+        q, k, v = ut.generate_qkv(qc, seed=11)
+        u = _sign_vector(5).to(torch.bfloat16)
+        k[b_, 3, h_] = a * u                 # key 3: in the LAST visited tile
+        q[b_, 256:512, h_] = a * u           # one whole Q block (two / four workgroups of the smaller tilings)
+        v = (v.float() * 2.0 ** 50).to(torch.bfloat16)
+        out = flash_attention.forward(spec, q, k, v)
+        out_safe = flash_attention.forward(safe, q, k, v)
+        assert torch.isfinite(out.float()).all() and torch.isfinite(out_safe.float()).all()
+        blk = (b_, slice(256, 512), h_)
+        if second:
+            assert torch.equal(out[blk], out_safe[blk]), (family, binades)
+        ref = ut.py_flash_attention(q, k, v, upcast=True).float()
+        tol = TOL[torch.bfloat16] * (2.0 ** 50 + ref.abs())
+        assert ((out.float() - ref).abs() <= tol).all(), (family, binades)
+        assert ((out_safe.float() - ref).abs() <= tol).all(), (family, binades)
+
+
 def test_speculative_softmax_on_the_32_row_kernels_starts_over():
     """optimized_softmax on the double-buffered 32-rows-per-wave variants (the key-split (64, 64, 4) form
     and the 16-rows-per-wave (64, 32, 4) kernel too) is the speculative softmax too: a workgroup whose check fails runs its item again with the
