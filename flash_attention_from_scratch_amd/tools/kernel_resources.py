@@ -15,17 +15,18 @@ import sys
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "csrc")
 SLICES = [("fa_inst.hip", 15, 1), ("fa_inst.hip", 15, 2), ("fa_inst.hip", 5, 1), ("fa_inst.hip", 5, 2),
           ("fa_inst16.hip", 15, 0), ("fa_inst16.hip", 5, 0)]
-FIELDS = {"VGPRs": "vgprs", "AGPRs": "agprs", "SGPRs": "sgprs", "ScratchSize [bytes/lane]": "scratch_bytes",
+FIELDS = {"VGPRs": "vgprs", "AGPRs": "agprs", "TotalSGPRs": "sgprs", "ScratchSize [bytes/lane]": "scratch_bytes",
           "Occupancy [waves/SIMD]": "occupancy", "VGPRs Spill": "vgpr_spill", "SGPRs Spill": "sgpr_spill"}
 
 
 def demangle_variant(name):
     """_ZN2fa13fa_fwd_kernelILi15ELi1ELi8ELi64ELb1ELb1ELb0ELb1ELi0EEE... -> dict"""
     nums = re.findall(r"L[ib](\d+)E", name)
-    if "fa_fwd_kernel64" in name and len(nums) >= 2:  # <DT, MASK, ABL, RAG>; serves both optimized_softmax values
+    if "fa_fwd_kernel64" in name and len(nums) >= 2:  # <DT, MASK, ABL, RAG, SPEC>
         dt, masked = map(int, nums[:2])
         rag = int(nums[3]) if len(nums) >= 4 else 0  # masked: 2 = causal form, 3 = ragged form of the same entry
-        return dict(dtype=dt, rows_per_wave=64, n_waves=4, B_c=64, swizzled=1, eager=1, opt_softmax=0,
+        spec = int(nums[4]) if len(nums) >= 5 else 0  # the speculative softmax = optimized_softmax
+        return dict(dtype=dt, rows_per_wave=64, n_waves=4, B_c=64, swizzled=1, eager=1, opt_softmax=spec,
                     pipelined=1, dma=1, masked=2 * masked + rag, d_head=128)
     if "fa_fwd_kernel16" in name and len(nums) >= 6:
         dt, nw, bc, swz, eager, opt = map(int, nums[:6])
@@ -33,7 +34,8 @@ def demangle_variant(name):
                     opt_softmax=opt, pipelined=0, dma=1, masked=0, d_head=128)
     if len(nums) >= 11:
         dt, qt, nw, bc, swz, eager, opt, pipe, dma, masked, d_head = map(int, nums[:11])
-        return dict(dtype=dt, rows_per_wave=32 * qt, n_waves=nw, B_c=bc, swizzled=swz, eager=eager,
+        ksplit = int(nums[12]) if len(nums) >= 13 else 1  # <..., ABL, KSPLIT>: KSPLIT waves share a 32-row group (B_r = rows * waves)
+        return dict(dtype=dt, rows_per_wave=32 * qt // ksplit, n_waves=nw, B_c=bc, swizzled=swz, eager=eager,
                     opt_softmax=opt, pipelined=pipe, dma=dma, masked=masked, d_head=d_head)
     return {}
 
@@ -82,7 +84,7 @@ def main(argv=None):
     rows = collect()
     cols = ["dtype", "d_head", "B_r", "B_c", "n_waves", "rows_per_wave", "pipelined", "dma", "masked", "opt_softmax",
             "swizzled", "eager",
-            "vgprs", "agprs", "sgprs", "scratch_bytes", "vgpr_spill", "occupancy", "lds_bytes"]
+            "vgprs", "agprs", "sgprs", "sgpr_spill", "scratch_bytes", "vgpr_spill", "occupancy", "lds_bytes"]
     out = open(args.csv, "w", newline="") if args.csv else sys.stdout
     w = csv.writer(out)
     w.writerow(cols)

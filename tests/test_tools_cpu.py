@@ -48,6 +48,10 @@ def test_symbol_and_mangled_name_round_trip_to_config():
     cfg64 = rocprof_bench.symbol_to_config("void fa::fa_fwd_kernel64<15, false, 0>(fa::KernelArgs)")
     assert cfg64 == kc.FlashForwardKernelConfig(kc.DType.BF16, 128, 256, 64, 4, True, True, True, 0, 0, 0, True, False)
     assert kernel_resources.demangle_variant("_ZN2fa15fa_fwd_kernel64ILi5ELb1ELi0EEEvNS_10KernelArgsE")["masked"] == 2
+    spec64 = kernel_resources.demangle_variant("_ZN2fa15fa_fwd_kernel64ILi15ELb1ELi0ELb1ELb1EEEvNS_10KernelArgsE")
+    assert (spec64["masked"], spec64["opt_softmax"], spec64["rows_per_wave"]) == (3, 1, 64)
+    ks = kernel_resources.demangle_variant("_ZN2fa13fa_fwd_kernelILi5ELi1ELi4ELi64ELb1ELb1ELb1ELb1ELb1ELb0ELi128ELi0ELi2EEEvNS_10KernelArgsE")
+    assert (ks["rows_per_wave"], ks["n_waves"], ks["opt_softmax"]) == (16, 4, 1)   # key split: B_r = 64
     assert rocprof_bench.symbol_to_config("void at::native::foo<float>()") is None
     v = kernel_resources.demangle_variant("_ZN2fa13fa_fwd_kernelILi15ELi1ELi8ELi64ELb1ELb1ELb0ELb1ELb0ELb0ELi128ELi0EEEvNS_10KernelArgsE")
     assert v == dict(dtype=15, rows_per_wave=32, n_waves=8, B_c=64, swizzled=1, eager=1, opt_softmax=0, pipelined=1, dma=0,
@@ -57,7 +61,9 @@ def test_symbol_and_mangled_name_round_trip_to_config():
 def test_resource_remark_parser():
     text = "\n".join([
         "./fa_fwd_kernel.hpp:150:1: remark: Function Name: _ZN2fa13fa_fwd_kernelILi15ELi1ELi8ELi64ELb1ELb1ELb0ELb1ELb1ELb0ELi128ELi0EEEvNS_10KernelArgsE [-Rpass-analysis=kernel-resource-usage]",
+        "./fa_fwd_kernel.hpp:150:1: remark:     TotalSGPRs: 58 [-Rpass-analysis=kernel-resource-usage]",
         "./fa_fwd_kernel.hpp:150:1: remark:     VGPRs: 246 [-Rpass-analysis=kernel-resource-usage]",
+        "./fa_fwd_kernel.hpp:150:1: remark:     SGPRs Spill: 7 [-Rpass-analysis=kernel-resource-usage]",
         "./fa_fwd_kernel.hpp:150:1: remark:     AGPRs: 0 [-Rpass-analysis=kernel-resource-usage]",
         "./fa_fwd_kernel.hpp:150:1: remark:     ScratchSize [bytes/lane]: 0 [-Rpass-analysis=kernel-resource-usage]",
         "./fa_fwd_kernel.hpp:150:1: remark:     Occupancy [waves/SIMD]: 2 [-Rpass-analysis=kernel-resource-usage]",
@@ -66,6 +72,7 @@ def test_resource_remark_parser():
     (row,) = kernel_resources.parse_remarks(text)
     assert row["vgprs"] == 246 and row["agprs"] == 0 and row["scratch_bytes"] == 0 and row["occupancy"] == 2
     assert row["vgpr_spill"] == 0 and row["n_waves"] == 8
+    assert row["sgprs"] == 58 and row["sgpr_spill"] == 7
 
 
 def test_rocprof_csv_parsers(tmp_path):
