@@ -536,7 +536,7 @@ fa_fwd_kernel64(const KernelArgs args) {
                 }
                 const uint16_t *rows0 = Qh + ((int64_t)qblk * TR::kBr + wave * TR::kRowsPerWave + 32 * qt) * ss;
 #pragma unroll
-                for (int i = 0; i < 8; ++i) glds16_sv_m0(rows0 + (int64_t)(4 * i) * ss, off ^ (64u * (i & 3)), stage + i * 1024);
+                for (int i = 0; i < 8; ++i) glds16_sv_m0(rows0, (off ^ (64u * (i & 3))) + (unsigned)(4 * i) * (unsigned)ss * 2u, stage + i * 1024);
             };
             auto read_q = [&](vec8 (&dst)[KS], unsigned stage) {  // this lane's chunks: row l % 32, chunk (2 ks + l/32) ^ (row & 15)
                 const int l_ = lane_now();
@@ -988,7 +988,7 @@ fa_fwd_kernel64(const KernelArgs args) {
                         }
                         __builtin_amdgcn_sched_barrier(0);  // one d tile at a time: S(0) of the next item is live
                     }
-                    // rows RPP i + rsub of the tile: a scalar row base per store, one 32-bit lane offset for all;
+                    // rows RPP i + rsub of the tile: one scalar base for the 32 rows, a 32-bit lane offset per store;
                     // all reads first (the waits then count down), and the read address is one XOR per row
                     // group: row = RPP i + rsub, so chunk ^ swz_of(row) = (chunk ^ rsub) ^ (RPP i & 15)
                     static_assert(D == 128 && RPP == 4, "epilogue address split");
@@ -1007,7 +1007,12 @@ fa_fwd_kernel64(const KernelArgs args) {
                         if constexpr (RAG) {  // rows beyond the sequence are not stored
                             if (qb_c * TR::kBr + wave * TR::kRowsPerWave + qt * 32 + RPP * i + rsub >= args.seq_len) continue;
                         }
-                        asm volatile("global_store_dwordx4 %0, %1, %2 nt" ::"v"(lane_off), "v"(v[i]), "s"(rows0 + (int64_t)(RPP * i) * ss));
+                        // (the row group's offset goes into the lane offset, one v_add per store: eight scalar row bases
+                        // instead cost 16 SGPRs that hipcc kept live -- spilled to VGPR lanes -- across the whole item)
+                        // s_nop 1: a store of more than 64 bits reads its data registers for two more cycles, and hipcc --
+                        // which does not see the instruction inside the asm -- may reuse v[i] for the very next vector
+                        // instruction (it did, for the next store's address: tools/isa_lint64.py, finding STDATA)
+                        asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" ::"v"(lane_off + (unsigned)(RPP * i) * (unsigned)ss * 2u), "v"(v[i]), "s"(rows0));
                     }
                 }
             };

@@ -9,6 +9,9 @@ reading them.  This script disassembles nothing: it reads the `-S` output and re
   RAW   an MFMA reads as A / B a VGPR written by a VALU instruction fewer than `--raw` instructions
         earlier (v_cvt_pk -> MFMA needs wait states hipcc does not insert for asm);
   AGPR  compiler-generated v_accvgpr_* inside the main loop (accumulators must stay put);
+  STDATA a vector instruction that writes a data register of a global / flat / buffer store of more than 64 bits
+        within 2 wait states behind it (the store still reads them; hipcc pads this only for its own stores, the
+        epilogue's are asm: seen as garbage rows in O when hipcc reused v[i] for the next store's address);
   M0    an instruction hipcc itself emitted (outside ;;#ASMSTART / ;;#ASMEND) that reads or writes M0 in
         a fa_fwd_kernel64 function: the DMA pieces leave their LDS destination in M0 across statements.
 
@@ -110,6 +113,20 @@ def lint(path, window=3, raw=2, only=None):
                     if regs(p.split()[1]) & rd:
                         findings.append(("RAW", kidx, i, l, p))
                 k += 1
+        # STDATA: wide stores and the two wait states behind them
+        for i, l in enumerate(code):
+            m = re.match(r"(global|flat|scratch)_store_dwordx[34]\s+\S+\s+(\S+)|buffer_store_dwordx[34]\s+(\S+)", l)
+            if not m:
+                continue
+            data = regs(m.group(2) or m.group(3))
+            slots, k = 0, 0
+            while slots < 2 and i + k + 1 < len(code):
+                k += 1
+                n = code[i + k]
+                if n.startswith("v_") and not n.startswith("v_cmp") and not n.startswith("v_readlane") and not n.startswith("v_readfirstlane"):
+                    if regs(n.split()[1]) & data:
+                        findings.append(("STDATA", kidx, i, l, n))
+                slots += 1 + (int(n.split()[1]) if n.startswith("s_nop") else 0)
         # AGPR: a visit is 32 MFMAs into VGPRs (S) followed by 32 into AGPRs (O).  Behind its third MFMA
         # (the rescale of O sits in front of it) no compiler-made accumulator copy may appear: hipcc has
         # been seen hoisting the rescale path's 128 v_accvgpr_read to the end of the PREVIOUS visit,

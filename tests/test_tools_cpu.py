@@ -183,6 +183,25 @@ def test_isa_lint_flags_compiler_uses_of_m0(tmp_path):
     assert isa_lint64.lint(str(other), only="fa_fwd_kernel64") == []
 
 
+def test_isa_lint_flags_writes_into_the_data_of_a_wide_store(tmp_path):
+    """A store of more than 64 bits keeps reading its data registers for two wait states; hipcc pads that for its own
+    stores only -- the epilogue's are asm.  (Seen: the register allocator reused a stored v[i] for the next store's
+    address, one instruction behind the store; rows of O came out as garbage.)"""
+    body = "\n".join(["global_store_dwordx4 v120, v[66:69], s[0:1] nt", "%s", "v_add_u32_e32 v66, 12, v98", "s_endpgm"]) + "\n"
+    for filler, expect in (("", ["STDATA"]), ("s_nop 0", ["STDATA"]), ("s_nop 1", []), ("v_mov_b32_e32 v1, v2\nv_mov_b32_e32 v3, v4", [])):
+        f = tmp_path / "st.s"
+        f.write_text(body % filler)
+        assert [k for k, *_ in isa_lint64.lint(str(f))] == expect, filler
+    other = tmp_path / "other.s"   # a write to another register, a 64-bit store, a compare (writes no VGPR): no finding
+    other.write_text("\n".join(["global_store_dwordx4 v120, v[66:69], s[0:1]", "v_add_u32_e32 v70, 12, v98",
+                                "global_store_dwordx2 v120, v[66:67], s[0:1]", "v_add_u32_e32 v66, 12, v98",
+                                "buffer_store_dwordx4 v[10:13], v1, s[4:7], 0 offen", "v_cmp_lt_f32_e32 vcc, v10, v2", "s_endpgm"]) + "\n")
+    assert isa_lint64.lint(str(other)) == []
+    buf = tmp_path / "buf.s"
+    buf.write_text("buffer_store_dwordx4 v[10:13], v1, s[4:7], 0 offen\nv_mov_b32_e32 v12, 0\ns_endpgm\n")
+    assert [k for k, *_ in isa_lint64.lint(str(buf))] == ["STDATA"]
+
+
 def test_isa_lint_on_the_built_64_row_kernels(tmp_path):
     """Compile the two hand-placed kernels to ISA (as the library build does) and require that no
     instruction near an inline-asm MFMA touches its operand registers: hipcc cannot see these
