@@ -261,9 +261,13 @@ static FA_DEV void glds16_sv(const void *base_wave_uniform, unsigned lane_byte_o
 }
 // Variant that leaves M0 changed (3 instructions instead of 5).  Only for kernels in which hipcc
 // itself never needs M0 (no LDS-DMA builtin, no s_movrel / sendmsg): the 64-row pinned schedule.
+// s_nop 3: five wait states between whatever hipcc put in front and the load -- the scalar base may just have come
+// back from a VGPR lane (v_readlane: hipcc parks scalars there), and a vector-memory instruction must not read an
+// SGPR a vector instruction wrote fewer than 5 wait states earlier; hipcc pads that for its own loads only
+// (tools/isa_lint64.py, finding SGPRVM).  Used at the prologue and the item seams, not in the steady-state visits.
 static FA_DEV void glds16_sv_m0(const void *base_wave_uniform, unsigned lane_byte_off,
                                 unsigned lds_dst_wave_uniform) {
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 3\n\tglobal_load_lds_dwordx4 %0, %1"
                  :
                  : "v"(lane_byte_off), "s"(base_wave_uniform), "s"(lds_dst_wave_uniform)
                  : "memory");

@@ -12,6 +12,9 @@ reading them.  This script disassembles nothing: it reads the `-S` output and re
   STDATA a vector instruction that writes a data register of a global / flat / buffer store of more than 64 bits
         within 2 wait states behind it (the store still reads them; hipcc pads this only for its own stores, the
         epilogue's are asm: seen as garbage rows in O when hipcc reused v[i] for the next store's address);
+  SGPRVM a vector-memory instruction that reads, as its scalar base, an SGPR written by a vector instruction
+        (v_readlane / v_readfirstlane: hipcc's reloads of scalars it parked in VGPR lanes) fewer than 5 wait states
+        earlier -- hipcc pads this for its own memory instructions, not for the DMA pieces and stores in asm;
   M0    an instruction hipcc itself emitted (outside ;;#ASMSTART / ;;#ASMEND) that reads or writes M0 in
         a fa_fwd_kernel64 function: the DMA pieces leave their LDS destination in M0 across statements.
 
@@ -113,6 +116,23 @@ def lint(path, window=3, raw=2, only=None):
                     if regs(p.split()[1]) & rd:
                         findings.append(("RAW", kidx, i, l, p))
                 k += 1
+        # SGPRVM: VALU write of an SGPR -> vector-memory read of it as the scalar base: 5 wait states
+        for i, l in enumerate(code):
+            m = re.match(r"(v_readlane_b32|v_readfirstlane_b32)\s+s(\d+)", l)
+            if not m:
+                continue
+            sreg, slots, k = int(m.group(2)), 0, 0
+            while slots < 5 and i + k + 1 < len(code):
+                k += 1
+                n = code[i + k]
+                w = re.match(r"s_(?!nop|waitcnt|cmp|cbranch|branch|barrier|bitcmp)\w+\s+s(?:(\d+)|\[(\d+):(\d+)\])", n)
+                if w and (int(w.group(1)) == sreg if w.group(1) else int(w.group(2)) <= sreg <= int(w.group(3))):
+                    break  # rewritten by a scalar instruction: the memory instruction reads that result
+                if re.match(r"(global|flat|scratch|buffer)_", n):
+                    if any(int(a) <= sreg <= int(b) for a, b in re.findall(r"s\[(\d+):(\d+)\]", n)):
+                        findings.append(("SGPRVM", kidx, i, n, l))
+                        break
+                slots += 1 + (int(n.split()[1]) if n.startswith("s_nop") else 0)
         # STDATA: wide stores and the two wait states behind them
         for i, l in enumerate(code):
             m = re.match(r"(global|flat|scratch)_store_dwordx[34]\s+\S+\s+(\S+)|buffer_store_dwordx[34]\s+(\S+)", l)

@@ -202,6 +202,22 @@ def test_isa_lint_flags_writes_into_the_data_of_a_wide_store(tmp_path):
     assert [k for k, *_ in isa_lint64.lint(str(buf))] == ["STDATA"]
 
 
+def test_isa_lint_flags_vector_written_sgpr_read_by_a_memory_instruction(tmp_path):
+    """hipcc parks scalars in VGPR lanes and reloads them with v_readlane; a vector-memory instruction may read such
+    an SGPR as its base only 5 wait states later.  hipcc pads its own loads and stores, not the asm DMA pieces."""
+    body = "\n".join(["v_readlane_b32 s7, v238, 44", "%s", "global_load_lds_dwordx4 v6, s[6:7]", "s_endpgm"]) + "\n"
+    cases = (("s_mov_b32 m0, s0\ns_nop 0", ["SGPRVM"]),            # 2 wait states
+             ("s_mov_b32 m0, s0\ns_nop 3", []),                     # 5
+             ("s_add_u32 s6, s6, s10\ns_addc_u32 s7, s7, s11", []))  # rewritten by scalar instructions: their result is read
+    for filler, expect in cases:
+        f = tmp_path / "sg.s"
+        f.write_text(body % filler)
+        assert [k for k, *_ in isa_lint64.lint(str(f))] == expect, filler
+    other = tmp_path / "other.s"   # another register pair: no finding
+    other.write_text("v_readfirstlane_b32 s9, v3\nglobal_store_dwordx2 v1, v[2:3], s[4:5]\ns_endpgm\n")
+    assert isa_lint64.lint(str(other)) == []
+
+
 def test_isa_lint_on_the_built_64_row_kernels(tmp_path):
     """Compile the two hand-placed kernels to ISA (as the library build does) and require that no
     instruction near an inline-asm MFMA touches its operand registers: hipcc cannot see these
