@@ -205,7 +205,7 @@ def test_isa_lint_flags_writes_into_the_data_of_a_wide_store(tmp_path):
 def test_isa_lint_flags_vector_written_sgpr_read_by_a_memory_instruction(tmp_path):
     """hipcc parks scalars in VGPR lanes and reloads them with v_readlane; a vector-memory instruction may read such
     an SGPR as its base only 5 wait states later.  hipcc pads its own loads and stores, not the asm DMA pieces."""
-    body = "\n".join(["v_readlane_b32 s7, v238, 44", "%s", "global_load_lds_dwordx4 v6, s[6:7]", "s_endpgm"]) + "\n"
+    body = "\n".join(["v_readlane_b32 s7, v238, 44", ";;#ASMSTART", "%s", "global_load_lds_dwordx4 v6, s[6:7]", ";;#ASMEND", "s_endpgm"]) + "\n"
     cases = (("s_mov_b32 m0, s0\ns_nop 0", ["SGPRVM"]),            # 2 wait states
              ("s_mov_b32 m0, s0\ns_nop 3", []),                     # 5
              ("s_add_u32 s6, s6, s10\ns_addc_u32 s7, s7, s11", []))  # rewritten by scalar instructions: their result is read
