@@ -9,6 +9,9 @@ reading them.  This script disassembles nothing: it reads the `-S` output and re
   RAW   an MFMA reads as A / B a VGPR written by a VALU instruction fewer than `--raw` instructions
         earlier (v_cvt_pk -> MFMA needs wait states hipcc does not insert for asm);
   AGPR  compiler-generated v_accvgpr_* inside the main loop (accumulators must stay put);
+  MFMAD an instruction that reads or writes a register of an MFMA's result fewer than passes + 3 wait states behind
+        it (11 for the 8-pass 32x32x16, 7 for 16x16x32): the result is not there yet, and nothing interlocks.  An MFMA
+        that accumulates into exactly the same registers (its C operand) is the one legal back-to-back user;
   STDATA a vector instruction that writes a data register of a global / flat / buffer store of more than 64 bits
         within 2 wait states behind it (the store still reads them; hipcc pads this only for its own stores, the
         epilogue's are asm: seen as garbage rows in O when hipcc reused v[i] for the next store's address);
@@ -33,6 +36,16 @@ def regs(tok):
         return set(range(int(m.group(1)), int(m.group(2)) + 1))
     m = re.match(r"v(\d+)$", tok)
     return {int(m.group(1))} if m else set()
+
+
+def regs2(tok):
+    """-> set of ('v' | 'a', index) named by one operand token (v7, v[4:7], a3, a[0:15]); empty for anything else."""
+    tok = tok.strip(",")
+    m = re.match(r"([va])\[(\d+):(\d+)\]$", tok)
+    if m:
+        return {(m.group(1), i) for i in range(int(m.group(2)), int(m.group(3)) + 1)}
+    m = re.match(r"([va])(\d+)$", tok)
+    return {(m.group(1), int(m.group(2)))} if m else set()
 
 
 M0_USERS = re.compile(r"\bm0\b|^s_movrel|^v_movrel|^s_set_gpr_idx")
@@ -116,6 +129,32 @@ def lint(path, window=3, raw=2, only=None):
                     if regs(p.split()[1]) & rd:
                         findings.append(("RAW", kidx, i, l, p))
                 k += 1
+        # MFMAD: MFMA result -> any other use, passes + 3 wait states
+        for i, l in enumerate(code):
+            if not l.startswith("v_mfma"):
+                continue
+            ops = [o.strip(",") for o in l.split()[1:5]]
+            dst = regs2(ops[0])
+            need = 7 if "16x16x32" in l else 11
+            slots, k = 0, 0
+            while slots < need and i + k + 1 < len(code):
+                k += 1
+                n = code[i + k]
+                if n.startswith(("s_branch", "s_endpgm", "s_setpc")):
+                    break  # what follows in the listing is another path
+                toks = [o.strip(",") for o in n.split()[1:]]
+                if n.startswith("v_mfma"):
+                    ab = regs2(toks[1]) | regs2(toks[2])
+                    c = regs2(toks[3]) if len(toks) > 3 else set()
+                    if (ab & dst) or ((c & dst) and c != dst) or ((regs2(toks[0]) & dst) and regs2(toks[0]) != dst):
+                        findings.append(("MFMAD", kidx, i, l, n))
+                elif not n.startswith("s_") and not n.startswith(";"):
+                    used = set()
+                    for t in toks:
+                        used |= regs2(t)
+                    if used & dst:
+                        findings.append(("MFMAD", kidx, i, l, n))
+                slots += 1 + (int(n.split()[1]) if n.startswith("s_nop") else 0)
         # SGPRVM: VALU write of an SGPR -> vector-memory read of it as the scalar base: 5 wait states
         for i, l in enumerate(code):
             m = re.match(r"(v_readlane_b32|v_readfirstlane_b32)\s+s(\d+)", l)
@@ -125,6 +164,8 @@ def lint(path, window=3, raw=2, only=None):
             while slots < 5 and i + k + 1 < len(code):
                 k += 1
                 n = code[i + k]
+                if n.startswith(("s_branch", "s_endpgm", "s_setpc")):
+                    break
                 w = re.match(r"s_(?!nop|waitcnt|cmp|cbranch|branch|barrier|bitcmp)\w+\s+s(?:(\d+)|\[(\d+):(\d+)\])", n)
                 if w and (int(w.group(1)) == sreg if w.group(1) else int(w.group(2)) <= sreg <= int(w.group(3))):
                     break  # rewritten by a scalar instruction: the memory instruction reads that result
@@ -143,6 +184,8 @@ def lint(path, window=3, raw=2, only=None):
             while slots < 2 and i + k + 1 < len(code):
                 k += 1
                 n = code[i + k]
+                if n.startswith(("s_branch", "s_endpgm", "s_setpc")):
+                    break
                 if n.startswith("v_") and not n.startswith("v_cmp") and not n.startswith("v_readlane") and not n.startswith("v_readfirstlane"):
                     if regs(n.split()[1]) & data:
                         findings.append(("STDATA", kidx, i, l, n))

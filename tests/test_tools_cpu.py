@@ -149,7 +149,9 @@ def test_isa_lint_flags_accumulator_copies_inside_a_visit(tmp_path):
     assert [k for k, *_ in isa_lint64.lint(str(close), window=3, raw=3)] == ["RAW"]
     bad = tmp_path / "bad.s"
     bad.write_text("\n".join(visit[:40] + ["v_accvgpr_read_b32 v200, a3"] + visit[40:] + ["s_endpgm"]) + "\n")
-    assert [k for k, *_ in isa_lint64.lint(str(bad), window=3, raw=3)] == ["AGPR"]
+    kinds = [k for k, *_ in isa_lint64.lint(str(bad), window=3, raw=3)]
+    assert [k for k in kinds if k != "MFMAD"] == ["AGPR"]
+    assert "MFMAD" in kinds   # (the copy also reads a3 while the MFMAs in front of it are still producing it)
 
 
 def test_isa_lint_flags_compiler_uses_of_m0(tmp_path):
@@ -200,6 +202,27 @@ def test_isa_lint_flags_writes_into_the_data_of_a_wide_store(tmp_path):
     buf = tmp_path / "buf.s"
     buf.write_text("buffer_store_dwordx4 v[10:13], v1, s[4:7], 0 offen\nv_mov_b32_e32 v12, 0\ns_endpgm\n")
     assert [k for k, *_ in isa_lint64.lint(str(buf))] == ["STDATA"]
+
+
+def test_isa_lint_flags_early_use_of_an_mfma_result(tmp_path):
+    """The result of an 8-pass MFMA exists passes + 3 = 11 wait states behind it (7 for the 4-pass 16x16x32); hipcc
+    sees a one-cycle asm statement.  Accumulating into exactly the same registers is the legal back-to-back use;
+    what stands behind an unconditional branch in the listing is another path."""
+    mf = "v_mfma_f32_32x32x16_bf16 v[0:15], v[100:103], v[104:107], v[0:15]"
+    def kinds(lines):
+        f = tmp_path / "m.s"
+        f.write_text("\n".join(lines + ["s_endpgm"]) + "\n")
+        return [k for k, *_ in isa_lint64.lint(str(f), window=0, raw=0)]
+    assert kinds([mf, "v_exp_f32_e32 v200, v3"]) == ["MFMAD"]                       # read too early
+    assert kinds([mf, "s_nop 7", "s_nop 1", "v_exp_f32_e32 v200, v3"]) == ["MFMAD"]  # 10 wait states
+    assert kinds([mf, "s_nop 7", "s_nop 2", "v_exp_f32_e32 v200, v3"]) == []        # 11
+    assert kinds([mf, mf, mf]) == []                                                # same accumulator, back to back
+    assert kinds([mf, "v_mfma_f32_32x32x16_bf16 v[16:31], v[0:3], v[104:107], v[16:31]"]) == ["MFMAD"]  # as an A operand
+    assert kinds([mf, "v_mov_b32_e32 v5, 0"]) == ["MFMAD"]                          # overwritten before it lands
+    assert kinds([mf, "s_branch .LBB0_3", "v_exp_f32_e32 v200, v3"]) == []
+    m16 = "v_mfma_f32_16x16x32_bf16 a[0:3], v[100:103], v[104:107], a[0:3]"
+    assert kinds([m16, "s_nop 5", "v_accvgpr_read_b32 v9, a2"]) == ["MFMAD"]
+    assert kinds([m16, "s_nop 6", "v_accvgpr_read_b32 v9, a2"]) == []
 
 
 def test_isa_lint_flags_vector_written_sgpr_read_by_a_memory_instruction(tmp_path):
