@@ -12,6 +12,8 @@ reading them.  This script disassembles nothing: it reads the `-S` output and re
   MFMAD an instruction that reads or writes a register of an MFMA's result fewer than passes + 3 wait states behind
         it (11 for the 8-pass 32x32x16, 7 for 16x16x32): the result is not there yet, and nothing interlocks.  An MFMA
         that accumulates into exactly the same registers (its C operand) is the one legal back-to-back user;
+  PERMSW a v_permlane16/32_swap fewer than 2 wait states behind a vector instruction that wrote one of its two
+        registers (hipcc pads this when it knows the producer; the row-max / row-sum producers are asm);
   STDATA a vector instruction that writes a data register of a global / flat / buffer store of more than 64 bits
         within 2 wait states behind it (the store still reads them; hipcc pads this only for its own stores, the
         epilogue's are asm: seen as garbage rows in O when hipcc reused v[i] for the next store's address);
@@ -155,6 +157,21 @@ def lint(path, window=3, raw=2, only=None):
                     if used & dst:
                         findings.append(("MFMAD", kidx, i, l, n))
                 slots += 1 + (int(n.split()[1]) if n.startswith("s_nop") else 0)
+        # PERMSW: VALU result -> v_permlane*_swap of it: 2 wait states
+        for i, l in enumerate(code):
+            m = re.match(r"v_permlane(?:16|32)_swap\S*\s+(\S+)\s+(\S+)", l)
+            if not m:
+                continue
+            rd = regs(m.group(1)) | regs(m.group(2))
+            slots, k = 0, 0
+            while slots < 2 and i - k - 1 >= 0:
+                k += 1
+                p = code[i - k]
+                if p.startswith(("s_branch", "s_endpgm", "s_setpc", "s_cbranch")):
+                    break
+                if p.startswith("v_") and not p.startswith(("v_cmp", "v_readlane", "v_readfirstlane")) and regs(p.split()[1]) & rd:
+                    findings.append(("PERMSW", kidx, i, l, p))
+                slots += 1 + (int(p.split()[1]) if p.startswith("s_nop") else 0)
         # SGPRVM: VALU write of an SGPR -> vector-memory read of it as the scalar base: 5 wait states
         for i, l in enumerate(code):
             m = re.match(r"(v_readlane_b32|v_readfirstlane_b32)\s+s(\d+)", l)

@@ -225,6 +225,17 @@ def test_isa_lint_flags_early_use_of_an_mfma_result(tmp_path):
     assert kinds([m16, "s_nop 6", "v_accvgpr_read_b32 v9, a2"]) == []
 
 
+def test_isa_lint_flags_permlane_swap_right_behind_its_producer(tmp_path):
+    def kinds(lines):
+        f = tmp_path / "p.s"
+        f.write_text("\n".join(lines + ["s_endpgm"]) + "\n")
+        return [k for k, *_ in isa_lint64.lint(str(f), window=0, raw=0)]
+    assert kinds(["v_max_f32 v0, v1, v2", "v_permlane32_swap_b32_e32 v0, v68"]) == ["PERMSW"]
+    assert kinds(["v_max_f32 v0, v1, v2", "v_mov_b32_e32 v68, v0", "v_permlane32_swap_b32_e32 v0, v68"]) == ["PERMSW"]  # the copy is 1 behind
+    assert kinds(["v_max_f32 v0, v1, v2", "v_mov_b32_e32 v68, v0", "s_nop 1", "v_permlane32_swap_b32_e32 v0, v68"]) == []
+    assert kinds(["v_max_f32 v9, v1, v2", "v_permlane16_swap_b32_e32 v0, v68"]) == []
+
+
 def test_isa_lint_flags_vector_written_sgpr_read_by_a_memory_instruction(tmp_path):
     """hipcc parks scalars in VGPR lanes and reloads them with v_readlane; a vector-memory instruction may read such
     an SGPR as its base only 5 wait states later.  hipcc pads its own loads and stores, not the asm DMA pieces."""
