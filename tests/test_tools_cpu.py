@@ -231,7 +231,7 @@ def test_isa_lint_flags_permlane_swap_right_behind_its_producer(tmp_path):
         f.write_text("\n".join(lines + ["s_endpgm"]) + "\n")
         return [k for k, *_ in isa_lint64.lint(str(f), window=0, raw=0)]
     assert kinds(["v_max_f32 v0, v1, v2", "v_permlane32_swap_b32_e32 v0, v68"]) == ["PERMSW"]
-    assert kinds(["v_max_f32 v0, v1, v2", "v_mov_b32_e32 v68, v0", "v_permlane32_swap_b32_e32 v0, v68"]) == ["PERMSW"]  # the copy is 1 behind
+    assert kinds(["v_max_f32 v0, v1, v2", "v_mov_b32_e32 v68, v0", "v_permlane32_swap_b32_e32 v0, v68"]) == ["PERMSW"] * 2  # copy 0, producer 1 behind
     assert kinds(["v_max_f32 v0, v1, v2", "v_mov_b32_e32 v68, v0", "s_nop 1", "v_permlane32_swap_b32_e32 v0, v68"]) == []
     assert kinds(["v_max_f32 v9, v1, v2", "v_permlane16_swap_b32_e32 v0, v68"]) == []
 
