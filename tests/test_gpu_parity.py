@@ -621,6 +621,17 @@ def test_every_variant_is_bit_identical_run_to_run():
             if rep % 2:
                 scratch.zero_()
             assert torch.equal(flash_attention.forward(cfg, q, k, v), first), (str(cfg), rep)
+    for name, dtype in ((kc.DType.BF16, torch.bfloat16), (kc.DType.FP16, torch.float16)):   # the masked and ragged forms
+        for spec in (True, False):
+            cfg = _persistent_cfg(name, spec)
+            for S, causal in ((1024, True), (1000, False), (1000, True)):
+                gen = torch.Generator(device=DEV).manual_seed(4)
+                q, k, v = (torch.randn((3, S, 5, 128), dtype=dtype, device=DEV, generator=gen) for _ in range(3))
+                first = flash_attention.forward_ex(cfg, q, k, v, causal=causal)
+                for rep in range(6):
+                    if rep % 2:
+                        scratch.zero_()
+                    assert torch.equal(flash_attention.forward_ex(cfg, q, k, v, causal=causal), first), (str(cfg), S, causal, rep)
 
 
 # ---- BASELINE.json full sizes: size-independent properties ----------------------
