@@ -2,6 +2,11 @@
 // with -DFA_TRACE; the shipped library carries no trace code).  Stamps: visit top, after the
 // barrier, then every 4 MFMA gaps (ideal: 4 x 32 = 128 cycles apiece), visit end.
 //
+// Builds (csrc/Makefile, target `tools`): -DFA_TRACE=1 (default) stamps every 4 MFMAs of one visit -> lib/trace64;
+// =2 the last 16 gaps of a visit; =3 one stamp per visit + the prologue pieces -> lib/trace64_tl; =4 ONE stamp per item,
+// kept in a VGPR lane and stored at the exit (nothing added to the visits) -> lib/trace64_items; =5 the same plus stamps
+// inside the first seam -> lib/trace64_seam.
+//
 // Caveats (check a trace build with tools/isa_lint64.py before believing it): the stamps change the
 // code hipcc generates.  Modes 1 and 2 have been seen with the rescale path's 128 v_accvgpr_read
 // hoisted behind the P.V MFMAs of two of the four visit variants (lint finding AGPR; those visits' last
