@@ -12,6 +12,8 @@ reading them.  This script disassembles nothing: it reads the `-S` output and re
   MFMAD an instruction that reads or writes a register of an MFMA's result fewer than passes + 3 wait states behind
         it (11 for the 8-pass 32x32x16, 7 for 16x16x32): the result is not there yet, and nothing interlocks.  An MFMA
         that accumulates into exactly the same registers (its C operand) is the one legal back-to-back user;
+  M0GAP an LDS-DMA (global_load_lds / buffer_load ... lds) or other M0 reader issued right behind the scalar write of M0,
+        with no instruction in between (one wait state is required; the pieces' M0 writes sit one gap early by plan);
   PERMSW a v_permlane16/32_swap fewer than 2 wait states behind a vector instruction that wrote one of its two
         registers (hipcc pads this when it knows the producer; the row-max / row-sum producers are asm);
   STDATA a vector instruction that writes a data register of a global / flat / buffer store of more than 64 bits
@@ -157,6 +159,12 @@ def lint(path, window=3, raw=2, only=None):
                     if used & dst:
                         findings.append(("MFMAD", kidx, i, l, n))
                 slots += 1 + (int(n.split()[1]) if n.startswith("s_nop") else 0)
+        # M0GAP: s_mov m0 -> LDS-DMA needs one wait state
+        for i, l in enumerate(code[:-1]):
+            if re.match(r"s_(mov|add|or|and|lshl)\w*\s+m0\b", l):
+                n = code[i + 1]
+                if re.match(r"global_load_lds|buffer_load\w+.*\blds\b|ds_gws|s_sendmsg", n):
+                    findings.append(("M0GAP", kidx, i, l, n))
         # PERMSW: VALU result -> v_permlane*_swap of it: 2 wait states
         for i, l in enumerate(code):
             m = re.match(r"v_permlane(?:16|32)_swap\S*\s+(\S+)\s+(\S+)", l)

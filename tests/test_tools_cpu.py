@@ -236,6 +236,14 @@ def test_isa_lint_flags_permlane_swap_right_behind_its_producer(tmp_path):
     assert kinds(["v_max_f32 v9, v1, v2", "v_permlane16_swap_b32_e32 v0, v68"]) == []
 
 
+def test_isa_lint_flags_dma_right_behind_its_m0_write(tmp_path):
+    f = tmp_path / "m0.s"
+    f.write_text(";;#ASMSTART\ns_mov_b32 m0, s4\nglobal_load_lds_dwordx4 v7, s[0:1]\n;;#ASMEND\ns_endpgm\n")
+    assert [k for k, *_ in isa_lint64.lint(str(f), window=0, raw=0)] == ["M0GAP"]
+    f.write_text(";;#ASMSTART\ns_mov_b32 m0, s4\ns_nop 0\nglobal_load_lds_dwordx4 v7, s[0:1]\n;;#ASMEND\ns_endpgm\n")
+    assert isa_lint64.lint(str(f), window=0, raw=0) == []
+
+
 def test_isa_lint_flags_vector_written_sgpr_read_by_a_memory_instruction(tmp_path):
     """hipcc parks scalars in VGPR lanes and reloads them with v_readlane; a vector-memory instruction may read such
     an SGPR as its base only 5 wait states later.  hipcc pads its own loads and stores, not the asm DMA pieces."""
