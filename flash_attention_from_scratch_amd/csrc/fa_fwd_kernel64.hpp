@@ -229,6 +229,21 @@ fa_fwd_kernel64(const KernelArgs args) {
             qb_out = bid % nq;
         }
     };
+    // causal: an item costs ~(qb + 1), and along the walk a workgroup would meet the same Q-block
+    // position of a head again and again (round r: slot w + G r of the XCD's item list).  So
+    // odd rounds run their G-slot window of a head (or their whole heads, if a head is shorter than
+    // the window) in reverse: still every Q block of every head exactly once, and two consecutive
+    // rounds sum to the same work for every workgroup.  Needs windows and rounds to line up
+    // (Q blocks per head and workgroups per XCD both powers of two, as a rule); otherwise the walk
+    // stays in order -- correct, just less balanced.  EVERY item's Q block goes through this, also the first of a
+    // walk: the second pass of the speculative softmax may start at an odd round.
+    auto walk_qb = [&](int it_, int pos) {
+        const int G = (args.n_bh & 7) == 0 ? (int)gridDim.x >> 3 : (int)gridDim.x;
+        const int W = nq < G ? nq : G;
+        if (W <= 0 || G % W != 0 || nq % W != 0) return pos;
+        const int in_w = pos % W;
+        return (pos / W) * W + (((it_ / (int)gridDim.x) & 1) ? W - 1 - in_w : in_w);
+    };
     const int64_t ss = args.seq_stride;
 
     // ---- per-lane DMA source offsets (elements), invariant over tiles ------------
@@ -299,6 +314,7 @@ fa_fwd_kernel64(const KernelArgs args) {
         if (ord < 0) return failed;  // (second pass only: nothing of this workgroup's failed)
         int bh, qb;
         item_coords((int)blockIdx.x + ord * (int)gridDim.x, bh, qb);
+        if (MASK && args.causal) qb = walk_qb((int)blockIdx.x + ord * (int)gridDim.x, qb);
         const int b = bh / args.n_heads, h = bh % args.n_heads;
         const int64_t head_off = (int64_t)b * args.batch_stride + (int64_t)h * args.head_stride;
         const uint16_t *Qg = (const uint16_t *)args.q + head_off;
@@ -840,20 +856,6 @@ fa_fwd_kernel64(const KernelArgs args) {
 #endif
             };
             // ---- first item: prologue -------------------------------------------------------------
-            // causal: an item costs ~(qb + 1), and along the walk a workgroup would meet the same Q-block
-            // position of a head again and again (round r: slot w + G r of the XCD's item list).  So
-            // odd rounds run their G-slot window of a head (or their whole heads, if a head is shorter than
-            // the window) in reverse: still every Q block of every head exactly once, and two consecutive
-            // rounds sum to the same work for every workgroup.  Needs windows and rounds to line up
-            // (Q blocks per head and workgroups per XCD both powers of two, as a rule); otherwise the walk
-            // stays in order -- correct, just less balanced.
-            auto walk_qb = [&](int it_, int pos) {
-                const int G = (args.n_bh & 7) == 0 ? (int)gridDim.x >> 3 : (int)gridDim.x;
-                const int W = nq < G ? nq : G;
-                if (W <= 0 || G % W != 0 || nq % W != 0) return pos;
-                const int in_w = pos % W;
-                return (pos / W) * W + (((it_ / (int)gridDim.x) & 1) ? W - 1 - in_w : in_w);
-            };
             auto set_next = [&]() {  // coordinates of the item after `item` (or `item` again)
                 ord_n = next_ord(ord);
                 has_next = ord_n >= 0;

@@ -472,6 +472,44 @@ def test_speculative_softmax_causal_second_pass():
             assert torch.equal(flash_attention.forward_ex(spec, q, k, v, causal=True), out)
 
 
+def test_speculative_softmax_causal_second_pass_starting_at_an_odd_round():
+    """More items than workgroups, causal: odd rounds of the walk run their window of Q blocks in reverse, and the
+    second pass starts at whatever round the first failed item sits in.  (tools/soak.py found the first item of a
+    walk taking its Q block un-reversed: the second pass then redid the mirror block and left the failed one as the
+    first pass had stored it -- inf / NaN rows.)  Failed items in odd and even rounds, every (batch, head) checked."""
+    for dtype, name in ((torch.bfloat16, kc.DType.BF16), (torch.float16, kc.DType.FP16)):
+        spec, safe = _persistent_cfg(name, True), _persistent_cfg(name, False)
+        B, H, S = 4, 16, 4096                       # 1024 items on 256 workgroups: rounds 0 .. 3
+        gen = torch.Generator(device=DEV).manual_seed(9)
+        q, k, v = (torch.randn((B, S, H, 128), dtype=dtype, device=DEV, generator=gen) for _ in range(3))
+        u = _sign_vector(2).to(dtype)
+        for b_, h_, key, row in ((1, 3, 3088, 3500), (0, 0, 5, 300), (2, 9, 1000, 1469), (3, 15, 2047, 4095), (1, 12, 700, 2100)):
+            k[b_, key, h_] = 30.0 * u
+            q[b_, row, h_] = 30.0 * u
+        out = flash_attention.forward_ex(spec, q, k, v, causal=True)
+        assert torch.isfinite(out.float()).all(), str(dtype)
+        out_safe = flash_attention.forward_ex(safe, q, k, v, causal=True)
+        ulp = TOL[dtype]
+        for b_ in range(B):
+            qf, kf, vf = (t[b_].float().permute(1, 0, 2) for t in (q, k, v))          # fp32 masked attention on the device
+            sc = (qf @ kf.transpose(-1, -2)) / 128 ** 0.5
+            sc = sc.masked_fill(torch.ones(S, S, dtype=torch.bool, device=DEV).triu(1), float("-inf"))
+            ref = (torch.softmax(sc, dim=-1) @ vf).permute(1, 0, 2)
+            for o_ in (out, out_safe):
+                assert ((o_[b_].float() - ref).abs() <= ulp * (1 + ref.abs())).all(), (str(dtype), b_)
+        assert torch.equal(flash_attention.forward_ex(spec, q, k, v, causal=True), out)
+
+
+def test_soak_of_the_persistent_kernel_short():
+    """tools/soak.py for a few seconds with a fixed seed: random shapes, dtypes, causal / ragged / plain, speculative or
+    not, spikes, a second stream disturbing memory; every launch checked against fp32 attention and repeated."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "soak.py"), "12", "7"], cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 @pytest.mark.parametrize("S", [1000, 2500])
 def test_speculative_softmax_ragged_second_pass(S):
     """The ragged form under optimized_softmax: the rounded-up tiles beyond the sequence are masked whole,
