@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Soak of the persistent kernel: random (batch, heads, seq_len, causal, dtype, speculative) launches for a time budget,
 each checked against fp32 attention computed by torch on the same device, launched twice (bits must repeat) and, every
-few launches, with another stream hammering the memory system.  Usage: python tools/soak.py [seconds] [seed]"""
+few launches, with another stream hammering the memory system.  Usage: python tools/soak.py [seconds] [seed] [all]   (all: every device variant of the library, plain launches)"""
 import random
 import sys
 import time
@@ -30,22 +30,29 @@ def main():
     side = torch.cuda.Stream()
     noise = torch.empty(512 << 20, dtype=torch.int8, device=DEV)
     t0, n, bad = time.time(), 0, 0
+    every = len(sys.argv) > 3 and sys.argv[3] == "all"   # every device variant of the library instead of the persistent kernel
+    pool = kc.get_all_supported_configs() + kc.get_d64_kernel_configs() if every else []
     while time.time() - t0 < budget:
         dtype, name = rng.choice(((torch.bfloat16, kc.DType.BF16), (torch.float16, kc.DType.FP16)))
         spec = rng.random() < 0.7
         cfg = kc.FlashForwardKernelConfig(name, 128, 256, 64, 4, True, True, True, 0, 0, 0, True, spec)
-        masked = rng.random() < 0.5
+        if every:
+            cfg = rng.choice(pool)
+            dtype, spec = cfg.dtype.to_torch_dtype(), cfg.optimized_softmax
+        masked = (not every) and rng.random() < 0.5
         S = rng.choice([64, 100, 200, 256, 300, 500, 512, 768, 1000, 1024, 1500, 2048, 3000, 4096]) if masked else 256 * rng.randint(1, 20)
+        if every:
+            S = max(cfg.B_r, cfg.B_c) * rng.randint(1, 24)
         causal = masked and rng.random() < 0.6
         B, H = rng.randint(1, 6), rng.choice([1, 2, 3, 5, 8, 16, 24])
         while B * H * S * S > 3e9:
             B = max(1, B - 1)
             H = max(1, H // 2)
         gen = torch.Generator(device=DEV).manual_seed(rng.randrange(1 << 30))
-        q, k, v = (torch.randn((B, S, H, 128), dtype=dtype, device=DEV, generator=gen) for _ in range(3))
+        q, k, v = (torch.randn((B, S, H, cfg.d_head), dtype=dtype, device=DEV, generator=gen) for _ in range(3))
         if rng.random() < 0.3:   # a spike: the speculative first pass fails somewhere
             b_, h_, key = rng.randrange(B), rng.randrange(H), rng.randrange(S)
-            u = (torch.randint(0, 2, (128,), device=DEV, generator=gen).float() * 2 - 1).to(dtype)
+            u = (torch.randint(0, 2, (cfg.d_head,), device=DEV, generator=gen).float() * 2 - 1).to(dtype)
             a = rng.choice([1.2, 3.0, 30.0])
             k[b_, key, h_] = a * u
             q[b_, rng.randrange(S), h_] = a * u
@@ -60,7 +67,7 @@ def main():
         n += 1
         if not ok:
             bad += 1
-            print("FAIL", str(dtype), "spec" if spec else "lazy", "masked" if masked else "plain", "causal" if causal else "", B, H, S,
+            print("FAIL", cfg.short_form() if every else "", str(dtype), "spec" if spec else "lazy", "masked" if masked else "plain", "causal" if causal else "", B, H, S,
                   "max err", float((out.float() - ref).abs().max()), "repeat", torch.equal(out, again), flush=True)
     torch.cuda.synchronize()
     print(f"soak: {n} launches x 2 in {time.time() - t0:.0f} s, {bad} failures")
