@@ -39,9 +39,9 @@ def main():
         if every:
             cfg = rng.choice(pool)
             dtype, spec = cfg.dtype.to_torch_dtype(), cfg.optimized_softmax
-        masked = (not every) and rng.random() < 0.5
+        masked = rng.random() < 0.5
         S = rng.choice([64, 100, 200, 256, 300, 500, 512, 768, 1000, 1024, 1500, 2048, 3000, 4096]) if masked else 256 * rng.randint(1, 20)
-        if every:
+        if every and not masked:
             S = max(cfg.B_r, cfg.B_c) * rng.randint(1, 24)
         causal = masked and rng.random() < 0.6
         B, H = rng.randint(1, 6), rng.choice([1, 2, 3, 5, 8, 16, 24])
@@ -60,7 +60,12 @@ def main():
             with torch.cuda.stream(side):
                 noise.zero_()
         run = (lambda: flash_attention.forward_ex(cfg, q, k, v, causal=causal)) if masked else (lambda: flash_attention.forward(cfg, q, k, v))
-        out, again = run(), run()
+        try:
+            out, again = run(), run()
+        except RuntimeError as exc:   # (all: this configuration has no masked form in the library)
+            if "no causal / ragged-length variant" not in str(exc):
+                raise
+            continue
         ref = eager(q, k, v, causal)
         ulp = 2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -10
         ok = bool(torch.isfinite(out.float()).all()) and bool(((out.float() - ref).abs() <= ulp * (1 + ref.abs())).all()) and torch.equal(out, again)
