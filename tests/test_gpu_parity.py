@@ -500,6 +500,30 @@ def test_speculative_softmax_causal_second_pass_starting_at_an_odd_round():
         assert torch.equal(flash_attention.forward_ex(spec, q, k, v, causal=True), out)
 
 
+def test_two_streams_launching_at_once():
+    """Launches of different shapes and variants queued on two streams at the same time (the persistent kernel sizes
+    its grid to the whole chip and owns a CU's LDS: workgroups of the other launch simply wait): every result must
+    equal the one computed alone."""
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    jobs = []
+    for i, (cfg, shape) in enumerate(((_persistent_cfg(kc.DType.BF16, True), (4, 2048, 16, 128)),
+                                      (kc.FlashForwardKernelConfig(kc.DType.FP16, 128, 128, 64, 4, True, True, True, 0, 0, 0, True, True), (3, 1024, 8, 128)),
+                                      (_persistent_cfg(kc.DType.FP16, False), (2, 4096, 8, 128)),
+                                      (kc.FlashForwardKernelConfig(kc.DType.BF16, 128, 64, 64, 4, True, True, True, 0, 0, 0, True, True), (5, 512, 7, 128)))):
+        gen = torch.Generator(device=DEV).manual_seed(50 + i)
+        q, k, v = (torch.randn(shape, dtype=cfg.dtype.to_torch_dtype(), device=DEV, generator=gen) for _ in range(3))
+        jobs.append((cfg, q, k, v, flash_attention.forward(cfg, q, k, v)))
+    torch.cuda.synchronize()
+    outs = []
+    for rep in range(20):
+        for j, (cfg, q, k, v, _) in enumerate(jobs):
+            with torch.cuda.stream(s1 if (j + rep) % 2 else s2):
+                outs.append((j, flash_attention.forward(cfg, q, k, v)))
+    torch.cuda.synchronize()
+    for j, o in outs:
+        assert torch.equal(o, jobs[j][4]), j
+
+
 def test_soak_of_the_persistent_kernel_short():
     """tools/soak.py for a few seconds with a fixed seed: random shapes, dtypes, causal / ragged / plain, speculative or
     not, spikes, a second stream disturbing memory; every launch checked against fp32 attention and repeated."""
