@@ -177,11 +177,12 @@ def test_isa_lint_flags_compiler_uses_of_m0(tmp_path):
     for offender in ("\ts_mov_b32 m0, s9", "\ts_set_gpr_idx_on s3, gpr_idx(SRC0)", "\tv_movrels_b32_e32 v1, v2"):
         bad = tmp_path / "bad.s"
         bad.write_text(body % offender)
-        assert [k for k, *_ in isa_lint64.lint(str(bad), only="fa_fwd_kernel64")] == ["M0"], offender
+        kinds = [k for k, *_ in isa_lint64.lint(str(bad), only="fa_fwd_kernel64")]
+        assert kinds[:1] == ["M0"] and set(kinds) <= {"M0", "M0GAP"}, offender   # (a write right in front of the DMA is also M0GAP)
     # another function of the same file is not held to the rule, and `only` skips it altogether
     other = tmp_path / "other.s"
     other.write_text(body.replace("15fa_fwd_kernel64", "13fa_fwd_kernel") % "\ts_mov_b32 m0, s9")
-    assert isa_lint64.lint(str(other)) == []
+    assert [k for k, *_ in isa_lint64.lint(str(other))] == ["M0GAP"]   # (the missing wait state is a finding in any function)
     assert isa_lint64.lint(str(other), only="fa_fwd_kernel64") == []
 
 
