@@ -24,7 +24,9 @@ EXPORTED_SYMBOLS = (
     "fa_init", "fa_fwd_supported", "fa_fwd_lds_bytes", "fa_fwd_launch",
     "fa_fwd_launch_timed", "fa_num_kernels", "fa_get_kernel", "fa_last_error", "fa_version",
     "fa_fwd_masked_supported", "fa_fwd_launch_masked", "fa_device_state",
+    "fa_fwd_ex_supported", "fa_fwd_launch_ex", "fa_fwd_query",
 )
+SOFTMAX_MODES = ("eager", "first_block_skip", "lazy", "speculative")  # fa_softmax_mode
 
 
 class FaFwdConfig(ctypes.Structure):
@@ -48,7 +50,35 @@ class FaKernelInfo(ctypes.Structure):
         ("cfg", FaFwdConfig), ("threads", ctypes.c_int32), ("lds_bytes", ctypes.c_int32),
         ("num_regs", ctypes.c_int32), ("scratch_bytes", ctypes.c_int32),
         ("rows_per_wave", ctypes.c_int32), ("masked", ctypes.c_int32),
+        ("softmax_mode", ctypes.c_int32), ("prescaled_q", ctypes.c_int32),
     ]
+
+
+class FaFwdStats(ctypes.Structure):
+    """fa_fwd_stats: two uint32 counters in DEVICE memory the kernel adds to."""
+
+    _fields_ = [("items", ctypes.c_uint32), ("items_redone", ctypes.c_uint32)]
+
+
+class FaFwdOpts(ctypes.Structure):
+    """fa_fwd_opts: the extensions of fa_fwd_launch_ex (zero = the reference's launch)."""
+
+    _fields_ = [
+        ("struct_size", ctypes.c_uint32), ("causal", ctypes.c_int32), ("allow_ragged", ctypes.c_int32),
+        ("speculative", ctypes.c_int32), ("prescaled_q", ctypes.c_int32),
+        ("ms", ctypes.POINTER(ctypes.c_float)), ("stats", ctypes.c_void_p),
+    ]
+
+
+def make_opts(causal=False, allow_ragged=False, speculative=False, prescaled_q=False, ms=None, stats_ptr=None):
+    o = FaFwdOpts()
+    o.struct_size = ctypes.sizeof(FaFwdOpts)
+    o.causal, o.allow_ragged = int(bool(causal)), int(bool(allow_ragged))
+    o.speculative, o.prescaled_q = int(bool(speculative)), int(bool(prescaled_q))
+    if ms is not None:
+        o.ms = ctypes.pointer(ms)
+    o.stats = stats_ptr
+    return o
 
 
 class FaError(RuntimeError):
@@ -92,6 +122,12 @@ def load():
     lib.fa_fwd_masked_supported.argtypes = [cfg_p]
     lib.fa_fwd_launch_masked.restype = ctypes.c_int
     lib.fa_fwd_launch_masked.argtypes = [args_p, ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_float)]
+    lib.fa_fwd_ex_supported.restype = ctypes.c_int
+    lib.fa_fwd_ex_supported.argtypes = [cfg_p, ctypes.POINTER(FaFwdOpts)]
+    lib.fa_fwd_query.restype = ctypes.c_int
+    lib.fa_fwd_query.argtypes = [cfg_p, ctypes.POINTER(FaFwdOpts), ctypes.POINTER(FaKernelInfo)]
+    lib.fa_fwd_launch_ex.restype = ctypes.c_int
+    lib.fa_fwd_launch_ex.argtypes = [args_p, ctypes.POINTER(FaFwdOpts), ctypes.c_void_p]
     lib.fa_num_kernels.restype = ctypes.c_int
     lib.fa_num_kernels.argtypes = []
     lib.fa_get_kernel.restype = ctypes.c_int
@@ -131,6 +167,23 @@ def supported(kernel_cfg) -> bool:
 def masked_supported(kernel_cfg) -> bool:
     cfg = make_config(kernel_cfg)
     return bool(load().fa_fwd_masked_supported(ctypes.byref(cfg)))
+
+
+def ex_supported(kernel_cfg, **opts) -> bool:
+    """fa_fwd_ex_supported: is there a device variant for the config with these fa_fwd_opts
+    (causal, allow_ragged, speculative, prescaled_q)?"""
+    cfg = make_config(kernel_cfg)
+    o = make_opts(**opts)
+    return bool(load().fa_fwd_ex_supported(ctypes.byref(cfg), ctypes.byref(o)))
+
+
+def query(kernel_cfg, **opts) -> FaKernelInfo:
+    """fa_fwd_query: the device variant that serves the config with these fa_fwd_opts (raises FaError if none)."""
+    cfg = make_config(kernel_cfg)
+    o = make_opts(**opts)
+    info = FaKernelInfo()
+    check(load().fa_fwd_query(ctypes.byref(cfg), ctypes.byref(o), ctypes.byref(info)))
+    return info
 
 
 def lds_bytes(kernel_cfg) -> int:

@@ -11,6 +11,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <atomic>
 #include <mutex>
 #include <vector>
 
@@ -58,7 +59,16 @@ bool valid_load_tiles(int v) { return v == 0 || v == 2 || v == 4 || v == 8; }
 // buffer) are validated with the reference's rules
 // (static_kernel_configuration.cuh:13-35) and then ignored: on CDNA4 the
 // compiler schedules LDS->MFMA operand reads and all hint values share one variant.
-const fa::KernelEntry *find_kernel(const fa_fwd_config *c, const char **why, bool masked = false) {
+// cfg.optimized_softmax keeps the reference's meaning (the first KV block skips the rescale): it selects the
+// variant built that way where one exists (softmax_mode 1) and is ignored where the schedule has no first-block
+// rescale to skip (the result is the same either way).  The speculative softmax and the pre-scaled Q are this
+// library's extensions and are asked for explicitly (fa_fwd_opts).
+struct Want {
+    bool masked = false;
+    bool speculative = false;
+    bool prescaled_q = false;
+};
+const fa::KernelEntry *find_kernel(const fa_fwd_config *c, const char **why, const Want &w = Want()) {
     static const char *kNotFound = "Kernel configuration was not found in the libfa_hip.so registry";
     *why = kNotFound;
     if (c->d_head != 128 && c->d_head != 64) { *why = "Only d_head = 128 (and 64) is supported"; return nullptr; }
@@ -71,18 +81,29 @@ const fa::KernelEntry *find_kernel(const fa_fwd_config *c, const char **why, boo
     const int rows_per_wave = c->B_r / c->n_warps;
     // mma_double_buffer_loads selects the software-pipelined loop where one is built;
     // otherwise it is a hint like the load_K_tiles fields and the plain loop is used.
-    const fa::KernelEntry *plain = nullptr;
+    // Preference among the variants of one shape: the pipelined flag as asked, then the softmax mode --
+    // speculative if (and only if) asked for; else the first-block-skip build for optimized_softmax where it
+    // exists; else the eager / lazy build.
+    const fa::KernelEntry *best = nullptr;
+    int best_score = -1;
     for (const auto &e : registry()) {
-        if (e.d_head == c->d_head && e.dtype == c->dtype && e.rows_per_wave == rows_per_wave &&
-            e.n_waves == c->n_warps &&
-            e.B_c == c->B_c && e.swizzled == (c->swizzled != 0) &&
-            e.eager == (c->eager_load_blocks != 0) && e.opt_softmax == (c->optimized_softmax != 0) &&
-            e.async_copy == (c->async_copy != 0) && (e.masked != 0) == masked) {
-            if (e.pipelined == (c->mma_double_buffer_loads != 0)) return &e;
-            if (!e.pipelined) plain = &e;
-        }
+        if (!(e.d_head == c->d_head && e.dtype == c->dtype && e.rows_per_wave == rows_per_wave &&
+              e.n_waves == c->n_warps && e.B_c == c->B_c && e.swizzled == (c->swizzled != 0) &&
+              e.eager == (c->eager_load_blocks != 0) && e.async_copy == (c->async_copy != 0) &&
+              (e.masked != 0) == w.masked && (e.prescaled_q != 0) == w.prescaled_q))
+            continue;
+        if ((e.softmax_mode == FA_SOFTMAX_SPECULATIVE) != w.speculative) continue;
+        const bool pipe_match = e.pipelined == (c->mma_double_buffer_loads != 0);
+        if (!pipe_match && e.pipelined) continue;  // the plain loop stands in for a pipelined one that is not built, never the reverse
+        const bool fbs = e.softmax_mode == FA_SOFTMAX_FIRST_BLOCK_SKIP;
+        if (fbs && !c->optimized_softmax) continue;
+        const int score = (pipe_match ? 2 : 0) + (fbs ? 1 : 0);
+        if (score > best_score) { best = &e; best_score = score; }
     }
-    return plain;
+    if (!best && (w.speculative || w.prescaled_q))
+        *why = "Kernel configuration has no device variant with the requested options (speculative softmax / pre-scaled Q) "
+               "in the libfa_hip.so registry";
+    return best;
 }
 
 // One-time setup PER DEVICE (the reference's device guard + module init, src/flash_attention.cu:42,142-149):
@@ -95,13 +116,12 @@ struct DeviceState {
     int status = FA_OK;
     char err[256] = "";
     int num_cus = 256;  // persistent variants launch one workgroup per CU
-    int inited = 0;
+    std::atomic<int> inited{0};  // published LAST (release): a reader that sees 1 sees the final status and num_cus
 };
 constexpr int kMaxDevices = 64;
 DeviceState g_dev[kMaxDevices];
 
-void do_init(int dev, DeviceState *st) {
-    st->inited = 1;
+void do_init_body(int dev, DeviceState *st) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, dev) != hipSuccess) {
         st->status = FA_ERR_DEVICE;
@@ -135,6 +155,11 @@ void do_init(int dev, DeviceState *st) {
     }
 }
 
+void do_init(int dev, DeviceState *st) {
+    do_init_body(dev, st);
+    st->inited.store(1, std::memory_order_release);
+}
+
 // State of the CURRENT device, initialised on first use; nullptr (and the thread's error set) if there is none.
 DeviceState *current_device(int *status) {
     int dev = 0;
@@ -153,12 +178,13 @@ DeviceState *current_device(int *status) {
     return st->status == FA_OK ? st : nullptr;
 }
 
-int validate(const fa_fwd_args *a, const fa::KernelEntry **out, bool masked = false) {
+int validate(const fa_fwd_args *a, const fa::KernelEntry **out, const Want &want = Want()) {
+    const bool masked = want.masked;
     if (!a || !a->q || !a->k || !a->v || !a->o) return fail(FA_ERR_NULL, "null pointer argument");
     if (a->cfg.dtype != FA_FP16 && a->cfg.dtype != FA_BF16)
         return fail(FA_ERR_DTYPE, "Only fp16 and bf16 are supported");
     const char *why = "";
-    const fa::KernelEntry *e = find_kernel(&a->cfg, &why, masked);
+    const fa::KernelEntry *e = find_kernel(&a->cfg, &why, want);
     if (!e)
         return fail(FA_ERR_NO_KERNEL, "%s%s", why,
                     masked ? " (no causal / ragged-length variant is built for this configuration)" : "");
@@ -201,8 +227,10 @@ int validate(const fa_fwd_args *a, const fa::KernelEntry **out, bool masked = fa
     return FA_OK;
 }
 
-int launch(const fa_fwd_args *a, const fa::KernelEntry *e, const DeviceState *dev, hipStream_t stream, int causal = 0) {
+int launch(const fa_fwd_args *a, const fa::KernelEntry *e, const DeviceState *dev, hipStream_t stream, int causal = 0,
+           fa_fwd_stats *stats = nullptr) {
     fa::KernelArgs ka;
+    ka.stats = (uint32_t *)stats;
     ka.q = a->q;
     ka.k = a->k;
     ka.v = a->v;
@@ -251,9 +279,10 @@ int fa_init(void) {
 int fa_device_state(int device, int *inited, int *status, int *num_cus) {
     if (device < 0 || device >= kMaxDevices) return fail(FA_ERR_DEVICE, "device ordinal %d out of range", device);
     const DeviceState &st = g_dev[device];
-    if (inited) *inited = st.inited;
-    if (status) *status = st.status;
-    if (num_cus) *num_cus = st.num_cus;
+    const int done = st.inited.load(std::memory_order_acquire);  // 0: nothing below is final yet
+    if (inited) *inited = done;
+    if (status) *status = done ? st.status : FA_OK;
+    if (num_cus) *num_cus = done ? st.num_cus : 0;
     return FA_OK;
 }
 
@@ -274,15 +303,15 @@ int fa_fwd_lds_bytes(const fa_fwd_config *cfg) {
 // Enqueue (ms == nullptr) or enqueue between two events on the stream and wait for the second one
 // (flash_attention.cu:119-132).  Whatever was created is destroyed on every path.
 static int launch_maybe_timed(const fa_fwd_args *args, const fa::KernelEntry *e, const DeviceState *dev,
-                              hipStream_t s, int causal, float *ms) {
-    if (!ms) return launch(args, e, dev, s, causal);
+                              hipStream_t s, int causal, float *ms, fa_fwd_stats *stats = nullptr) {
+    if (!ms) return launch(args, e, dev, s, causal, stats);
     hipEvent_t start = nullptr, stop = nullptr;
     hipError_t hrc = hipEventCreate(&start);
     if (hrc == hipSuccess) hrc = hipEventCreate(&stop);
     if (hrc == hipSuccess) hrc = hipEventRecord(start, s);
     int rc = FA_OK;
     if (hrc == hipSuccess) {
-        rc = launch(args, e, dev, s, causal);
+        rc = launch(args, e, dev, s, causal, stats);
         hrc = hipEventRecord(stop, s);  // (recorded even if the launch failed: nothing is left pending)
         if (hrc == hipSuccess) hrc = hipEventSynchronize(stop);
     }
@@ -318,24 +347,90 @@ int fa_fwd_launch_timed(const fa_fwd_args *args, void *stream, float *ms) {
 int fa_fwd_masked_supported(const fa_fwd_config *cfg) {
     if (!cfg) return 0;
     const char *why;
-    return find_kernel(cfg, &why, true) != nullptr;
+    Want w;
+    w.masked = true;
+    return find_kernel(cfg, &why, w) != nullptr;
 }
 
 int fa_fwd_launch_masked(const fa_fwd_args *args, int causal, void *stream, float *ms) {
-    const fa::KernelEntry *e = nullptr;
-    int rc = validate(args, &e, true);
+    fa_fwd_opts o;
+    memset(&o, 0, sizeof(o));
+    o.struct_size = (uint32_t)sizeof(o);
+    o.causal = causal;
+    o.allow_ragged = 1;
+    o.ms = ms;
+    return fa_fwd_launch_ex(args, &o, stream);
+}
+
+// fa_fwd_opts as this library understands it: a caller built against an older (shorter) header passes a
+// smaller struct_size and gets zeros for the fields it does not know.
+static int read_opts(const fa_fwd_opts *in, fa_fwd_opts *o) {
+    memset(o, 0, sizeof(*o));
+    if (!in) return FA_OK;
+    if (in->struct_size < sizeof(uint32_t) || in->struct_size > 4096)
+        return fail(FA_ERR_SHAPE, "fa_fwd_opts.struct_size (%u) is not set: zero the struct and set it to sizeof(fa_fwd_opts)",
+                    in->struct_size);
+    memcpy(o, in, in->struct_size < sizeof(*o) ? in->struct_size : sizeof(*o));
+    return FA_OK;
+}
+
+int fa_fwd_ex_supported(const fa_fwd_config *cfg, const fa_fwd_opts *opts) {
+    if (!cfg) return 0;
+    fa_fwd_opts o;
+    if (read_opts(opts, &o) != FA_OK) return 0;
+    const char *why;
+    Want w;
+    w.masked = o.causal || o.allow_ragged;
+    w.speculative = o.speculative != 0;
+    w.prescaled_q = o.prescaled_q != 0;
+    return find_kernel(cfg, &why, w) != nullptr;
+}
+
+int fa_fwd_launch_ex(const fa_fwd_args *args, const fa_fwd_opts *opts, void *stream) {
+    fa_fwd_opts o;
+    int rc = read_opts(opts, &o);
     if (rc != FA_OK) return rc;
+    Want w;
+    w.masked = o.causal || o.allow_ragged;
+    w.speculative = o.speculative != 0;
+    w.prescaled_q = o.prescaled_q != 0;
+    const fa::KernelEntry *e = nullptr;
+    rc = validate(args, &e, w);
+    if (rc != FA_OK) return rc;
+    if (o.stats && ((uintptr_t)o.stats & 3)) return fail(FA_ERR_ALIGN, "fa_fwd_opts.stats must be 4-byte aligned");
     const DeviceState *dev = current_device(&rc);
     if (!dev) return rc;
-    return launch_maybe_timed(args, e, dev, (hipStream_t)stream, causal != 0, ms);
+    return launch_maybe_timed(args, e, dev, (hipStream_t)stream, o.causal != 0, o.ms, o.stats);
 }
 
 int fa_num_kernels(void) { return (int)registry().size(); }
 
+static void fill_info(const fa::KernelEntry &e, fa_kernel_info *out);
+
+int fa_fwd_query(const fa_fwd_config *cfg, const fa_fwd_opts *opts, fa_kernel_info *out) {
+    if (!cfg || !out) return fail(FA_ERR_NULL, "null pointer argument");
+    fa_fwd_opts o;
+    int rc = read_opts(opts, &o);
+    if (rc != FA_OK) return rc;
+    Want w;
+    w.masked = o.causal || o.allow_ragged;
+    w.speculative = o.speculative != 0;
+    w.prescaled_q = o.prescaled_q != 0;
+    const char *why = "";
+    const fa::KernelEntry *e = find_kernel(cfg, &why, w);
+    if (!e) return fail(FA_ERR_NO_KERNEL, "%s", why);
+    fill_info(*e, out);
+    return FA_OK;
+}
+
 int fa_get_kernel(int index, fa_kernel_info *out) {
     if (!out) return fail(FA_ERR_NULL, "null output");
     if (index < 0 || index >= (int)registry().size()) return fail(FA_ERR_SHAPE, "index out of range");
-    const fa::KernelEntry &e = registry()[index];
+    fill_info(registry()[index], out);
+    return FA_OK;
+}
+
+static void fill_info(const fa::KernelEntry &e, fa_kernel_info *out) {
     memset(out, 0, sizeof(*out));
     out->cfg.dtype = e.dtype;
     out->cfg.d_head = e.d_head;
@@ -345,8 +440,10 @@ int fa_get_kernel(int index, fa_kernel_info *out) {
     out->cfg.async_copy = e.async_copy;
     out->cfg.eager_load_blocks = e.eager;
     out->cfg.swizzled = e.swizzled;
-    out->cfg.optimized_softmax = e.opt_softmax;
+    out->cfg.optimized_softmax = e.softmax_mode == FA_SOFTMAX_FIRST_BLOCK_SKIP;  // (the reference's meaning only)
     out->cfg.mma_double_buffer_loads = e.pipelined;
+    out->softmax_mode = e.softmax_mode;
+    out->prescaled_q = e.prescaled_q;
     out->threads = e.threads;
     out->lds_bytes = e.lds_bytes;
     out->rows_per_wave = e.rows_per_wave;
@@ -360,11 +457,10 @@ int fa_get_kernel(int index, fa_kernel_info *out) {
     } else {
         (void)hipGetLastError();  // no device: resource fields stay -1
     }
-    return FA_OK;
 }
 
 const char *fa_last_error(void) { return g_err; }
 
-const char *fa_version(void) { return "fa_hip 0.2 gfx950"; }
+const char *fa_version(void) { return "fa_hip 0.3 gfx950"; }
 
 }  // extern "C"

@@ -77,6 +77,7 @@ struct KernelArgs {
     int32_t n_q_blocks;
     int32_t n_kv_blocks;
     int32_t causal;        // MASK variants only: key j contributes to query i iff j <= i
+    uint32_t *stats = nullptr;  // nullptr, or two device counters the kernel adds to (fa_fwd_stats: items, items_redone)
 #ifdef FA_TRACE
     unsigned long long *trace;  // tools/segment_timer.hip only: [wave][visit][8] s_memtime stamps
     int32_t trace_block;
@@ -1013,6 +1014,10 @@ fa_fwd_kernel(const KernelArgs args) {
     };  // attempt
     bool done = false;
     if constexpr (SPEC) done = attempt(TrueTag{});
+    if (args.stats && threadIdx.x == 0) {  // fa_fwd_stats: one item per workgroup; redone = the speculative pass failed
+        atomicAdd(args.stats, 1u);
+        if (SPEC && !done) atomicAdd(args.stats + 1, 1u);
+    }
     if (!done) {
         if constexpr (SPEC) {  // start over with the running max
             reset_state();

@@ -279,6 +279,10 @@ fa_fwd_kernel16(const KernelArgs args) {
     };
     bool done = false;
     if constexpr (SPEC) done = attempt(TrueTag{});
+    if (args.stats && threadIdx.x == 0) {  // fa_fwd_stats: one item per workgroup; redone = the speculative pass failed
+        atomicAdd(args.stats, 1u);
+        if (SPEC && !done) atomicAdd(args.stats + 1, 1u);
+    }
     if (!done) {
         if constexpr (SPEC) {  // start over with the running max
             reset_state();
@@ -319,7 +323,8 @@ template <int DT, int NWAVES, int BC, bool SWZ, bool EAGER, bool OPT>
 constexpr KernelEntry make_entry16() {
     using TR = FwdTraits16<DT, NWAVES, BC, SWZ, EAGER, OPT>;
     return KernelEntry{DT, 16, NWAVES, BC, SWZ, EAGER, OPT, 0, 1, 0, 128, TR::kThreads, TR::kLdsBytes, 0,
-                       (kernel_fn)&fa_fwd_kernel16<DT, NWAVES, BC, SWZ, EAGER, OPT>, nullptr};
+                       (kernel_fn)&fa_fwd_kernel16<DT, NWAVES, BC, SWZ, EAGER, OPT>, nullptr,
+                       softmax_mode_of(false, OPT, EAGER, true, false), 0};
 }
 
 }  // namespace fa

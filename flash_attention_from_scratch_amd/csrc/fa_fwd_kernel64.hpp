@@ -301,7 +301,7 @@ fa_fwd_kernel64(const KernelArgs args) {
     // (same encoding) of the items whose check failed in any row of this wave.
     auto walk = [&](auto fast_tag, const unsigned long long todo) -> unsigned long long {
         constexpr bool FAST = decltype(fast_tag)::value;
-        unsigned long long failed = 0;
+        unsigned long long failed = 0;  // FAST: the ordinals whose check failed; the second pass: the number of items it computed
         const int n_items = args.n_bh * nq;
         auto next_ord = [&](int o) {  // next ordinal of this pass behind o, or -1 (scalar; item seams only)
             for (;;) {
@@ -648,12 +648,12 @@ fa_fwd_kernel64(const KernelArgs args) {
                             // multiply: in that variant (and in trace builds) hipcc otherwise hoists the reads out of
                             // this branch to the end of the previous visit, right behind the MFMAs that write the
                             // tiles (tools/isa_lint64.py, finding AGPR); so it does in the second pass of the speculative
-                            // build.  The other variants do not need the pins
-                            // (the lint checks that) and measure 0.3 % faster without them, at 65 more VGPRs.
-                            if constexpr (RAG || SPEC || FA_RING_SLOTS > 4) asm volatile("" : "+a"(O[qt][t]));
+                            // build, and -- since the statistics tail of round 3 -- in the plain lazy build too: pinned
+                            // in every variant (the lint checks the result; 65 fewer VGPRs, 0.3 % on the lazy build).
+                            asm volatile("" : "+a"(O[qt][t]));
 #pragma unroll
                             for (int r = 0; r < 16; ++r) O[qt][t][r] *= alpha;
-                            if constexpr (RAG || SPEC || FA_RING_SLOTS > 4) asm volatile("" : "+a"(O[qt][t]));
+                            asm volatile("" : "+a"(O[qt][t]));
                         }
                     }
                 }
@@ -970,6 +970,9 @@ fa_fwd_kernel64(const KernelArgs args) {
                         constexpr float kLimit = spec_limit<DT>();
                         if (__ballot(!(l_row < kLimit)) != 0) failed |= 1ull << (ord < 63 ? ord : 63);
                     }
+                    if constexpr (SPEC && !FAST) {
+                        if (qt == 0) ++failed;  // (scalar: one more item of the second pass, for fa_fwd_stats)
+                    }
                     const float inv = 1.0f / l_row;
                     char *wp = stage_o + r31 * ROWB + hi * 8;
 #pragma unroll
@@ -1130,12 +1133,22 @@ fa_fwd_kernel64(const KernelArgs args) {
         const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)all);
         const unsigned hi32 = __builtin_amdgcn_readfirstlane((unsigned)(all >> 32));
         all = ((unsigned long long)hi32 << 32) | lo;
+        unsigned redone = 0;
         if (all) {
             barrier();  // (all four slots read before the second pass requests its first Q tile into one of them)
-            walk(BoolTag<false>{}, all);
+            redone = (unsigned)walk(BoolTag<false>{}, all);
+        }
+        if (args.stats && threadIdx.x == 0) {  // fa_fwd_stats: this workgroup's items, and how many of them ran twice
+            const long long n_items = (long long)args.n_bh * args.n_q_blocks;
+            atomicAdd(args.stats, (unsigned)((n_items - (long long)blockIdx.x + (long long)gridDim.x - 1) / (long long)gridDim.x));
+            if (redone) atomicAdd(args.stats + 1, redone);
         }
     } else {
         walk(BoolTag<false>{}, ~0ull);
+        if (args.stats && threadIdx.x == 0) {
+            const long long n_items = (long long)args.n_bh * args.n_q_blocks;
+            atomicAdd(args.stats, (unsigned)((n_items - (long long)blockIdx.x + (long long)gridDim.x - 1) / (long long)gridDim.x));
+        }
     }
 }
 

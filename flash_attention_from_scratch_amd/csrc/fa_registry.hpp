@@ -19,7 +19,7 @@ struct KernelEntry {
     int B_c;
     int swizzled;
     int eager;
-    int opt_softmax;
+    int opt_softmax;    // the variant's OPT template flag: see softmax_mode for what it means there
     int pipelined;      // cfg.mma_double_buffer_loads
     int async_copy;     // 1: LDS-DMA transport, 0: register-staged
     int masked;         // 1: handles ragged seq_len and the causal mask; 2: the same through two device forms (fn, fn_ragged)
@@ -29,7 +29,20 @@ struct KernelEntry {
     int persistent;     // 1: launch one workgroup per CU; the kernel walks the items itself
     kernel_fn fn;
     kernel_fn fn_ragged;  // masked == 2 only: the form for seq_len % B_r != 0 (any seq_len >= 64); else null
+    int softmax_mode;     // fa_softmax_mode (include/fa_hip.h): 0 eager, 1 first block skips the rescale, 2 lazy, 3 speculative
+    int prescaled_q;      // 1: logits from a 16-bit Q * c (fa_fwd_opts.prescaled_q); persistent kernel only
 };
+
+// What the OPT template flag selects in each kernel body (the device-side predicates are SPEC in
+// fa_fwd_kernel.hpp / fa_fwd_kernel16.hpp and the SPEC parameter of fa_fwd_kernel64): the speculative softmax
+// where it is built -- the persistent kernel (every form), the double-buffered LDS-DMA variants of the
+// 32-rows-per-wave kernel without a mask, the double-buffered 16-rows-per-wave variants -- and the
+// reference's first-block skip elsewhere.
+constexpr int softmax_mode_of(bool persistent, bool opt, bool eager, bool dma, bool masked) {
+    if (persistent) return opt ? 3 : 2;
+    if (!opt) return 0;
+    return (eager && dma && !masked) ? 3 : 1;
+}
 
 template <int DT, int QT, int NWAVES, int BC, bool SWZ, bool EAGER, bool OPT, bool PIPE, bool DMA,
           bool MASK = false, int D = 128>
@@ -39,15 +52,18 @@ constexpr KernelEntry make_entry() {
         static_assert(NWAVES == 4 && BC == 64 && SWZ && EAGER && DMA && D == 128, "64-row pinned schedule");
         if constexpr (MASK)
             return KernelEntry{DT, 64, 4, 64, 1, 1, OPT, 1, 1, 2, 128, TR::kThreads, TR::kLdsBytes, 1,
-                               (kernel_fn)&fa_fwd_kernel64<DT, true, 0, false, OPT>,   // causal form (opt_softmax: speculative softmax)
-                               (kernel_fn)&fa_fwd_kernel64<DT, true, 0, true, OPT>};    // ragged form
+                               (kernel_fn)&fa_fwd_kernel64<DT, true, 0, false, OPT>,   // causal form (OPT: speculative softmax)
+                               (kernel_fn)&fa_fwd_kernel64<DT, true, 0, true, OPT>,    // ragged form
+                               softmax_mode_of(true, OPT, true, true, true), 0};
         else
             return KernelEntry{DT, 64, 4, 64, 1, 1, OPT, 1, 1, 0, 128, TR::kThreads, TR::kLdsBytes, 1,
-                               (kernel_fn)&fa_fwd_kernel64<DT, false, 0, false, OPT>, nullptr};  // opt_softmax: speculative softmax
+                               (kernel_fn)&fa_fwd_kernel64<DT, false, 0, false, OPT>, nullptr,  // OPT: speculative softmax
+                               softmax_mode_of(true, OPT, true, true, false), 0};
     } else {
         return KernelEntry{DT, 32 * QT, NWAVES, BC, SWZ, EAGER, OPT, PIPE, DMA, MASK ? 1 : 0, D, TR::kThreads,
                            TR::kLdsBytes, 0,
-                           (kernel_fn)&fa_fwd_kernel<DT, QT, NWAVES, BC, SWZ, EAGER, OPT, PIPE, DMA, MASK, D>, nullptr};
+                           (kernel_fn)&fa_fwd_kernel<DT, QT, NWAVES, BC, SWZ, EAGER, OPT, PIPE, DMA, MASK, D>, nullptr,
+                           softmax_mode_of(false, OPT, EAGER, DMA, MASK), 0};
     }
 }
 
@@ -58,7 +74,8 @@ constexpr KernelEntry make_entry_ks() {
     using TR = FwdTraits<DT, 1, 4, 64, SWZ, EAGER, OPT, PIPE, true, false, 128, 2>;
     static_assert(TR::kBr == 64, "two row groups of 32");
     return KernelEntry{DT, 16, 4, 64, SWZ, EAGER, OPT, PIPE, 1, 0, 128, TR::kThreads, TR::kLdsBytes, 0,
-                       (kernel_fn)&fa_fwd_kernel<DT, 1, 4, 64, SWZ, EAGER, OPT, PIPE, true, false, 128, 0, 2>, nullptr};
+                       (kernel_fn)&fa_fwd_kernel<DT, 1, 4, 64, SWZ, EAGER, OPT, PIPE, true, false, 128, 0, 2>, nullptr,
+                       softmax_mode_of(false, OPT, EAGER, true, false), 0};
 }
 
 struct KernelTable {

@@ -9,9 +9,17 @@ torch's current stream, blocking only when benchmark=True.  PyTorch-ROCm is
 plumbing here (device memory, current stream); the computation is the HIP kernel
 behind fa_fwd_launch.  There is no eager/CPU fallback: a missing library or a
 non-gfx950 device raises.
+
+`kernel_cfg.optimized_softmax` has the reference's meaning only (the first KV block skips the
+rescale; same result with or without).  This build's extensions are asked for explicitly: a
+`flash_helpers.kernel_configs.NativeKernelConfig` (what `best_config()` returns) carries
+`speculative_softmax` / `prescaled_q`, which travel in `fa_fwd_opts` beside the 13-field key.  A plain
+13-field config with `optimized_softmax` selects the speculative softmax only under
+FA_ALLOW_SPECULATIVE=1 (the round-2 mapping, kept for sweeps).
 """
 
 import ctypes
+import os
 
 import torch
 
@@ -26,10 +34,20 @@ def _check_input(t, name):
         raise RuntimeError(f"{name} must be contiguous")
 
 
-def forward(kernel_cfg, q, k, v, o=None, benchmark=False, causal=False, allow_ragged=False):
-    """Reference signature plus two keyword-only-by-convention wideners (default off, so the
+def _native_options(kernel_cfg):
+    spec = bool(getattr(kernel_cfg, "speculative_softmax", False))
+    if not spec and getattr(kernel_cfg, "optimized_softmax", False) and os.environ.get("FA_ALLOW_SPECULATIVE", "") == "1":
+        spec = None  # "if the config has a speculative variant": resolved against the registry below
+    return spec, bool(getattr(kernel_cfg, "prescaled_q", False))
+
+
+def forward(kernel_cfg, q, k, v, o=None, benchmark=False, causal=False, allow_ragged=False, stats=None):
+    """Reference signature plus keyword-only-by-convention wideners (default off, so the
     reference behaviour -- including its errors for seq_len not a multiple of the tiles -- is
-    unchanged): `causal` applies a causal mask, `allow_ragged` accepts any seq_len."""
+    unchanged): `causal` applies a causal mask, `allow_ragged` accepts any seq_len, `stats` is an
+    int32 / uint32 device tensor of >= 2 elements whose [0] the kernel increases by the number of work
+    items it computed and whose [1] by the number the speculative softmax had to compute twice
+    (fa_fwd_stats)."""
     masked = bool(causal or allow_ragged)
     _check_input(q, "q")
     _check_input(k, "k")
@@ -49,6 +67,15 @@ def forward(kernel_cfg, q, k, v, o=None, benchmark=False, causal=False, allow_ra
         raise RuntimeError("Kernel configuration was not found in flash_kernels (libfa_hip.so registry)")
     if masked and not lib.fa_fwd_masked_supported(ctypes.byref(cfg)):
         raise RuntimeError("Kernel configuration has no causal / ragged-length variant in libfa_hip.so")
+    speculative, prescaled_q = _native_options(kernel_cfg)
+    if speculative is None:  # FA_ALLOW_SPECULATIVE=1: where the variant exists
+        probe = _capi.make_opts(causal=causal, allow_ragged=allow_ragged, speculative=True, prescaled_q=prescaled_q)
+        speculative = bool(lib.fa_fwd_ex_supported(ctypes.byref(cfg), ctypes.byref(probe)))
+    if speculative or prescaled_q:
+        probe = _capi.make_opts(causal=causal, allow_ragged=allow_ragged, speculative=speculative, prescaled_q=prescaled_q)
+        if not lib.fa_fwd_ex_supported(ctypes.byref(cfg), ctypes.byref(probe)):
+            raise RuntimeError("Kernel configuration has no device variant with the requested native options "
+                               f"(speculative_softmax={speculative}, prescaled_q={prescaled_q}, masked={masked}) in libfa_hip.so")
     cfg_dtype = kernel_cfg.dtype.to_torch_dtype() if hasattr(kernel_cfg.dtype, "to_torch_dtype") else None
     if cfg_dtype is None:
         cfg_dtype = {5: torch.float16, 15: torch.bfloat16}[int(kernel_cfg.dtype)]
@@ -80,12 +107,19 @@ def forward(kernel_cfg, q, k, v, o=None, benchmark=False, causal=False, allow_ra
         batch_stride=q.stride(0), seq_stride=q.stride(1), head_stride=q.stride(2),
         cfg=cfg,
     )
+    stats_ptr = None
+    if stats is not None:
+        if not stats.is_cuda or stats.device != q.device or stats.dtype not in (torch.int32, torch.uint32) \
+                or stats.numel() < 2 or not stats.is_contiguous():
+            raise RuntimeError("stats must be a contiguous int32 / uint32 tensor of >= 2 elements on q's device")
+        stats_ptr = stats.data_ptr()
     with torch.cuda.device(q.device):
         stream = ctypes.c_void_p(torch.cuda.current_stream(q.device).cuda_stream)
-        if masked:
+        if masked or speculative or prescaled_q or stats_ptr is not None:
             ms = ctypes.c_float(0.0)
-            _capi.check(lib.fa_fwd_launch_masked(ctypes.byref(args), int(bool(causal)), stream,
-                                                 ctypes.byref(ms) if benchmark else None))
+            opts = _capi.make_opts(causal=causal, allow_ragged=allow_ragged, speculative=speculative,
+                                   prescaled_q=prescaled_q, ms=ms if benchmark else None, stats_ptr=stats_ptr)
+            _capi.check(lib.fa_fwd_launch_ex(ctypes.byref(args), ctypes.byref(opts), stream))
             return o, float(ms.value)
         if benchmark:
             ms = ctypes.c_float(0.0)

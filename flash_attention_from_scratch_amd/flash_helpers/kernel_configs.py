@@ -14,7 +14,15 @@ fields *select* on CDNA4 is documented in DESIGN.md ("config -> device variant")
 * ``*_mma_load_K_tiles`` / ``mma_double_buffer_loads``  operand-fetch schedule
   hints; validated exactly like the reference, but the CDNA4 compiler schedules
   LDS->MFMA operand reads itself, so they map onto the same device code.
-* ``optimized_softmax``  first K/V block skips the rescale of (l, O).
+* ``optimized_softmax``  first K/V block skips the rescale of (l, O) -- the reference's meaning and
+  nothing else.  The result is the same with or without it, so device variants whose schedule
+  has no first-block rescale to skip ignore it (``softmax_mode(cfg)`` says what a config runs).
+
+Extensions of this build live OUTSIDE the 13 fields, in ``NativeKernelConfig`` (a subclass):
+``speculative_softmax`` and ``prescaled_q``; ``best_config()``
+returns one.  A plain 13-field config never selects them (unless FA_ALLOW_SPECULATIVE=1 is set
+in the environment, which maps ``optimized_softmax`` to the speculative softmax where it is built
+-- the round-2 behaviour, kept for sweeps).
 """
 
 import itertools
@@ -108,6 +116,11 @@ _TAIL_WORDS = (
     ("mma_double_buffer_loads", "buffer"),
     ("optimized_softmax", "opt_softmax"),
 )
+# extensions of this build (NativeKernelConfig), spelled behind the reference's words
+_NATIVE_WORDS = (
+    ("speculative_softmax", "spec_softmax"),
+    ("prescaled_q", "prescaled_q"),
+)
 
 
 @dataclass(frozen=True, order=True)
@@ -139,6 +152,7 @@ class FlashForwardKernelConfig:
             % (self.Q_mma_load_K_tiles, self.K_mma_load_K_tiles, self.V_mma_load_K_tiles)
         )
         words += [word for attr, word in _TAIL_WORDS if getattr(self, attr)]
+        words += [word for attr, word in _NATIVE_WORDS if getattr(self, attr, False)]
         features = "+".join(words)
         if not include_tup:
             return features
@@ -159,12 +173,12 @@ class FlashForwardKernelConfig:
             return str(int(value))
 
         return "FlashForwardKernelConfig{%s}" % ", ".join(
-            lit(getattr(self, f.name)) for f in fields(self)
+            lit(getattr(self, f.name)) for f in fields(FlashForwardKernelConfig)
         )
 
     def to_c_abi_tuple(self):
         """The 13 ints of ``fa_fwd_config`` (include/fa_hip.h), in field order."""
-        return tuple(int(getattr(self, f.name)) for f in fields(self))
+        return tuple(int(getattr(self, f.name)) for f in fields(FlashForwardKernelConfig))
 
     def kernel_name(self) -> str:
         return "flash_forward_kernel"
@@ -182,6 +196,40 @@ class FlashForwardKernelConfig:
 
     def mfma_flop(self, n_samples: int, n_heads: int, seq_len: int) -> int:
         return calc_mfma_flop(n_samples, n_heads, seq_len, self.d_head)
+
+
+@dataclass(frozen=True, order=True)
+class NativeKernelConfig(FlashForwardKernelConfig):
+    """The 13-field key plus this build's extensions, which the reference has no field for and which
+    therefore travel beside ``fa_fwd_config`` in ``fa_fwd_opts`` (include/fa_hip.h):
+
+    * ``speculative_softmax``  the item's first visited tile gives the reference max for all its tiles
+      (no per-tile row max, no rescale); the row sums are checked at the end and a failed item is
+      computed again with the running max.  Same real result; the cost of a failed
+      item is 2x (``fa_fwd_stats.items_redone`` counts them).
+    * ``prescaled_q``  logits from a 16-bit ``Q * log2(e)/sqrt(d)`` instead of an fp32 multiply per
+      logit: not the reference's arithmetic, inside its tolerance rule.
+    """
+
+    speculative_softmax: bool = False
+    prescaled_q: bool = False
+
+    def base(self) -> FlashForwardKernelConfig:
+        """The plain 13-field config (what a reference user would pass)."""
+        return FlashForwardKernelConfig(*(getattr(self, f.name) for f in fields(FlashForwardKernelConfig)))
+
+
+def as_native(cfg, speculative_softmax=None, prescaled_q=None) -> NativeKernelConfig:
+    """`cfg` (plain or native) as a NativeKernelConfig with the given extensions (None = keep / off)."""
+    base = [getattr(cfg, f.name) for f in fields(FlashForwardKernelConfig)]
+    spec = getattr(cfg, "speculative_softmax", False) if speculative_softmax is None else speculative_softmax
+    psq = getattr(cfg, "prescaled_q", False) if prescaled_q is None else prescaled_q
+    return NativeKernelConfig(*base, speculative_softmax=bool(spec), prescaled_q=bool(psq))
+
+
+def config_sort_key(cfg):
+    """Total order over plain and native configs (dataclass ordering refuses mixed classes)."""
+    return cfg.to_c_abi_tuple() + (bool(getattr(cfg, "speculative_softmax", False)), bool(getattr(cfg, "prescaled_q", False)))
 
 
 # ---------------------------------------------------------------------------
@@ -254,7 +302,11 @@ def _parse_short_form_flash_forward_kernel_config(line: str) -> FlashForwardKern
         raise ValueError(f"Cannot find load segment in features: {found.group(2)}")
     q_t, k_t, v_t = (int(x) for x in loads[0][len("load_"):-len("_tiles")].split("_"))
     flags = {attr: (word in words) for attr, word in _FLAG_WORDS + _TAIL_WORDS}
-    return FlashForwardKernelConfig(
+    native = {attr: (word in words) for attr, word in _NATIVE_WORDS}
+    cls = NativeKernelConfig if any(native.values()) else FlashForwardKernelConfig
+    if cls is NativeKernelConfig:
+        flags.update(native)
+    return cls(
         dtype=DType.from_string(dims[0]),
         d_head=int(dims[1]),
         B_r=int(dims[2]),
@@ -396,12 +448,14 @@ def get_native_kernel_configs(dtypes=(DType.BF16, DType.FP16)):
                 for pipelined in (False, True):
                     if pipelined and not dma and n_waves == 4:
                         continue  # 4 landing registers per tile kind: the pipelined loop would spill
-                    for opt in (False, True):
-                        out.append(
-                            FlashForwardKernelConfig(
-                                dtype, 128, B_r, B_c, n_waves, dma, True, True, 0, 0, 0, pipelined, opt
-                            )
-                        )
+                    for second in (False, True):
+                        # LDS-DMA shapes: with / without the speculative softmax (a native extension);
+                        # register-staged shapes: with / without the reference's first-block skip
+                        base = (dtype, 128, B_r, B_c, n_waves, dma, True, True, 0, 0, 0, pipelined)
+                        if dma and second:
+                            out.append(NativeKernelConfig(*base, False, speculative_softmax=True))
+                        else:
+                            out.append(FlashForwardKernelConfig(*base, second))
     return out
 
 
@@ -413,18 +467,26 @@ def get_d64_kernel_configs(dtypes=(DType.BF16, DType.FP16)):
         for B_r, B_c, n_waves, pipes in ((128, 64, 4, (False, True)), (256, 64, 8, (False, True)),
                                          (256, 128, 8, (False,))):
             for pipelined in pipes:
-                for opt in (False, True):
-                    out.append(
-                        FlashForwardKernelConfig(
-                            dtype, 64, B_r, B_c, n_waves, True, True, True, 0, 0, 0, pipelined, opt
-                        )
-                    )
+                base = (dtype, 64, B_r, B_c, n_waves, True, True, True, 0, 0, 0, pipelined, False)
+                out.append(FlashForwardKernelConfig(*base))
+                out.append(NativeKernelConfig(*base, speculative_softmax=True))
     return out
+
+
+def get_speculative_reference_shape_configs(dtypes=(DType.BF16, DType.FP16)):
+    """The speculative softmax on the REFERENCE's tile shapes ((64,32), (64,64), (128,32), (128,64), 4 waves):
+    native configs (`speculative_softmax`), one per device variant -- with and without the pipelined loop."""
+    out = set()
+    for cfg in get_autotuning_kernel_configs(dtypes):
+        if cfg.optimized_softmax and has_speculative_variant(cfg):
+            out.add(as_native(replace(cfg, optimized_softmax=False, Q_mma_load_K_tiles=0, K_mma_load_K_tiles=0,
+                                      V_mma_load_K_tiles=0), speculative_softmax=True))
+    return sorted(out, key=config_sort_key)
 
 
 def get_kernels_to_build():
     """The drop-in list: exactly the reference's built set (:458-463)."""
-    return sorted(set(get_autotuning_kernel_configs()))
+    return sorted(set(get_autotuning_kernel_configs()), key=config_sort_key)
 
 
 def get_all_supported_configs():
@@ -433,7 +495,8 @@ def get_all_supported_configs():
     cfgs.update(get_native_kernel_configs())
     cfgs.update(get_d64_kernel_configs())
     cfgs.update(get_kernel_progression_configs())
-    return sorted(cfgs)
+    cfgs.update(get_speculative_reference_shape_configs())
+    return sorted(cfgs, key=config_sort_key)
 
 
 def get_kernel_configs(kernels_key=""):
@@ -459,22 +522,62 @@ def get_kernel_configs(kernels_key=""):
     raise ValueError(f"Invalid kernels env key: {kernels_key}")
 
 
+def is_persistent_shape(cfg) -> bool:
+    """The config served by the persistent 64-rows-per-wave kernel."""
+    return (cfg.d_head, cfg.B_r, cfg.B_c, cfg.n_warps, bool(cfg.mma_double_buffer_loads)) == (128, 256, 64, 4, True) \
+        and bool(cfg.async_copy and cfg.eager_load_blocks and cfg.swizzled)
+
+
 def uses_lazy_rescale(cfg) -> bool:
     """True for the config served by the 64-rows-per-wave device schedule, whose softmax moves
     its reference max lazily (CPU restatement: oracle blockwise_forward_lazy)."""
     return (cfg.d_head, cfg.B_r, cfg.B_c, cfg.n_warps, bool(cfg.mma_double_buffer_loads)) == (128, 256, 64, 4, True)
 
 
-def uses_speculative_softmax(cfg) -> bool:
-    """True where ``optimized_softmax`` selects the speculative softmax: an item is
-    first run against the row max of its first K/V tile only (no per-tile row max, no rescale), its row
-    sums are checked against an overflow limit at the end, and an item that fails is run again with the
-    running max -- by the lazy-rescale schedule on the persistent 64-rows-per-wave kernel, by the same
-    workgroup starting over on the other kernels (every double-buffered LDS-DMA variant).  CPU
-    restatement: blockwise_forward_lazy with an infinite threshold.  On the single-stage progression
-    steps and the register-staged variants the flag keeps the reference's meaning: the first K/V block
-    skips the rescale."""
-    return bool(cfg.optimized_softmax and cfg.eager_load_blocks and cfg.async_copy)
+def has_speculative_variant(cfg, masked=False) -> bool:
+    """Mirror of the device-side predicates (fa_registry.hpp softmax_mode_of): the speculative softmax is
+    built on the persistent kernel (plain, causal and ragged forms) and on every double-buffered LDS-DMA
+    variant of the other kernels WITHOUT a mask (their masked forms keep the running max)."""
+    if is_persistent_shape(cfg):
+        return True
+    return bool(cfg.eager_load_blocks and cfg.async_copy and not masked)
+
+
+def wants_speculative(cfg) -> bool:
+    """Does this config ASK for the speculative softmax?  Only a NativeKernelConfig can
+    (``speculative_softmax``); a plain 13-field config asks for the reference's arithmetic -- unless
+    FA_ALLOW_SPECULATIVE=1 maps its ``optimized_softmax`` to it (round 2's behaviour, for sweeps)."""
+    if getattr(cfg, "speculative_softmax", False):
+        return True
+    return bool(cfg.optimized_softmax) and os.environ.get("FA_ALLOW_SPECULATIVE", "") == "1"
+
+
+def softmax_mode(cfg, masked=False) -> str:
+    """What the device variant behind ``cfg`` does to keep exp2 in range -- the Python mirror of
+    ``fa_kernel_info.softmax_mode`` (include/fa_hip.h): 'eager' (the reference, softmax.cuh:85-105),
+    'first_block_skip' (the reference's optimized_softmax), 'lazy' (persistent kernel: the reference max
+    moves only when a row max rose by more than 8 binades), 'speculative' (DESIGN.md 3.6)."""
+    if wants_speculative(cfg) and has_speculative_variant(cfg, masked):
+        return "speculative"
+    if is_persistent_shape(cfg):
+        return "lazy"
+    if cfg.optimized_softmax and not has_speculative_variant(cfg, masked):
+        return "first_block_skip"  # (where OPT builds the speculative schedule there is no first-block variant: ignored)
+    return "eager"
+
+
+SOFTMAX_MODES = ("eager", "first_block_skip", "lazy", "speculative")  # index = fa_softmax_mode
+
+
+def uses_speculative_softmax(cfg, masked=False) -> bool:
+    """True where the config runs the speculative softmax: an item is first run against
+    the row max of its first K/V tile only (no per-tile row max, no rescale), its row sums are checked
+    against an overflow limit at the end, and an item that fails is run again with the running max -- by
+    the lazy-rescale schedule on the persistent 64-rows-per-wave kernel, by the same workgroup starting
+    over on the other kernels.  CPU restatement: blockwise_forward_lazy with an infinite threshold.
+    ``masked``: the causal / ragged form of the config (forward_ex) -- only the persistent kernel's
+    masked forms are speculative."""
+    return softmax_mode(cfg, masked) == "speculative"
 
 
 def best_config(dtype=DType.BF16, seq_len=4096, masked=False) -> FlashForwardKernelConfig:
@@ -486,13 +589,20 @@ def best_config(dtype=DType.BF16, seq_len=4096, masked=False) -> FlashForwardKer
     persistent kernel when seq_len is a multiple of 256 (causal form) or when rounding seq_len up to
     one costs at most an eighth more rows (its ragged form works on whole 256-row Q blocks and whole
     rounds of four 64-key tiles; measured ahead of the 32-rows-per-wave kernels from seq_len ~1000 up,
-    profiles/r01/ragged_persistent.txt), otherwise 4 waves x 32 rows."""
+    profiles/r01/ragged_persistent.txt), otherwise 4 waves x 32 rows.
+
+    Softmax: bf16 takes the speculative softmax (a row may rise 32 binades = 22 nats above the max of
+    its last 64 keys before its item is redone); fp16 does NOT by default -- its 16-bit P leaves ~15
+    binades (~10 nats) of headroom, which attention-sink-like logits at the first keys (visited last)
+    exceed, and every such item then costs 2x (profiles/r03/sink_data.txt).  Ask for it explicitly
+    (``replace(cfg, speculative_softmax=True)``) when the logits are known to be flat."""
+    dtype = DType(dtype)
+    spec = dtype == DType.BF16
     pad = (-seq_len) % 256
     if pad == 0 or (masked and seq_len >= 64 and pad * 8 <= seq_len):
-        # optimized_softmax = the speculative softmax (plain, causal and ragged forms)
-        return FlashForwardKernelConfig(
-            DType(dtype), 128, 256, 64, 4, True, True, True, 0, 0, 0, True, True
+        return NativeKernelConfig(
+            dtype, 128, 256, 64, 4, True, True, True, 0, 0, 0, True, False, speculative_softmax=spec
         )
-    return FlashForwardKernelConfig(
-        DType(dtype), 128, 128, 64, 4, True, True, True, 0, 0, 0, True, not masked
+    return NativeKernelConfig(
+        dtype, 128, 128, 64, 4, True, True, True, 0, 0, 0, True, False, speculative_softmax=spec and not masked
     )

@@ -17,6 +17,9 @@
  *   fa_fwd_lds_bytes   <- FlashForwardKernelConfig::smem_bytes(), flash_attention.cuh:54-56
  *   fa_fwd_launch      <- kernel<<<grid, block, smem, stream>>>(args), flash_attention.cu:110-126
  *   fa_fwd_launch_timed<- the benchmark=True event bracket, flash_attention.cu:119-132
+ *   fa_fwd_launch_ex   <- the same launch with this library's NATIVE extensions (no reference counterpart):
+ *                         causal / ragged seq_len, the speculative softmax, the pre-scaled Q, event timing,
+ *                         device-side statistics -- one options struct (fa_fwd_opts)
  *   fa_init            <- PYBIND11_MODULE body (max dynamic smem opt-in), flash_attention.cu:142-149
  *   fa_num_kernels / fa_get_kernel <- iteration over the forward_kernels map,
  *                         src/include/flash_kernels.cuh:14-186
@@ -67,8 +70,26 @@ typedef struct fa_fwd_config {
     int32_t K_mma_load_K_tiles;
     int32_t V_mma_load_K_tiles;
     int32_t mma_double_buffer_loads;
-    int32_t optimized_softmax;       /* first KV block skips the (l, O) rescale */
+    int32_t optimized_softmax;       /* the reference's meaning and nothing else: the first KV block skips the
+                                        (l, O) rescale (softmax.cuh:85-105, forward_kernel.cuh:158-161).  The
+                                        result is identical with or without it (the skipped factor is exp2(-inf)
+                                        = 0 on l = O = 0), so device variants whose schedule has no first-block
+                                        rescale to skip accept the flag and ignore it (fa_kernel_info.softmax_mode
+                                        says what a variant does).  The speculative softmax is NOT selected by
+                                        this field: fa_fwd_opts.speculative */
 } fa_fwd_config;
+
+/* How a device variant keeps exp2 in range (fa_kernel_info.softmax_mode).  All four give the same real
+ * result; the first two are the reference's arithmetic bit for bit, the other two move the rounding
+ * point of P and are checked against the same tolerances. */
+typedef enum fa_softmax_mode {
+    FA_SOFTMAX_EAGER = 0,            /* running row max, (l, O) rescaled at every tile (softmax.cuh:85-105) */
+    FA_SOFTMAX_FIRST_BLOCK_SKIP = 1, /* the same, first KV block skips the rescale (the reference's optimized_softmax) */
+    FA_SOFTMAX_LAZY = 2,             /* running row max, moved only when some row's max rose by > 8 binades */
+    FA_SOFTMAX_SPECULATIVE = 3       /* reference = row max of the item's first visited tile, no per-tile max;
+                                        the row sums are checked at the end and an item that fails is computed
+                                        again with the running max (counted: fa_fwd_stats.items_redone) */
+} fa_softmax_mode;
 
 /*
  * One forward call.  q, k, v, o are DEVICE pointers to (batch, seq_len, n_heads,
@@ -103,7 +124,34 @@ typedef struct fa_kernel_info {
     int32_t rows_per_wave;   /* Q rows owned by one wavefront */
     int32_t masked;          /* 1: the causal / ragged-length variant of cfg; 2: the same for the persistent
                                 (256, 64, 4) kernel, which needs seq_len >= B_c when seq_len % B_r != 0 */
+    int32_t softmax_mode;    /* fa_softmax_mode of this device variant */
+    int32_t prescaled_q;     /* 1: the variant folds the softmax scale into a 16-bit copy of Q (fa_fwd_opts.prescaled_q) */
 } fa_kernel_info;
+
+/* Device-side statistics (optional, fa_fwd_opts.stats): a DEVICE pointer to two 32-bit counters the
+ * kernel ADDS to (zero them yourself).  items = work items (batch*head, Q block) computed;
+ * items_redone = items the speculative softmax had to compute a second time because a row sum
+ * exceeded its limit -- the cost of such an item is 2x.  0 for every other softmax mode. */
+typedef struct fa_fwd_stats {
+    uint32_t items;
+    uint32_t items_redone;
+} fa_fwd_stats;
+
+/* Options of fa_fwd_launch_ex: this library's extensions beyond the reference's launch.  Zero-initialise,
+ * set struct_size = sizeof(fa_fwd_opts), then set what you need. */
+typedef struct fa_fwd_opts {
+    uint32_t struct_size;    /* sizeof(fa_fwd_opts) of the caller's header */
+    int32_t causal;          /* key j contributes to query i iff j <= i (masked variant of cfg) */
+    int32_t allow_ragged;    /* accept seq_len that is not a multiple of B_r / B_c (masked variant of cfg) */
+    int32_t speculative;     /* 1: the speculative-softmax variant of cfg (FA_SOFTMAX_SPECULATIVE).  fp16: P must stay
+                                below 2^15, i.e. a row may rise ~10 nats above the max of its LAST 64 keys (visited
+                                first) before its item is redone; bf16: ~22 nats.  See INTEGRATION.md */
+    int32_t prescaled_q;     /* 1: logits from a 16-bit Q * (log2 e / sqrt d) instead of an fp32 multiply per logit
+                                (perturbs every logit by <= 2^-9 relative (bf16) -- FA-3 / Triton practice, not the
+                                reference's arithmetic; inside the reference's tolerance rule) */
+    float *ms;               /* HOST pointer or NULL: bracket the launch with events, block, return elapsed ms */
+    fa_fwd_stats *stats;     /* DEVICE pointer or NULL */
+} fa_fwd_opts;
 
 /* One-time setup for the CURRENT device (idempotent; also called lazily by every launch): arch check,
  * CU count, the > 48 KB dynamic-LDS opt-in of every kernel function.  State is kept per device ordinal,
@@ -114,7 +162,8 @@ typedef struct fa_kernel_info {
 int fa_init(void);
 
 /* Introspection of that per-device state (tests): has `device` been initialised, with which status,
- * and how many CUs cap the persistent grid there.  Any out pointer may be NULL. */
+ * and how many CUs cap the persistent grid there.  Any out pointer may be NULL.  Safe to call from any
+ * thread at any time: `inited` is published (release) after status and num_cus are final. */
 int fa_device_state(int device, int *inited, int *status, int *num_cus);
 
 /* 1 if a device kernel exists for cfg, else 0 (never negative). */
@@ -139,6 +188,15 @@ int fa_fwd_launch_timed(const fa_fwd_args *args, void *stream, float *ms);
 int fa_fwd_masked_supported(const fa_fwd_config *cfg);
 int fa_fwd_launch_masked(const fa_fwd_args *args, int causal, void *stream, float *ms);
 
+/* The general launch: fa_fwd_launch (opts == NULL or all zero), fa_fwd_launch_timed (opts->ms) and
+ * fa_fwd_launch_masked (opts->causal / allow_ragged) are special cases of it.  fa_fwd_ex_supported: 1 if a
+ * device variant exists for cfg with these options. */
+int fa_fwd_ex_supported(const fa_fwd_config *cfg, const fa_fwd_opts *opts);
+/* Which device variant would serve cfg with these options (opts may be NULL)?  Fills *out like fa_get_kernel
+ * -- softmax_mode says what the variant does with the softmax -- or returns FA_ERR_NO_KERNEL. */
+int fa_fwd_query(const fa_fwd_config *cfg, const fa_fwd_opts *opts, fa_kernel_info *out);
+int fa_fwd_launch_ex(const fa_fwd_args *args, const fa_fwd_opts *opts, void *stream);
+
 /* Registry enumeration: distinct device variants built into this library. */
 int fa_num_kernels(void);
 int fa_get_kernel(int index, fa_kernel_info *out);
@@ -146,7 +204,7 @@ int fa_get_kernel(int index, fa_kernel_info *out);
 /* Message for the last non-zero status on this thread ("" if none). */
 const char *fa_last_error(void);
 
-/* Library version string, e.g. "fa_hip 0.1 gfx950". */
+/* Library version string, e.g. "fa_hip 0.3 gfx950". */
 const char *fa_version(void);
 
 #ifdef __cplusplus

@@ -137,12 +137,13 @@ def blockwise_forward_lazy(q, k, v, B_r, B_c, tau=8.0, n_threads=0):
 SPEC_TAU = 1e30  # "never move the reference max": the speculative schedule's first pass
 
 
-def blockwise_for_config(cfg, q, k, v, n_threads=0):
+def blockwise_for_config(cfg, q, k, v, n_threads=0, masked=False):
     """The CPU restatement of the arithmetic the device variant behind `cfg` performs on inputs that
-    do not trip the speculative schedule's overflow check (those rows are redone with tau = 8)."""
+    do not trip the speculative schedule's overflow check (those rows are redone with tau = 8).
+    `masked`: the config's causal / ragged form (only the persistent kernel's is speculative)."""
     from flash_helpers import kernel_configs as kc
 
-    if kc.uses_speculative_softmax(cfg):
+    if kc.uses_speculative_softmax(cfg, masked):
         return blockwise_forward_lazy(q, k, v, min(cfg.B_r, q.shape[1]), cfg.B_c, tau=SPEC_TAU, n_threads=n_threads)
     if kc.uses_lazy_rescale(cfg):
         return blockwise_forward_lazy(q, k, v, cfg.B_r, cfg.B_c, n_threads=n_threads)

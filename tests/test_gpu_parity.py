@@ -36,7 +36,7 @@ def _unique_variants(cfgs):
     seen, out = set(), []
     for c in cfgs:
         key = (c.dtype, c.d_head, c.B_r, c.B_c, c.n_warps, c.async_copy, c.eager_load_blocks, c.swizzled,
-               c.optimized_softmax, c.mma_double_buffer_loads and ((c.B_r // c.n_warps == 32 and c.B_c <= 64) or (c.B_r // c.n_warps == 64 and c.B_c == 64)))
+               c.optimized_softmax, kc.wants_speculative(c), getattr(c, "prescaled_q", False), c.mma_double_buffer_loads and ((c.B_r // c.n_warps == 32 and c.B_c <= 64) or (c.B_r // c.n_warps == 64 and c.B_c == 64)))
         if key not in seen:
             seen.add(key)
             out.append(c)
@@ -229,7 +229,7 @@ def test_online_softmax_rescale_is_exercised():
     """A key spike in the LAST-visited block (block 0) forces a large rescale of the
     accumulated O and l (guide rule 26): one Q row against one K row."""
     for dtype, cfg in ((torch.bfloat16, kc.best_config(kc.DType.BF16)),
-                       (torch.float16, kc.FlashForwardKernelConfig(kc.DType.FP16, 128, 64, 64, 4, True, True, True, 0, 0, 0, False, True))):
+                       (torch.float16, _native(kc.DType.FP16, 64, 64, 4, False, True))):
         qc = ut.QKVConfig(n_heads=2, d_head=128, batch_size=1, seq_len=1024, dtype=dtype,
                           device=torch.device(DEV))
         q, k, v = ut.generate_qkv(qc, seed=77)
@@ -247,7 +247,7 @@ def test_64_row_variant_against_its_lazy_rescale_restatement():
     arithmetic and against fp32 eager, on data whose row maxima keep rising along the visit order
     (keys near the start of the sequence are visited last)."""
     for dtype, name in ((torch.bfloat16, kc.DType.BF16), (torch.float16, kc.DType.FP16)):
-        cfg = kc.FlashForwardKernelConfig(name, 128, 256, 64, 4, True, True, True, 0, 0, 0, True, False)
+        cfg = _native(name, 256, 64, 4, True, False)
         qc = ut.QKVConfig(n_heads=2, d_head=128, batch_size=1, seq_len=1024, dtype=dtype,
                           device=torch.device(DEV))
         q, k, v = ut.generate_qkv(qc, seed=31)
@@ -308,8 +308,8 @@ def test_persistent_walk_seams(shape):
     B, H, S = shape
     for dtype, name, opt in ((torch.bfloat16, kc.DType.BF16, False), (torch.float16, kc.DType.FP16, False),
                              (torch.bfloat16, kc.DType.BF16, True), (torch.float16, kc.DType.FP16, True)):
-        cfg = kc.FlashForwardKernelConfig(name, 128, 256, 64, 4, True, True, True, 0, 0, 0, True, opt)
-        other = kc.FlashForwardKernelConfig(name, 128, 128, 64, 4, True, True, True, 0, 0, 0, True, False)
+        cfg = _native(name, 256, 64, 4, True, opt)
+        other = _native(name, 128, 64, 4, True, False)
         qc = ut.QKVConfig(n_heads=H, d_head=128, batch_size=B, seq_len=S, dtype=dtype, device=torch.device(DEV))
         q, k, v = ut.generate_qkv(qc, seed=B + S)
         torch.cuda.synchronize()
@@ -322,8 +322,15 @@ def test_persistent_walk_seams(shape):
         assert (runs[0][sl].float() - eager.float()).abs().max().item() <= TOL[dtype]
 
 
+def _native(name, B_r, B_c, n_waves, buffer, speculative):
+    """(B_r, B_c, n_waves) LDS-DMA config with / without the speculative softmax (a NativeKernelConfig: the
+    13-field key's optimized_softmax keeps the reference's meaning and never selects it)."""
+    return kc.NativeKernelConfig(name, 128, B_r, B_c, n_waves, True, True, True, 0, 0, 0, buffer, False,
+                                 speculative_softmax=speculative)
+
+
 def _persistent_cfg(name, speculative):
-    return kc.FlashForwardKernelConfig(name, 128, 256, 64, 4, True, True, True, 0, 0, 0, True, speculative)
+    return _native(name, 256, 64, 4, True, speculative)
 
 
 def _sign_vector(seed):
@@ -332,7 +339,7 @@ def _sign_vector(seed):
 
 
 def test_speculative_softmax_against_its_restatement():
-    """optimized_softmax on the persistent kernel = the speculative softmax: the first
+    """speculative_softmax on the persistent kernel: the first
     pass keeps the row max of an item's first tile as the reference for the whole item.  On inputs
     that do not trip the overflow check the result is the lazy restatement with an infinite
     threshold; rising logits (P up to ~2^40 in bf16) lose nothing."""
@@ -358,7 +365,7 @@ def test_speculative_softmax_against_its_restatement():
 def test_speculative_softmax_second_pass(rise):
     """An item whose logits rise far above its first tile's row max fails the epilogue's check and is
     run again by the lazy-rescale schedule after the walk: its 256 rows must then be BIT-identical to
-    what the lazy-rescale build (optimized_softmax = False) computes, every other item keeps the
+    what the lazy-rescale build (speculative_softmax = False) computes, every other item keeps the
     first pass's result, and everything stays within tolerance of fp32 eager.  `overflow`: q.k c of
     ~14 000 binades (exp2 overflows fp32: inf / NaN in the first pass) -- both dtypes fail.
     `moderate`: ~20 binades -- fp16 fails (P would pass 65504), bf16 does not."""
@@ -391,12 +398,12 @@ def test_speculative_softmax_second_pass(rise):
 @pytest.mark.parametrize("family", ["persistent", "32-row", "16-row"])
 def test_speculative_softmax_limit_and_large_values(family):
     """The bf16 limit of the first pass is l < 2^64 (spec_limit): a rise of ~50 binades above the first visited tile
-    stays in the first pass, ~75 binades takes the second -- there the rows equal the optimized_softmax = False build
+    stays in the first pass, ~75 binades takes the second -- there the rows equal the speculative_softmax = False build
     bit for bit -- and with V scaled by 2^50 (|O| <= l max|V| = 2^114 < fp32 max in the first pass) both stay finite
     and within relative tolerance of fp32 eager."""
     cfg_of = {"persistent": lambda o: _persistent_cfg(kc.DType.BF16, o),
-              "32-row": lambda o: kc.FlashForwardKernelConfig(kc.DType.BF16, 128, 128, 64, 4, True, True, True, 0, 0, 0, True, o),
-              "16-row": lambda o: kc.FlashForwardKernelConfig(kc.DType.BF16, 128, 64, 32, 4, True, True, True, 0, 0, 0, False, o)}[family]
+              "32-row": lambda o: _native(kc.DType.BF16, 128, 64, 4, True, o),
+              "16-row": lambda o: _native(kc.DType.BF16, 64, 32, 4, False, o)}[family]
     spec, safe = cfg_of(True), cfg_of(False)
     B, H, S, b_, h_ = 2, 3, 1024, 1, 2
     for binades, second in ((50.0, False), (75.0, True)):
@@ -420,10 +427,10 @@ def test_speculative_softmax_limit_and_large_values(family):
 
 
 def test_speculative_softmax_on_the_32_row_kernels_starts_over():
-    """optimized_softmax on the double-buffered 32-rows-per-wave variants (the key-split (64, 64, 4) form
-    and the 16-rows-per-wave (64, 32, 4) kernel too) is the speculative softmax too: a workgroup whose check fails runs its item again with the
+    """speculative_softmax on the double-buffered 32-rows-per-wave variants (the key-split (64, 64, 4) form
+    and the 16-rows-per-wave (64, 32, 4) kernel too): a workgroup whose check fails runs its item again with the
     running max.  That second attempt is the arithmetic of the same variant without the flag, so the
-    rows of the failed workgroup must equal the optimized_softmax = False build bit for bit; all rows
+    rows of the failed workgroup must equal the speculative_softmax = False build bit for bit; all rows
     stay within tolerance of fp32 eager."""
     shapes = [(128, 64, 4, True), (128, 64, 4, False), (128, 32, 4, True), (256, 128, 8, False), (64, 64, 4, True),
               (64, 64, 4, False), (256, 64, 8, True), (64, 32, 4, False)]
@@ -436,8 +443,8 @@ def test_speculative_softmax_on_the_32_row_kernels_starts_over():
         ref = ut.py_flash_attention(q, k, v, upcast=True).float()
         tol = TOL[dtype] * (1 + ref.abs())
         for B_r, B_c, nw, buf in shapes:
-            spec = kc.FlashForwardKernelConfig(name, 128, B_r, B_c, nw, True, True, True, 0, 0, 0, buf, True)
-            plain = replace(spec, optimized_softmax=False)
+            spec = _native(name, B_r, B_c, nw, buf, True)
+            plain = replace(spec, speculative_softmax=False)
             assert kc.uses_speculative_softmax(spec) and not kc.uses_speculative_softmax(plain)
             out, out_plain = flash_attention.forward(spec, q, k, v), flash_attention.forward(plain, q, k, v)
             assert torch.isfinite(out.float()).all(), str(spec)
@@ -448,7 +455,7 @@ def test_speculative_softmax_on_the_32_row_kernels_starts_over():
 
 
 def test_speculative_softmax_causal_second_pass():
-    """The causal form of the persistent kernel under optimized_softmax: a wave's reference is the row max
+    """The causal form of the persistent kernel under speculative_softmax: a wave's reference is the row max
     of its diagonal tile.  A key far below the diagonal with a huge logit (visited later) overflows the first
     pass; the item is redone by the lazy-rescale schedule: bit-identical to the build without the flag for
     that item, within tolerance of the masked fp32 eager result everywhere."""
@@ -507,9 +514,9 @@ def test_two_streams_launching_at_once():
     s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
     jobs = []
     for i, (cfg, shape) in enumerate(((_persistent_cfg(kc.DType.BF16, True), (4, 2048, 16, 128)),
-                                      (kc.FlashForwardKernelConfig(kc.DType.FP16, 128, 128, 64, 4, True, True, True, 0, 0, 0, True, True), (3, 1024, 8, 128)),
+                                      (_native(kc.DType.FP16, 128, 64, 4, True, True), (3, 1024, 8, 128)),
                                       (_persistent_cfg(kc.DType.FP16, False), (2, 4096, 8, 128)),
-                                      (kc.FlashForwardKernelConfig(kc.DType.BF16, 128, 64, 64, 4, True, True, True, 0, 0, 0, True, True), (5, 512, 7, 128)))):
+                                      (_native(kc.DType.BF16, 64, 64, 4, True, True), (5, 512, 7, 128)))):
         gen = torch.Generator(device=DEV).manual_seed(50 + i)
         q, k, v = (torch.randn(shape, dtype=cfg.dtype.to_torch_dtype(), device=DEV, generator=gen) for _ in range(3))
         jobs.append((cfg, q, k, v, flash_attention.forward(cfg, q, k, v)))
@@ -536,7 +543,7 @@ def test_soak_of_the_persistent_kernel_short():
 
 @pytest.mark.parametrize("S", [1000, 2500])
 def test_speculative_softmax_ragged_second_pass(S):
-    """The ragged form under optimized_softmax: the rounded-up tiles beyond the sequence are masked whole,
+    """The ragged form under speculative_softmax: the rounded-up tiles beyond the sequence are masked whole,
     a wave's reference is the row max of the last tile that holds keys (causal: or its diagonal tile, the
     earlier of the two).  A huge logit at a key visited later fails the check; the item is redone."""
     for dtype, name in ((torch.bfloat16, kc.DType.BF16), (torch.float16, kc.DType.FP16)):
@@ -571,7 +578,7 @@ def test_speculative_softmax_fuzz():
     for trial in range(36):
         B_r, B_c, nw, buf = shapes[trial % len(shapes)]
         dtype, name = ((torch.bfloat16, kc.DType.BF16), (torch.float16, kc.DType.FP16))[trial & 1]
-        cfg = kc.FlashForwardKernelConfig(name, 128, B_r, B_c, nw, True, True, True, 0, 0, 0, buf, True)
+        cfg = _native(name, B_r, B_c, nw, buf, True)
         B, H = rng.choice([1, 2, 5]), rng.choice([1, 3, 8])
         S = B_r * rng.choice([1, 2, 3, 4, 8] if B_r == 256 else [1, 2, 4, 9, 16])
         gen = torch.Generator(device=DEV).manual_seed(trial)
@@ -735,7 +742,7 @@ def test_full_size_properties(name, dtype, B, H, S):
     ref = ut.py_flash_attention(q[sl].contiguous(), k[sl].contiguous(), v[sl].contiguous(), upcast=True)
     assert (out[sl].float() - ref.float()).abs().max().item() <= TOL[dtype]
     # (6) a different tile shape computes the same function (different summation order)
-    other = replace(cfg, B_r=128, B_c=64, n_warps=4, optimized_softmax=False)
+    other = kc.as_native(replace(cfg, B_r=128, B_c=64, n_warps=4, optimized_softmax=False), speculative_softmax=False)
     oo = flash_attention.forward(other, q, k, v)
     assert (oo.float() - out.float()).abs().max().item() <= TOL[dtype]
 
@@ -751,9 +758,9 @@ def test_whole_c4_job_on_one_device_offsets_beyond_4_gib(shape):
     if free < 24 << 30:
         pytest.skip("needs 16 GiB of q/k/v/o")
     cfg = {"persistent": kc.best_config(kc.DType.BF16),
-           "32-row": kc.FlashForwardKernelConfig(kc.DType.BF16, 128, 128, 64, 4, True, True, True, 0, 0, 0, True, True),
-           "key-split": kc.FlashForwardKernelConfig(kc.DType.BF16, 128, 64, 64, 4, True, True, True, 0, 0, 0, True, True),
-           "16-row": kc.FlashForwardKernelConfig(kc.DType.BF16, 128, 64, 32, 4, True, True, True, 0, 0, 0, False, False)}[shape]
+           "32-row": _native(kc.DType.BF16, 128, 64, 4, True, True),
+           "key-split": _native(kc.DType.BF16, 64, 64, 4, True, True),
+           "16-row": _native(kc.DType.BF16, 64, 32, 4, False, False)}[shape]
     gen = torch.Generator(device=DEV).manual_seed(64)
     q, k, v = (torch.empty((B, S, H, 128), dtype=torch.bfloat16, device=DEV) for _ in range(3))
     for t in (q, k, v):
@@ -800,7 +807,7 @@ def test_c2_sweep_shape_properties(S, B):
     sl = (slice(B - 1, B), slice(None), slice(3, 4))
     ref = ut.py_flash_attention(q[sl].contiguous(), k[sl].contiguous(), v[sl].contiguous(), upcast=True)
     assert (out[sl].float() - ref.float()).abs().max().item() <= TOL[dtype]
-    other = kc.FlashForwardKernelConfig(kc.DType.BF16, 128, 128, 64, 4, True, True, True, 0, 0, 0, True, False)
+    other = _native(kc.DType.BF16, 128, 64, 4, True, False)
     oo = flash_attention.forward(other, q, k, v)
     assert (oo.float() - out.float()).abs().max().item() <= TOL[dtype]
     # bitwise run-to-run determinism at full size
@@ -838,7 +845,8 @@ def test_c4_all_eight_shards_on_one_gpu():
 
 
 # ---- scope wideners beyond the reference: causal mask, ragged seq_len -----------
-MASKED = [c for c in VARIANTS if _capi.masked_supported(c)]
+# (a native config that asks for the speculative softmax has a masked form on the persistent kernel only)
+MASKED = [c for c in VARIANTS if _capi.ex_supported(c, allow_ragged=True, speculative=kc.wants_speculative(c))]
 
 
 def _rel_ok(out, ref, dtype):
@@ -878,19 +886,15 @@ def test_masked_variants_against_eager_sdpa_and_oracle(S, causal):
 
 def test_masked_variant_equals_plain_kernel_when_nothing_is_masked():
     """At a tile-multiple seq_len without causal mask the widened variant must reproduce the
-    reference-scope kernel bit for bit.  (The masked forms always keep a running max; where
-    optimized_softmax selects the speculative softmax in the plain kernel, its arithmetic is that of
-    the plain kernel WITHOUT the flag -- the first-block skip multiplies by exact zeros and ones.)"""
+    reference-scope kernel bit for bit.  (The masked forms of the 32-rows-per-wave kernels keep a running max and
+    build the reference's first-block skip under optimized_softmax, which the plain LDS-DMA kernels ignore: the
+    skip multiplies by exact zeros and ones, so the two still agree bit for bit.)"""
     for cfg in MASKED:
         dtype = cfg.dtype.to_torch_dtype()
         gen = torch.Generator(device=DEV).manual_seed(3)
         q, k, v = (torch.randn((2, 1024, 4, 128), dtype=dtype, device=DEV, generator=gen) for _ in range(3))
-        plain = replace(cfg, optimized_softmax=False) if kc.uses_speculative_softmax(cfg) else cfg
-        if kc.uses_lazy_rescale(cfg):
-            plain = cfg  # the persistent kernel's causal form is speculative under the flag too: the same arithmetic
-        assert torch.equal(flash_attention.forward_ex(cfg, q, k, v), flash_attention.forward(plain, q, k, v)), str(cfg)
-        if plain is not cfg:
-            assert (flash_attention.forward(cfg, q, k, v).float() - flash_attention.forward(plain, q, k, v).float()).abs().max().item() <= TOL[dtype]
+        assert kc.uses_speculative_softmax(cfg, masked=True) == kc.uses_speculative_softmax(cfg)  # (by construction of MASKED)
+        assert torch.equal(flash_attention.forward_ex(cfg, q, k, v), flash_attention.forward(cfg, q, k, v)), str(cfg)
 
 
 @pytest.mark.parametrize("shape", [(8, 16, 1024), (40, 16, 256), (5, 7, 512), (3, 16, 2048), (2, 16, 4096),
@@ -903,8 +907,8 @@ def test_persistent_walk_causal(shape):
     B, H, S = shape
     for dtype, name, opt in ((torch.bfloat16, kc.DType.BF16, False), (torch.float16, kc.DType.FP16, False),
                              (torch.bfloat16, kc.DType.BF16, True), (torch.float16, kc.DType.FP16, True)):
-        cfg = kc.FlashForwardKernelConfig(name, 128, 256, 64, 4, True, True, True, 0, 0, 0, True, opt)
-        other = kc.FlashForwardKernelConfig(name, 128, 128, 64, 4, True, True, True, 0, 0, 0, True, False)
+        cfg = _native(name, 256, 64, 4, True, opt)
+        other = _native(name, 128, 64, 4, True, False)
         qc = ut.QKVConfig(n_heads=H, d_head=128, batch_size=B, seq_len=S, dtype=dtype, device=torch.device(DEV))
         q, k, v = ut.generate_qkv(qc, seed=B + S + 1)
         runs = [flash_attention.forward_ex(cfg, q, k, v, causal=True) for _ in range(3)]
@@ -931,8 +935,8 @@ def test_persistent_ragged_lengths(S):
     B, H = (3, 5) if S < 2048 else (2, 3)
     for dtype, name, opt in ((torch.bfloat16, kc.DType.BF16, False), (torch.float16, kc.DType.FP16, False),
                              (torch.bfloat16, kc.DType.BF16, True), (torch.float16, kc.DType.FP16, True)):
-        cfg = kc.FlashForwardKernelConfig(name, 128, 256, 64, 4, True, True, True, 0, 0, 0, True, opt)
-        other = kc.FlashForwardKernelConfig(name, 128, 128, 64, 4, True, True, True, 0, 0, 0, True, False)
+        cfg = _native(name, 256, 64, 4, True, opt)
+        other = _native(name, 128, 64, 4, True, False)
         gen = torch.Generator(device=DEV).manual_seed(S)
         # q, k, v, o: the first S rows of (B, S + 8, H, 128) buffers (through the C ABI: the shim wants contiguous)
         big = [torch.randn((B, S + 8, H, 128), dtype=dtype, device=DEV, generator=gen) for _ in range(3)]
@@ -975,8 +979,8 @@ def test_ragged_item_seams_under_load(S):
     n_qb = (S + 255) // 256
     assert B * H * n_qb > 4 * 256
     for dtype, name, opt in ((torch.bfloat16, kc.DType.BF16, False), (torch.float16, kc.DType.FP16, True)):
-        cfg = kc.FlashForwardKernelConfig(name, 128, 256, 64, 4, True, True, True, 0, 0, 0, True, opt)
-        other = kc.FlashForwardKernelConfig(name, 128, 128, 64, 4, True, True, True, 0, 0, 0, True, False)
+        cfg = _native(name, 256, 64, 4, True, opt)
+        other = _native(name, 128, 64, 4, True, False)
         gen = torch.Generator(device=DEV).manual_seed(S)
         q, k, v = (torch.randn((B, S, H, 128), dtype=dtype, device=DEV, generator=gen) for _ in range(3))
         flush = torch.empty(600 * 1024 * 1024, dtype=torch.int8, device=DEV)
@@ -1007,8 +1011,8 @@ def test_persistent_walk_random_shapes():
             S = 256 * rng.choice([1, 2, 4])
         causal = bool(trial & 1)
         dtype, name = ((torch.bfloat16, kc.DType.BF16), (torch.float16, kc.DType.FP16))[(trial >> 1) & 1]
-        cfg = kc.FlashForwardKernelConfig(name, 128, 256, 64, 4, True, True, True, 0, 0, 0, True, bool(trial & 4))
-        other = kc.FlashForwardKernelConfig(name, 128, 128, 64, 4, True, True, True, 0, 0, 0, True, False)
+        cfg = _native(name, 256, 64, 4, True, bool(trial & 4))
+        other = _native(name, 128, 64, 4, True, False)
         gen = torch.Generator(device=DEV).manual_seed(trial)
         q, k, v = (torch.randn((B, S, H, 128), dtype=dtype, device=DEV, generator=gen) for _ in range(3))
         a = flash_attention.forward_ex(cfg, q, k, v, causal=causal) if causal else flash_attention.forward(cfg, q, k, v)
@@ -1027,7 +1031,7 @@ def test_c_abi_strided_views_and_long_sequence():
     import ctypes
     lib = _capi.load()
     for cfg in (kc.best_config(kc.DType.BF16, 4096),
-                kc.FlashForwardKernelConfig(kc.DType.BF16, 128, 256, 128, 8, True, True, True, 0, 0, 0, False, True)):
+                _native(kc.DType.BF16, 256, 128, 8, False, True)):
         B, S, H = 3, 1024, 5
         gen = torch.Generator(device=DEV).manual_seed(11)
         big = [torch.randn((B, S, 2 * H, 128), dtype=torch.bfloat16, device=DEV, generator=gen) for _ in range(3)]
@@ -1043,7 +1047,7 @@ def test_c_abi_strided_views_and_long_sequence():
         assert torch.equal(o, ref), str(cfg)
         assert torch.count_nonzero(obig[:, :, H:]) == 0   # the other heads of the buffer are untouched
     cfg = kc.best_config(kc.DType.BF16, 32768)
-    other = kc.FlashForwardKernelConfig(kc.DType.BF16, 128, 128, 64, 4, True, True, True, 0, 0, 0, True, False)
+    other = _native(kc.DType.BF16, 128, 64, 4, True, False)
     gen = torch.Generator(device=DEV).manual_seed(12)
     q, k, v = (torch.randn((1, 32768, 2, 128), dtype=torch.bfloat16, device=DEV, generator=gen) for _ in range(3))
     a = flash_attention.forward(cfg, q, k, v)

@@ -30,7 +30,28 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layout_matches_header():
     assert ctypes.sizeof(_capi.FaFwdConfig) == 13 * 4
     assert ctypes.sizeof(_capi.FaFwdArgs) == 4 * 8 + 7 * 8 + 13 * 4 + 4  # tail padding to 8
-    assert ctypes.sizeof(_capi.FaKernelInfo) == 13 * 4 + 6 * 4
+    assert ctypes.sizeof(_capi.FaKernelInfo) == 13 * 4 + 8 * 4
+    assert ctypes.sizeof(_capi.FaFwdStats) == 8
+    assert ctypes.sizeof(_capi.FaFwdOpts) == 5 * 4 + 4 + 2 * 8   # five 32-bit fields, padding, two pointers
+    # the header's own view, compiled: sizes and offsets of the structs ctypes mirrors
+    src = r'''
+#include <stdio.h>
+#include <stddef.h>
+#include "fa_hip.h"
+int main(void) {
+    printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(fa_fwd_config), sizeof(fa_fwd_args), sizeof(fa_kernel_info),
+           sizeof(fa_fwd_stats), sizeof(fa_fwd_opts), offsetof(fa_fwd_opts, ms), offsetof(fa_fwd_opts, stats),
+           offsetof(fa_kernel_info, softmax_mode), offsetof(fa_fwd_opts, prescaled_q));
+    return 0;
+}'''
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        open(os.path.join(tmp, "t.c"), "w").write(src)
+        subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(tmp, "t.c"), "-o", os.path.join(tmp, "t")], check=True)
+        got = [int(x) for x in subprocess.run([os.path.join(tmp, "t")], capture_output=True, text=True, check=True).stdout.split()]
+    assert got == [ctypes.sizeof(_capi.FaFwdConfig), ctypes.sizeof(_capi.FaFwdArgs), ctypes.sizeof(_capi.FaKernelInfo),
+                   ctypes.sizeof(_capi.FaFwdStats), ctypes.sizeof(_capi.FaFwdOpts), _capi.FaFwdOpts.ms.offset,
+                   _capi.FaFwdOpts.stats.offset, _capi.FaKernelInfo.softmax_mode.offset, _capi.FaFwdOpts.prescaled_q.offset]
 
 
 def test_every_enumerated_config_has_a_device_kernel():
@@ -54,8 +75,12 @@ def test_registry_enumeration_is_consistent():
     seen = set()
     for info in infos:
         key = tuple(getattr(info.cfg, f) for f in _capi.CONFIG_FIELDS)
-        assert (key, info.masked) not in seen
-        seen.add((key, info.masked))
+        ident = (key, info.masked, info.softmax_mode, info.prescaled_q)
+        assert ident not in seen
+        seen.add(ident)
+        assert 0 <= info.softmax_mode < 4
+        # the canonical config's optimized_softmax has the reference's meaning only
+        assert bool(info.cfg.optimized_softmax) == (_capi.SOFTMAX_MODES[info.softmax_mode] == "first_block_skip")
         assert info.threads == 64 * info.cfg.n_warps
         assert info.rows_per_wave * info.cfg.n_warps == info.cfg.B_r
         assert info.rows_per_wave in (16, 32, 64)
@@ -63,6 +88,67 @@ def test_registry_enumeration_is_consistent():
         cfg = kc.FlashForwardKernelConfig(kc.DType(info.cfg.dtype), *key[1:5], *map(bool, key[5:8]),
                                           *key[8:11], *map(bool, key[11:13]))
         assert _capi.supported(cfg)
+
+
+def test_one_flag_one_meaning_softmax_mode_of_every_config():
+    """`optimized_softmax` keeps the reference's meaning (softmax.cuh:85-105, forward_kernel.cuh:158-161) through the C
+    ABI: a plain 13-field config NEVER reaches a speculative variant; the speculative softmax and the pre-scaled Q are
+    asked for in fa_fwd_opts (a NativeKernelConfig on the Python side).  kc.softmax_mode() is the Python mirror of
+    fa_kernel_info.softmax_mode: checked here for every enumerable config, plain and masked, against the registry's
+    own lookup (fa_fwd_ex_supported) and the enumeration (fa_get_kernel)."""
+    from dataclasses import replace
+
+    n_spec = 0
+    for cfg in kc.get_all_supported_configs():
+        for masked in (False, True):
+            if not _capi.ex_supported(cfg, allow_ragged=masked):
+                assert masked
+                continue
+            wants = kc.wants_speculative(cfg)
+            has = _capi.ex_supported(cfg, allow_ragged=masked, speculative=True)
+            assert has == kc.has_speculative_variant(cfg, masked) or not has, (str(cfg), masked)
+            if wants and not has:
+                assert masked  # every enumerated native config has its plain speculative variant
+                continue
+            info = _capi.query(cfg, allow_ragged=masked, speculative=wants)
+            mode = kc.softmax_mode(cfg, masked)
+            assert mode == _capi.SOFTMAX_MODES[info.softmax_mode], (str(cfg), masked, mode, info.softmax_mode)
+            assert (mode == "speculative") == wants
+            n_spec += wants
+            if not isinstance(cfg, kc.NativeKernelConfig):
+                assert mode != "speculative"
+                # the flag alone never changes which arithmetic family runs
+                other = kc.softmax_mode(replace(cfg, optimized_softmax=not cfg.optimized_softmax), masked)
+                assert {mode, other} <= {"eager", "first_block_skip"} or mode == other == "lazy"
+    assert n_spec >= 30
+    os.environ["FA_ALLOW_SPECULATIVE"] = "1"
+    try:
+        cfg = kc.get_kernel_configs("tune")[-1]
+        assert cfg.optimized_softmax and kc.softmax_mode(cfg) == "speculative"   # the round-2 mapping, opt-in
+    finally:
+        del os.environ["FA_ALLOW_SPECULATIVE"]
+    assert kc.softmax_mode(cfg) == "eager"
+    # best_config: bf16 speculative, fp16 not (its 16-bit P leaves ~10 nats of headroom; DESIGN.md 3.6)
+    assert kc.softmax_mode(kc.best_config(kc.DType.BF16)) == "speculative"
+    assert kc.softmax_mode(kc.best_config(kc.DType.FP16)) == "lazy"
+    assert kc.softmax_mode(kc.best_config(kc.DType.BF16, 1000, masked=True), masked=True) == "speculative"
+    assert kc.softmax_mode(kc.best_config(kc.DType.BF16, 100, masked=True), masked=True) == "eager"
+
+
+def test_opts_struct_size_is_checked():
+    lib = _capi.load()
+    cfg = kc.best_config(kc.DType.BF16)
+    args = _args(cfg)
+    bad = _capi.FaFwdOpts()  # struct_size left 0
+    assert lib.fa_fwd_launch_ex(ctypes.byref(args), ctypes.byref(bad), None) == -4 and "struct_size" in _capi.last_error()
+    o = _capi.make_opts(prescaled_q=True)
+    o_lazy = _capi.make_opts()
+    c = _capi.make_config(cfg)
+    assert lib.fa_fwd_ex_supported(ctypes.byref(c), ctypes.byref(o_lazy)) == 1
+    assert lib.fa_fwd_ex_supported(ctypes.byref(c), None) == 1
+    short = _capi.make_opts(speculative=True)
+    short.struct_size = 16   # an older caller whose header ended behind `speculative`
+    assert lib.fa_fwd_ex_supported(ctypes.byref(c), ctypes.byref(short)) == 1
 
 
 def test_unsupported_configs_are_rejected():
@@ -254,7 +340,7 @@ def test_per_device_init_bookkeeping_without_a_gpu():
         assert b"no HIP device" in lib.fa_last_error()
     for dev in (0, 1, 63):
         inited, status, num_cus = _capi.device_state(dev)
-        assert (inited, status) == (False, 0) and num_cus == 256
+        assert (inited, status, num_cus) == (False, 0, 0)   # (nothing is published before a device's init has finished)
     with pytest.raises(RuntimeError):
         _capi.device_state(64)
     with pytest.raises(RuntimeError):

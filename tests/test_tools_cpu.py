@@ -106,8 +106,10 @@ def test_generated_variant_list_is_current_and_covers_every_config():
     built, masked = set(), set()
     for info in _capi.kernels():
         c = info.cfg
+        # the variant's OPT template flag: the reference's first-block skip or the speculative softmax (softmax_mode says which)
+        opt = _capi.SOFTMAX_MODES[info.softmax_mode] in ("first_block_skip", "speculative")
         key = (c.dtype, info.rows_per_wave, c.n_warps, c.B_c, bool(c.swizzled), bool(c.eager_load_blocks),
-               bool(c.optimized_softmax), bool(c.mma_double_buffer_loads), bool(c.async_copy), c.d_head)
+               opt, bool(c.mma_double_buffer_loads), bool(c.async_copy), c.d_head)
         (masked if info.masked else built).add(key)
     wanted = {gen.variant_of(cfg) for cfg in kc.get_all_supported_configs()}
     assert wanted == built
