@@ -26,9 +26,17 @@ One JSON line on rank 0:
   cpu_baseline  torch CPU scaled_dot_product_attention (oracle.fa_oracle.sdpa_cpu)
              on the SAME workload, on this host's cores, rank 0, N=1 only.
 
---hermetic times every launch on its own behind a cache flush and an idle spin (the
-reference's tools/benchmark/pt_bench.py:145-174 protocol); the default is back-to-back
-launches, which is what the driver's wall clock sees.
+  roofline.mfma_only_*  the matrix pipe's practical roof on THIS box in THIS run: a register-only MFMA
+             loop (tools/mfma_energy.hip `quick`: the kernel's issue order, no memory traffic, ~20 ms
+             launches) on zero and on N(0,1) operands, bf16 and fp16 -- the chip clocks to its power
+             budget, and random operands cost ~30 % of the datasheet rate before any kernel is involved
+  protocols  the same kernel under the reference's own timing protocol as well (pt_bench.py:145-174:
+             cache flush + idle spin before every launch, >= 50 reps): `value` is back-to-back launches
+             (what the driver's wall clock sees), `protocols.hermetic` the other figure, same run
+  speculative  fa_fwd_stats of the timed launches: work items and how many the speculative softmax
+             computed twice (--data sink / heavy show the cliff on non-Gaussian logits)
+
+--hermetic makes the hermetic protocol the headline `value` instead.
 """
 import argparse
 import glob
@@ -65,6 +73,54 @@ def mfma_flop(batch, heads, seq, d):
     return 4 * batch * heads * seq * seq * d
 
 
+def make_inputs(data, shape, dtype, device, gen):
+    """Synthetic q, k, v of `shape` = (batch, seq, heads, d).  `randn`: N(0, 1) (the reference's benchmark data,
+    utils.py:112-121).  `sink`: the same plus an attention sink -- one head dimension carries a constant in every
+    query and in the FIRST FOUR keys, worth +12 nats of logit (= 17 binades) over everything else: the shape of
+    BOS / sink keys in trained models, and the speculative softmax's worst case (those keys are visited LAST).
+    `heavy`: K drawn from a Student-t with 3 degrees of freedom (unit variance): occasional large logits anywhere."""
+    q, k, v = (torch.empty(shape, dtype=dtype, device=device) for _ in range(3))
+    for t in (q, k, v):
+        t.normal_(generator=gen)
+    d = shape[-1]
+    if data == "sink":
+        a = (12.0 * d ** 0.5) ** 0.5           # a * a / sqrt(d) = 12 nats
+        q[..., 0] = a
+        k[..., 0] = 0
+        k[:, :4, :, 0] = a
+    elif data == "heavy":
+        z = torch.empty(shape, dtype=torch.float32, device=device).normal_(generator=gen)
+        chi = sum(torch.empty(shape, dtype=torch.float32, device=device).normal_(generator=gen) ** 2 for _ in range(3))
+        k.copy_((z / (chi / 3).sqrt() / 3 ** 0.5).to(dtype))   # t_3 has variance 3
+    elif data != "randn":
+        raise SystemExit(f"unknown --data {data}")
+    return q, k, v
+
+
+def mfma_only_roof(device_index):
+    """Run lib/mfma_energy quick on `device_index` (HIP_VISIBLE_DEVICES narrows the child to it): -> {"bf16_zeros": ...,
+    "bf16_normal": ..., "fp16_zeros": ..., "fp16_normal": ...} TFLOP/s, or {"error": ...}."""
+    exe = os.path.join(ROOT, "flash_attention_from_scratch_amd", "lib", "mfma_energy")
+    if not os.path.exists(exe):
+        return {"error": "lib/mfma_energy not built (make -C flash_attention_from_scratch_amd/csrc tools)"}
+    env = dict(os.environ)
+    vis = env.get("HIP_VISIBLE_DEVICES") or env.get("ROCR_VISIBLE_DEVICES")
+    if vis is None:
+        env["HIP_VISIBLE_DEVICES"] = str(device_index)
+    try:
+        out = subprocess.run([exe, "quick"], env=env, capture_output=True, text=True, timeout=120, check=True).stdout
+    except (subprocess.SubprocessError, OSError) as exc:
+        return {"error": f"mfma_energy quick: {type(exc).__name__}"}
+    words = out.replace("mfma_energy quick:", "").split()
+    got = {}
+    for name, val in zip(words[0::2], words[1::2]):
+        try:
+            got[name] = float(val)
+        except ValueError:
+            break
+    return got if len(got) == 4 else {"error": "unparsed: " + out.strip()[:200]}
+
+
 def shard_for_rank(global_batch, world, rank):
     """Contiguous batch shard [lo, hi) of rank `rank` (plain batch split)."""
     base, extra = divmod(global_batch, world)
@@ -73,7 +129,10 @@ def shard_for_rank(global_batch, world, rank):
 
 
 def timed_steps(step, steps, warmup, sync, barrier):
-    """W untimed steps, then exactly K steps bracketed by barrier + sync. Seconds."""
+    """W untimed steps, then exactly K steps bracketed by a barrier + synchronize on both sides.  Seconds of THIS rank;
+    the caller takes the max over ranks.  The closing pair is barrier THEN synchronize: the launches are asynchronous,
+    so the host-side barrier (a gloo round trip is 0.1-1 ms, 10 % of a 20-step region) runs while the devices still
+    work, and the clock stops when this rank's device goes idle."""
     for _ in range(warmup):
         step()
     sync()
@@ -81,8 +140,8 @@ def timed_steps(step, steps, warmup, sync, barrier):
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
-    sync()
     barrier()
+    sync()
     return time.perf_counter() - t0
 
 
@@ -398,6 +457,8 @@ def dry_run(args, rank, world):
     else:
         def barrier():
             return None
+    if args.steps is None:
+        args.steps = 5
     _, batch, heads, seq, d = WORKLOADS[args.workload if args.workload != "c2" else "c1"]
     lo, hi = shard_for_rank(batch * world, world, rank)
     seconds = timed_steps(lambda: time.sleep(0.002), args.steps, args.warmup, lambda: None, barrier)
@@ -417,7 +478,8 @@ def dry_run(args, rank, world):
                           "unit": "TFLOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": seconds / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
                           "vs_baseline": None, "dtype": "none", "data": "none (dry run)",
-                          "config": {"workload": "dry run", "global_batch": batch * world,
+                          "config": {"workload": f"dry run of {args.workload}", "global_batch": batch * world, "heads": heads,
+                                     "seq_len": seq, "flop_per_step_per_gpu": mfma_flop(hi - lo, heads, seq, d),
                                      "shards": [list(shard_for_rank(batch * world, world, r)) for r in range(world)]},
                           "per_gpu_tflops": per_rank}), flush=True)
     if world > 1:
@@ -429,10 +491,19 @@ def dry_run(args, rank, world):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=None,
+                    help="timed steps (exactly this many).  Default: 50 at N = 1; at N > 1 as many as make the timed region "
+                         ">= 200 ms per rank (a 20-step region is 8 ms, and the max over ranks then mostly measures host jitter)")
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="c1", choices=sorted(WORKLOADS) + ["c2"])
     ap.add_argument("--kernel", default="", help="short-form config; default = best_config(dtype)")
+    ap.add_argument("--dtype", default="", choices=["", "bf16", "fp16"], help="override the workload's dtype (same shape)")
+    ap.add_argument("--data", default="randn", choices=["randn", "sink", "heavy"],
+                    help="synthetic inputs: N(0,1) (the reference's; default) | an attention sink (+12 nats at the first 4 keys) "
+                         "| heavy-tailed K (Student-t, 3 dof): what the speculative softmax's second pass costs (line: speculative)")
+    ap.add_argument("--hermetic-reps", type=int, default=50,
+                    help="launches of the side measurement under the reference's flush + idle-spin protocol (protocols.hermetic); 0 = skip")
+    ap.add_argument("--no-mfma-roof", action="store_true", help="skip the register-only MFMA loop (roofline.mfma_only_*)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-traffic", action="store_true",
                     help="skip the three rocprofv3 PMC passes (HBM bytes per launch; matrix-pipe occupancy, "
@@ -490,8 +561,12 @@ def main():
     if args.workload == "c2":
         if world != 1:
             raise SystemExit("the c2 sweep is a single-GPU workload")
+        if args.steps is None:
+            args.steps = 50
         return run_c2_sweep(args, device)
     dtype_name, batch, heads, seq, d = WORKLOADS[args.workload]
+    if args.dtype:
+        dtype_name = args.dtype
     dtype = {"bf16": torch.bfloat16, "fp16": torch.float16}[dtype_name]
     cfg = (kc.parse_kernel_name_into_config(args.kernel) if args.kernel
            else kc.best_config(kc.DType.BF16 if dtype_name == "bf16" else kc.DType.FP16, seq))
@@ -501,8 +576,9 @@ def main():
     gen = torch.Generator(device=device).manual_seed(1000 + rank)
     slab = torch.empty((4, hi - lo, seq, heads, d), dtype=dtype, device=device)
     q, o, k, v = slab[0], slab[1], slab[2], slab[3]   # generate_qkvo layout (utils.py:124-134)
-    for t in (q, k, v):
-        t.normal_(generator=gen)
+    for dst, src in zip((q, k, v), make_inputs(args.data, (hi - lo, seq, heads, d), dtype, device, gen)):
+        dst.copy_(src)
+        del src
 
     stream = torch.cuda.current_stream(device)
 
@@ -524,37 +600,55 @@ def main():
         sync()
         return
 
+    flush_buf = torch.empty(512 * 1024 * 1024, dtype=torch.int8, device=device) if (args.hermetic or args.hermetic_reps) else None
+
+    def hermetic_launch():
+        """pt_bench.py:145-174: flush (> L2 + Infinity Cache), idle spin, events around ONE launch -> ms"""
+        flush_buf.zero_()
+        torch.cuda._sleep(1_000_000)
+        sync()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        step()
+        e1.record(stream)
+        sync()
+        return e0.elapsed_time(e1)
+
+    sampler = ClockSampler(hwmon_dir(local_rank))
+    # wake the clocks: the same launches, untimed, until --precondition-ms have passed
+    pre_steps, t_pre, pre_gpu_s = 0, time.perf_counter(), 0.0
+    while (time.perf_counter() - t_pre) * 1e3 < args.precondition_ms or pre_steps < 8:
+        t_a = time.perf_counter()
+        for _ in range(8):
+            step()
+        sync()
+        pre_gpu_s = time.perf_counter() - t_a
+        pre_steps += 8
+    if args.steps is None:
+        # N = 1: 50.  N > 1: a timed region of >= 200 ms per rank (from the last preconditioning batch's step time)
+        est = max(pre_gpu_s / 8, 1e-6)
+        args.steps = 50 if world == 1 else max(50, int(0.2 / est) + 1)
+        if world > 1:  # every rank times the same number of steps
+            import torch.distributed as dist
+
+            t = torch.tensor([args.steps], dtype=torch.int64, device=reduce_device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            args.steps = int(t.item())
+
     # events on the launch stream (flash_attention launches on torch's current stream): one in front
     # of the first timed launch and one behind every launch
     events = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
-    flush_buf = torch.empty(512 * 1024 * 1024, dtype=torch.int8, device=device) if args.hermetic else None
     herm_ms = []
 
     def timed_step(i):
-        if args.hermetic:  # pt_bench.py:145-174: flush (> L2 + Infinity Cache), idle spin, events around the launch
-            flush_buf.zero_()
-            torch.cuda._sleep(1_000_000)
-            sync()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(stream)
-            step()
-            e1.record(stream)
-            sync()
-            herm_ms.append(e0.elapsed_time(e1))
+        if args.hermetic:
+            herm_ms.append(hermetic_launch())
             return
         if i == 0:
             events[0].record(stream)
         step()
         events[i + 1].record(stream)
 
-    sampler = ClockSampler(hwmon_dir(local_rank))
-    # wake the clocks: the same launches, untimed, until --precondition-ms have passed
-    pre_steps, t_pre = 0, time.perf_counter()
-    while (time.perf_counter() - t_pre) * 1e3 < args.precondition_ms:
-        for _ in range(8):
-            step()
-        sync()
-        pre_steps += 8
     for _ in range(args.warmup):
         step()
     sync()
@@ -563,8 +657,8 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         timed_step(i)
+    barrier()   # (host side, while the devices still work: see timed_steps)
     sync()
-    barrier()
     seconds = time.perf_counter() - t0
     sampler.stop()
     if args.hermetic:
@@ -582,14 +676,25 @@ def main():
     achieved = flop_per_step_rank / (kernel_ms * 1e-3) / 1e12
     peak = PEAK_TFLOPS[dtype_name]
 
-    per_rank = None
-    if world > 1:  # per-GPU rates next to the aggregate (rank order)
+    # one more launch, untimed, with the device-side statistics on: how many items the speculative softmax ran twice
+    stats = torch.zeros(2, dtype=torch.int32, device=device)
+    import flash_attention_kernels
+
+    flash_attention_kernels.forward(cfg, q, k, v, o, stats=stats)
+    sync()
+    items, redone = (int(x) for x in stats.tolist())
+
+    per_rank = per_rank_clocks = None
+    if world > 1:  # per-GPU rates, clocks and power next to the aggregate (rank order)
         import torch.distributed as dist
 
-        mine = torch.tensor([achieved], dtype=torch.float64, device=reduce_device)
-        gathered = [torch.zeros_like(mine) for _ in range(world)]
-        dist.all_gather(gathered, mine)
-        per_rank = [float(g.item()) for g in gathered]
+        clk = sampler.summary()
+        mine = {"tflops": achieved, "sclk_mhz": clk.get("sclk_mhz", {}).get("mean"), "power_w": clk.get("power_w", {}).get("mean"),
+                "device": local_rank, "kernel_ms": kernel_ms}
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine)
+        per_rank = [g["tflops"] for g in gathered]
+        per_rank_clocks = gathered
 
     if rank == 0:
         props = torch.cuda.get_device_properties(device)
@@ -597,7 +702,7 @@ def main():
         sclk = clocks.get("sclk_mhz", {}).get("mean")
         line = {
             "metric": "achieved bf16 TFLOPs and % of MFMA peak at seq_len=4096 d_head=128"
-                      if args.workload == "c1" else f"achieved {dtype_name} TFLOPs ({args.workload})",
+                      if (args.workload == "c1" and dtype_name == "bf16") else f"achieved {dtype_name} TFLOPs ({args.workload})",
             "value": value,
             "unit": "TFLOP/s",
             "n_gpus": world,
@@ -608,7 +713,7 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": dtype_name,
-            "data": "synthetic",
+            "data": "synthetic" if args.data == "randn" else f"synthetic ({args.data}: see bench.py make_inputs)",
             "pct_of_mfma_peak": 100.0 * value / (peak * world),
             "ref_convention_tflops": value * (4 * d + 6) / (4 * d),  # B*H*(4S^2d+6S^2), kernel_configs.py:102
             "protocol": "hermetic: flush + idle spin before every launch, value from the per-launch events"
@@ -620,6 +725,7 @@ def main():
                             f"seq_len={seq} d_head={d} non-causal",
                 "global_batch": batch * world,
                 "kernel": cfg.short_form(),
+                "softmax_mode": kc.softmax_mode(cfg),
                 "parallelism": f"batch-shard x{world}, no collective",
                 "device": getattr(props, "gcnArchName", props.name),
                 "compute_units": props.multi_processor_count,
@@ -640,12 +746,41 @@ def main():
                 "frac_of_peak_at_measured_clock": achieved / (peak * sclk / MAX_SCLK_MHZ) if sclk else None,
             },
             "clocks": clocks,
+            "speculative": {"items": items, "items_redone": redone, "second_pass_fraction": redone / items if items else None,
+                            "source": "fa_fwd_stats of one more (untimed) launch of the same step"},
         }
         if per_rank:
             line["per_gpu_tflops"] = per_rank
+            line["per_gpu"] = per_rank_clocks
             line["aggregate_over_sum_of_gpus"] = value / sum(per_rank)
+        if world == 1 and args.hermetic_reps and not args.hermetic:
+            # the same kernel under the reference's protocol, in the same run (pt_bench.py:145-174)
+            for _ in range(3):
+                hermetic_launch()
+            side = [hermetic_launch() for _ in range(args.hermetic_reps)]
+            line["protocols"] = {
+                "back_to_back": {"tflops": value, "ms": seconds / args.steps * 1e3, "n": args.steps},
+                "hermetic": {"tflops": flop_per_step_rank / (statistics.mean(side) * 1e-3) / 1e12,
+                             "tflops_median": flop_per_step_rank / (statistics.median(side) * 1e-3) / 1e12,
+                             "ms": distribution(side),
+                             "what": "512 MiB flush + idle spin + sync before every launch, events around the launch "
+                                     "(tools/benchmark/pt_bench.py:145-174), 3 warm-ups"},
+            }
+        if world == 1 and not args.no_mfma_roof:
+            del flush_buf
+            roof = mfma_only_roof(local_rank)
+            line["roofline"]["mfma_only"] = roof
+            rand = roof.get(f"{dtype_name}_normal")
+            if rand:
+                line["roofline"]["mfma_only_random_tflops"] = rand
+                line["roofline"]["mfma_only_zero_tflops"] = roof.get(f"{dtype_name}_zeros")
+                line["roofline"]["frac_of_mfma_only_random"] = achieved / rand
+                line["roofline"]["mfma_only_source"] = ("lib/mfma_energy quick (tools/mfma_energy.hip): register-only "
+                                                        "v_mfma_f32_32x32x16 loop in the kernel's issue order, one wave per "
+                                                        "SIMD, 256 workgroups, ~20 ms launches, this device, after the timed region")
         if world == 1 and not args.no_traffic:
-            tail = ["--workload", args.workload] + (["--kernel", args.kernel] if args.kernel else [])
+            tail = ["--workload", args.workload, "--data", args.data] + (["--kernel", args.kernel] if args.kernel else []) \
+                + (["--dtype", args.dtype] if args.dtype else [])
             traffic, how = measure_traffic(tail)
             if traffic is None:
                 line["roofline"]["traffic"] = committed_traffic(cfg.short_form(), args.workload)

@@ -32,6 +32,7 @@ sys.path.insert(0, ROOT)
 from flash_helpers.kernel_configs import (  # noqa: E402
     DType,
     FlashForwardKernelConfig,
+    NativeKernelConfig,
     calc_mfma_flop,
     calc_self_attn_flop,
 )
@@ -42,7 +43,9 @@ PMC_GROUPS = [["GRBM_GUI_ACTIVE", "TCC_HIT_sum", "TCC_MISS_sum"]]
 
 def symbol_to_config(symbol):
     """'void fa::fa_fwd_kernel<15, 1, 8, 64, true, true, false, true, true, false, 128, 0>(fa::KernelArgs)' ->
-    FlashForwardKernelConfig of that device variant (None for other kernels)."""
+    config of that device variant (None for other kernels).  A variant whose OPT template flag builds the speculative
+    softmax (fa_registry.hpp softmax_mode_of) comes back as a NativeKernelConfig with speculative_softmax set; where OPT is
+    the reference's first-block skip, as optimized_softmax."""
     m = re.search(r"fa::fa_fwd_kernel(16|64)?<([^>]*)>", symbol)
     if not m:
         return None
@@ -50,7 +53,8 @@ def symbol_to_config(symbol):
     vals = [int(v) for v in vals]
     if m.group(1) == "64":  # fa_fwd_kernel64<DT, MASK, ABL, RAG, SPEC>: the persistent (256, 64, 4) + buffer kernel
         spec = bool(vals[4]) if len(vals) > 4 else False
-        return FlashForwardKernelConfig(DType(vals[0]), 128, 256, 64, 4, True, True, True, 0, 0, 0, True, spec)
+        base = (DType(vals[0]), 128, 256, 64, 4, True, True, True, 0, 0, 0, True, False)
+        return NativeKernelConfig(*base, speculative_softmax=True) if spec else FlashForwardKernelConfig(*base)
     if m.group(1):
         dt, nw, bc, swz, eager, opt = vals[:6]
         rows, pipe = 16, 0
@@ -59,10 +63,15 @@ def symbol_to_config(symbol):
         d_head = vals[10] if len(vals) > 10 else 128
         ksplit = vals[12] if len(vals) > 12 else 1  # key split: KSPLIT waves share a 32-row group
         rows = 32 * qt // ksplit
-        return FlashForwardKernelConfig(DType(dt), d_head, rows * nw, bc, nw, bool(dma), bool(eager), bool(swz),
-                                        0, 0, 0, bool(pipe), bool(opt))
-    return FlashForwardKernelConfig(DType(dt), 128, rows * nw, bc, nw, True, bool(eager), bool(swz),
-                                    0, 0, 0, bool(pipe), bool(opt))
+        masked = bool(vals[9]) if len(vals) > 9 else False
+        base = (DType(dt), d_head, rows * nw, bc, nw, bool(dma), bool(eager), bool(swz), 0, 0, 0, bool(pipe))
+        if opt and eager and dma and not masked:
+            return NativeKernelConfig(*base, False, speculative_softmax=True)
+        return FlashForwardKernelConfig(*base, bool(opt))
+    base = (DType(dt), 128, rows * nw, bc, nw, True, bool(eager), bool(swz), 0, 0, 0, bool(pipe))
+    if opt and eager:
+        return NativeKernelConfig(*base, False, speculative_softmax=True)
+    return FlashForwardKernelConfig(*base, bool(opt))
 
 
 def lds_of(cfg):

@@ -13,6 +13,11 @@ What each fixture pins:
                               -- utils.py:137-162
   block_<case>.npz           O_final of tools/debug/debug.py:block_flash_attention
                               (rows of "warp 2", :50-57) on fp32 copies of bf16 inputs
+  seam_<dtype>.npz           a case big enough that the persistent walk crosses item seams on a 256-CU chip
+                              (3 x 1024 x 24 heads = 288 items of 256 rows) with planted logit spikes in a FIRST and in
+                              a SECOND item of a workgroup (the speculative softmax's second pass): inputs by recipe
+                              (seed + the spikes, rebuilt by tests/conftest.py:build_seam_inputs), outputs of
+                              py_flash_attention as a ROW SAMPLE (every row of the spiked Q blocks + every 64th row)
   configs.json               get_kernels_to_build / progression short forms, FLOP model
                               values -- kernel_configs.py
 Usage:  python oracle/gen_golden.py   (from the repo root)
@@ -57,9 +62,56 @@ def u16(t):
     return t.contiguous().view(torch.int16).numpy().view(np.uint16)
 
 
+SEAM = dict(shape=(3, 1024, 24, 128), seed=17,
+            # (batch, head, key, first q row, q rows, amplitude, sign seed): q rows and the key get amplitude * (+-1 vector)
+            # item numbering of the persistent walk (n_bh = 72, 4 Q blocks): item 5 = (b 0, h 5, Q block 0), ordinal 0;
+            # item 260 = (b 2, h 20, Q block 0), the SECOND item of workgroup 4; the third spike is mild (bf16 stays in
+            # the first pass, fp16 does not)
+            spikes=[(0, 5, 3, 40, 8, 30.0, 1), (2, 20, 700, 100, 4, 30.0, 2), (1, 7, 70, 600, 6, 1.107, 3)])
+
+
+def build_seam_inputs(dtype):
+    """The seam case's q, k, v from its recipe (the same function lives in tests/conftest.py: the GPU box has no copy
+    of this file's reference imports)."""
+    B, S, H, D = SEAM["shape"]
+    gen = torch.Generator().manual_seed(SEAM["seed"])
+    q, k, v = (torch.randn((B, S, H, D), generator=gen).to(dtype) for _ in range(3))
+    for (b, h, key, row0, nrows, amp, sseed) in SEAM["spikes"]:
+        g2 = torch.Generator().manual_seed(1000 + sseed)
+        u = (torch.randint(0, 2, (D,), generator=g2).float() * 2 - 1) * amp
+        k[b, key, h] = u.to(dtype)
+        q[b, row0:row0 + nrows, h] = u.to(dtype)
+    return q, k, v
+
+
+def seam_row_sample():
+    """(batch, row, head) index arrays of the stored sample: the spiked Q blocks whole, and every 64th row of everything."""
+    B, S, H, D = SEAM["shape"]
+    idx = set()
+    for (b, h, key, row0, nrows, amp, sseed) in SEAM["spikes"]:
+        blk = (row0 // 256) * 256
+        idx.update((b, r, h) for r in range(blk, blk + 256))
+    idx.update((b, r, h) for b in range(B) for r in range(5, S, 64) for h in range(H))
+    idx = sorted(idx)
+    return tuple(np.array([t[i] for t in idx], dtype=np.int64) for i in range(3))
+
+
 def main():
     kc, ut, dbg = import_reference()
     os.makedirs(OUT, exist_ok=True)
+    bi, ri, hi = seam_row_sample()
+    for dtype, tag in ((torch.bfloat16, "bf16"), (torch.float16, "fp16")):
+        q, k, v = build_seam_inputs(dtype)
+        o_b16 = ut.py_flash_attention(q, k, v, upcast=False)
+        o_f32 = ut.py_flash_attention(q, k, v, upcast=True)
+        np.savez_compressed(
+            os.path.join(OUT, f"seam_{tag}.npz"),
+            shape=np.array(SEAM["shape"]), seed=np.array(SEAM["seed"]), spikes=np.array(SEAM["spikes"], dtype=np.float64),
+            b=bi.astype(np.int16), r=ri.astype(np.int16), h=hi.astype(np.int16),
+            o_b16=u16(o_b16[bi, ri, hi]), o_f32=u16(o_f32[bi, ri, hi]),
+            # a checksum of the rebuilt inputs, so a different torch RNG cannot silently change the case
+            qkv_sum=np.array([float(t.float().sum()) for t in (q, k, v)]),
+        )
     for dtype, tag in ((torch.bfloat16, "bf16"), (torch.float16, "fp16")):
         for name, (B, S, H, D, seed) in CASES.items():
             torch.manual_seed(seed)

@@ -20,11 +20,12 @@ import torch
 pytestmark = pytest.mark.gpu
 
 import flash_attention  # noqa: E402
+import flash_attention_kernels  # noqa: E402
 from flash_attention_from_scratch_amd import _capi  # noqa: E402
 from flash_helpers import kernel_configs as kc  # noqa: E402
 from flash_helpers.test import utils as ut  # noqa: E402
 from oracle import fa_oracle as fo  # noqa: E402
-from tests.conftest import load_eager_golden  # noqa: E402
+from tests.conftest import load_eager_golden, load_seam_golden  # noqa: E402
 
 DEV = "cuda:0"
 TOL = {torch.bfloat16: 2.0 ** -7, torch.float16: 2.0 ** -10}
@@ -91,6 +92,66 @@ def test_golden_fixtures(cfg, case):
     assert lhs <= rhs, (lhs, rhs)
     ref = fo.blockwise_for_config(cfg, g["q"], g["k"], g["v"])
     assert (out.float() - ref.float()).abs().max().item() <= TOL[g["dtype"]]
+
+
+@pytest.mark.parametrize("tag", ["bf16", "fp16"])
+def test_seam_golden_with_spikes_and_the_redo_counter(tag):
+    """The reference-generated fixture that reaches what the small ones cannot (tests/golden/seam_*.npz, rebuilt from its
+    recipe): 288 items of 256 rows -- more than the chip has CUs, so the persistent walk crosses item seams -- with logit
+    spikes in a FIRST item (item 5) and a SECOND item (item 260) of a workgroup and a mild one (20 binades: bf16 stays
+    in the first pass, fp16 does not).  Every form of the persistent kernel and the reference's winning shape against
+    the stored rows of the reference's eager outputs; and fa_fwd_stats counts exactly the items that ran twice."""
+    g = load_seam_golden(tag)
+    dtype, name = g["dtype"], {"bf16": kc.DType.BF16, "fp16": kc.DType.FP16}[tag]
+    q, k, v = (g[n].to(DEV) for n in ("q", "k", "v"))
+    b, r, h = g["b"], g["r"], g["h"]
+    tol = TOL[dtype] * (1 + g["o_f32"].float().abs())
+    sane = torch.isfinite(g["o_b16"].float()).all(dim=-1)   # (fp16: the reference's 16-bit eager overflows on the 30-sigma rows)
+    n_items = {256: 3 * 24 * 4, 128: 3 * 24 * 8}
+    for cfg, redone in ((_persistent_cfg(name, True), 2 if tag == "bf16" else 3), (_persistent_cfg(name, False), 0),
+                        (_native(name, 128, 64, 4, True, True), 2 if tag == "bf16" else 3), (_native(name, 128, 64, 4, True, False), 0),
+                        (kc.FlashForwardKernelConfig(name, 128, 128, 64, 4, True, True, True, 2, 2, 0, True, True), 0)):
+        stats = torch.zeros(2, dtype=torch.int32, device=DEV)
+        out, _ = flash_attention_kernels.forward(cfg, q, k, v, None, stats=stats)
+        got = out.cpu()[b, r, h]
+        assert torch.isfinite(out.float()).all(), str(cfg)
+        assert ((got.float() - g["o_f32"].float()).abs() <= tol).all(), str(cfg)
+        lhs, rhs = fo.tolerance_rule(got[sane], g["o_b16"][sane], g["o_f32"][sane])
+        assert lhs <= rhs, (str(cfg), lhs, rhs)
+        assert stats.tolist() == [n_items[cfg.B_r], redone], (str(cfg), stats.tolist())
+        # the counters ADD: a second launch doubles them; and without the pointer nothing changes
+        flash_attention_kernels.forward(cfg, q, k, v, out, stats=stats)
+        assert stats.tolist() == [2 * n_items[cfg.B_r], 2 * redone]
+        assert torch.equal(flash_attention.forward(cfg, q, k, v), out)
+
+
+def test_optimized_softmax_keeps_the_reference_meaning(monkeypatch):
+    """One flag, one meaning: a plain 13-field config with optimized_softmax (what a reference user passes, e.g. the
+    A100 winner of kernel_sass/16_A100.asm:5 plus the RTX 3090 winner's flag) computes the reference's arithmetic -- the
+    first-block skip changes nothing, so the result is BIT-identical to the same config without the flag -- and never
+    the speculative softmax: a spike that would send that one through its second pass is not counted as redone.  Under
+    FA_ALLOW_SPECULATIVE=1 the round-2 mapping is back (the counter sees it)."""
+    from flash_helpers.kernel_configs import parse_kernel_name_into_config as parse
+    a100 = parse("(FP16, 128, 128, 64, 4): async+eager+swizzled+load_2_2_0_tiles+buffer+opt_softmax")
+    for cfg in (a100, replace(a100, dtype=kc.DType.BF16), replace(a100, B_r=64, B_c=32, Q_mma_load_K_tiles=2, K_mma_load_K_tiles=2)):
+        monkeypatch.delenv("FA_ALLOW_SPECULATIVE", raising=False)
+        dtype = cfg.dtype.to_torch_dtype()
+        qc = ut.QKVConfig(n_heads=3, d_head=128, batch_size=2, seq_len=1024, dtype=dtype, device=torch.device(DEV))
+        q, k, v = ut.generate_qkv(qc, seed=23)
+        u = _sign_vector(5).to(dtype)
+        k[1, 3, 2] = 30.0 * u
+        q[1, 600:604, 2] = 30.0 * u
+        stats = torch.zeros(2, dtype=torch.int32, device=DEV)
+        out, _ = flash_attention_kernels.forward(cfg, q, k, v, None, stats=stats)
+        assert kc.softmax_mode(cfg) == "eager" and stats[1].item() == 0
+        assert torch.equal(out, flash_attention.forward(replace(cfg, optimized_softmax=False), q, k, v))
+        monkeypatch.setenv("FA_ALLOW_SPECULATIVE", "1")
+        stats.zero_()
+        out2, _ = flash_attention_kernels.forward(cfg, q, k, v, None, stats=stats)
+        assert kc.softmax_mode(cfg) == "speculative" and stats[1].item() == 1
+        ref = ut.py_flash_attention(q, k, v, upcast=True).float()
+        for o in (out, out2):
+            assert ((o.float() - ref).abs() <= TOL[dtype] * (1 + ref.abs())).all()
 
 
 @pytest.fixture(scope="module", params=[torch.bfloat16, torch.float16], ids=["bf16", "fp16"])

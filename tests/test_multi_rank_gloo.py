@@ -95,3 +95,27 @@ def test_bench_launches_its_own_ranks(n):
     assert 2.0 <= rec["ms_per_step"] < 50.0          # five 2-ms sleeps per rank, max over ranks
     # the aggregate is N ranks' work over the slowest rank's time: never more than the sum of the ranks
     assert rec["value"] <= sum(rec["per_gpu_tflops"]) * (1 + 1e-9)
+
+
+def test_scale_command_dry_run_eight_ranks_on_c4():
+    """The documented SCALE command is `python bench.py --gpus 8 --workload c4` (BASELINE.json configs[4]: B=64 H=32
+    S=8192 bf16 as eight batch shards of 8, no collective).  Its launcher, shard arithmetic, barrier-bracketed timing and
+    per-rank gather run here with eight gloo ranks and a sleeping step (--cpu-dry-run); no --steps: the default applies."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--workload", "c4", "--warmup", "1",
+                          "--cpu-dry-run"], env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 8 and rec["scaling"] == "weak" and len(rec["per_gpu_tflops"]) == 8
+    assert rec["config"]["global_batch"] == 64 and rec["config"]["heads"] == 32 and rec["config"]["seq_len"] == 8192
+    assert rec["config"]["shards"] == [[8 * r, 8 * r + 8] for r in range(8)]
+    assert rec["config"]["flop_per_step_per_gpu"] == 8796093022208          # BASELINE.md: C4 per GPU
+    assert 8 * rec["config"]["flop_per_step_per_gpu"] == 70368744177664     # ... and the whole job
+    assert rec["value"] <= sum(rec["per_gpu_tflops"]) * (1 + 1e-9)

@@ -4,6 +4,7 @@ import textwrap
 
 from flash_attention_from_scratch_amd.tools import isa_lint64, isa_stats, kernel_resources, rocprof_bench
 from flash_helpers import kernel_configs as kc
+from tests.conftest import ROOT
 
 SAMPLE_ASM = textwrap.dedent("""\
     \t.text
@@ -40,11 +41,15 @@ def test_symbol_and_mangled_name_round_trip_to_config():
     cfg = rocprof_bench.symbol_to_config("void fa::fa_fwd_kernel<15, 1, 8, 64, true, true, false, true, true, false, 128, 0>(fa::KernelArgs)")
     assert cfg == kc.FlashForwardKernelConfig(kc.DType.BF16, 128, 256, 64, 8, True, True, True, 0, 0, 0, True, False)
     cfg16 = rocprof_bench.symbol_to_config("void fa::fa_fwd_kernel16<5, 4, 32, true, true, true>(fa::KernelArgs)")
-    assert (cfg16.dtype, cfg16.B_r, cfg16.B_c, cfg16.n_warps, cfg16.optimized_softmax) == (kc.DType.FP16, 64, 32, 4, True)
+    # (OPT on a double-buffered LDS-DMA variant builds the speculative softmax: a native config, optimized_softmax unset)
+    assert (cfg16.dtype, cfg16.B_r, cfg16.B_c, cfg16.n_warps, cfg16.optimized_softmax, cfg16.speculative_softmax) == \
+        (kc.DType.FP16, 64, 32, 4, False, True)
+    fbs = rocprof_bench.symbol_to_config("void fa::fa_fwd_kernel<15, 1, 8, 64, true, true, true, false, false, false, 128, 0>(fa::KernelArgs)")
+    assert fbs.optimized_softmax and not kc.wants_speculative(fbs) and kc.softmax_mode(fbs) == "first_block_skip"   # register-staged
     cfg_ks = rocprof_bench.symbol_to_config("void fa::fa_fwd_kernel<5, 1, 4, 64, true, true, false, true, true, false, 128, 0, 2>(fa::KernelArgs)")
     assert (cfg_ks.B_r, cfg_ks.B_c, cfg_ks.n_warps, cfg_ks.mma_double_buffer_loads) == (64, 64, 4, True)
     cfg_spec = rocprof_bench.symbol_to_config("void fa::fa_fwd_kernel64<15, false, 0, false, true>(fa::KernelArgs)")
-    assert cfg_spec.optimized_softmax and (cfg_spec.B_r, cfg_spec.n_warps) == (256, 4)
+    assert cfg_spec == kc.best_config(kc.DType.BF16) and kc.softmax_mode(cfg_spec) == "speculative"
     cfg64 = rocprof_bench.symbol_to_config("void fa::fa_fwd_kernel64<15, false, 0>(fa::KernelArgs)")
     assert cfg64 == kc.FlashForwardKernelConfig(kc.DType.BF16, 128, 256, 64, 4, True, True, True, 0, 0, 0, True, False)
     assert kernel_resources.demangle_variant("_ZN2fa15fa_fwd_kernel64ILi5ELb1ELi0EEEvNS_10KernelArgsE")["masked"] == 2
@@ -290,3 +295,37 @@ def test_isa_lint_on_the_built_64_row_kernels(tmp_path):
     assert "scratch_" not in text
     assert isa_lint64.lint(str(out), window=4, raw=3) == []
     assert len(isa_lint64.split_kernels(str(out))) >= 6  # (plain, plain fp16, causal, ragged, speculative x 2)
+
+
+def test_visit_histogram_matches_the_committed_digest():
+    """Toolchain pin (profiles/r03/toolchain.json, tools/isa_digest.py): the hand-placed visit of the persistent kernel
+    must come out of THIS hipcc as the plan dealt it -- per visit 64 MFMAs, 64 v_exp_f32, 64 v_fmamk (c applied in fp32,
+    softmax.cuh:51-64), 64 row-sum adds, 32 packs, 48 LDS operand reads (16 ds_read_b128 + 32 ds_read_b64_tr_b16), 8 LDS-DMA
+    pieces, and in the speculative first pass no row max, no lane spill and no accumulator copy -- and as the digest the
+    round's measurements belong to recorded it.  A compiler upgrade (or any source change) that moves it fails here: look
+    at the new ISA, re-measure, then regenerate the digest (python flash_attention_from_scratch_amd/tools/isa_digest.py
+    --write profiles/r03/toolchain.json)."""
+    import json
+
+    from flash_attention_from_scratch_amd.tools import isa_digest
+
+    got = isa_digest.digest()
+    assert got is not None, "the build keeps the ISA of every slice under csrc/build (make -C flash_attention_from_scratch_amd/csrc)"
+    for name, visits in got["kernels"].items():
+        assert visits and len(visits) in (4, 8), (name, len(visits or []))   # one walk (lazy) or two (speculative + its second pass)
+        for i, v in enumerate(visits):
+            assert v["mfma"] in (61, 64) and v["ds_read_b128"] == (16 if v["mfma"] == 64 else 14), (name, i, v)
+            assert (v["v_exp_f32"], v["v_cvt_pk"], v["ds_read_b64_tr_b16"], v["global_load_lds_dwordx4"]) in ((64, 32, 32, 8), (65, 32, 32, 8)), (name, i, v)
+            # (64 v_accvgpr_mov: the next item's Q swapped in behind the visit that ends an item -- a branch-guarded tail of
+            # that label's block, not part of the steady state)
+            # the lazy walk's rare rescale path (128 accumulator reads + writes per Q tile) is such a tail too)
+            assert v["v_readlane_b32"] == 0 and v["v_writelane_b32"] == 0, (name, i, v)
+            assert v["v_accvgpr"] in (0, 64) or ("speculative" not in name or i >= 4), (name, i, v)
+        if "speculative" in name:
+            first_pass = visits[:4]
+            assert all(v["v_max3_f32"] == 0 and v["v_exp_f32"] == 64 and v["v_fmamk_f32"] == 64 and v["v_add_f32"] == 64 for v in first_pass), name
+            assert all(v["v_max3_f32"] > 0 for v in visits[4:]), name   # the second pass keeps the running max
+    want = json.load(open(os.path.join(ROOT, "profiles", "r03", "toolchain.json")))
+    assert got["hipcc"] == want["hipcc"], ("the compiler changed: every hand-placed schedule needs re-verification on the GPU "
+                                           "(pytest -m gpu, tools/soak.py, bench.py) before the digest is regenerated", got["hipcc"])
+    assert got["kernels"] == want["kernels"], "the visit's instruction histogram moved: see the docstring"

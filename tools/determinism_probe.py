@@ -13,7 +13,7 @@ os.environ['KERNELS']='all'
 cfgs=kc.get_kernel_configs()
 seen=set(); uniq=[]
 for c in cfgs:
-    key=(c.dtype,c.B_r,c.B_c,c.n_warps,c.async_copy,c.eager_load_blocks,c.swizzled,c.optimized_softmax,c.mma_double_buffer_loads)
+    key=(c.dtype,c.B_r,c.B_c,c.n_warps,c.async_copy,c.eager_load_blocks,c.swizzled,c.optimized_softmax,kc.wants_speculative(c),c.mma_double_buffer_loads)
     if key in seen: continue
     seen.add(key); uniq.append(c)
 print(len(uniq),'variants')

@@ -23,7 +23,7 @@ def main():
     t0, n, bad = time.time(), 0, 0
     while time.time() - t0 < budget:
         dtype, name = rng.choice(((torch.bfloat16, kc.DType.BF16), (torch.float16, kc.DType.FP16)))
-        cfg = kc.FlashForwardKernelConfig(name, 128, 256, 64, 4, True, True, True, 0, 0, 0, True, rng.random() < 0.8)
+        cfg = kc.NativeKernelConfig(name, 128, 256, 64, 4, True, True, True, 0, 0, 0, True, False, speculative_softmax=rng.random() < 0.8)
         mode = rng.choice(["plain", "causal", "ragged", "ragged-causal"])
         S = rng.choice([256, 512, 768]) if mode in ("plain", "causal") else rng.choice([300, 500, 700])
         H = rng.choice([8, 32, 64, 128, 100])
@@ -48,7 +48,7 @@ def main():
         n += 1
         if not ok:
             bad += 1
-            print("FAIL", str(dtype), cfg.optimized_softmax, mode, B, H, S, "items per workgroup", B * H * ((S + 255) // 256) / 256, flush=True)
+            print("FAIL", str(dtype), cfg.speculative_softmax, mode, B, H, S, "items per workgroup", B * H * ((S + 255) // 256) / 256, flush=True)
     print(f"soak (many items): {n} launches x 2 in {time.time() - t0:.0f} s, {bad} failures")
     sys.exit(1 if bad else 0)
 
