@@ -115,11 +115,18 @@ constexpr bool plan64_ok(const Plan64 &p) {
 // a limit that proves nothing overflowed (fp32 exp2, the 16-bit P, the accumulators), and an item that
 // fails -- a row whose logits rise ~100 (bf16) / ~15 (fp16) binades above its first tile's max -- is
 // run again by the lazy-rescale schedule (walk<SAFE>, the whole of the non-SPEC kernel) after the walk.
-template <int DT, bool MASK = false, int ABL = 0, bool RAG = false, bool SPEC = false>
+// PSQ (fa_fwd_opts.prescaled_q; NOT the reference's arithmetic, which multiplies every logit by
+// c = log2(e) / sqrt(d) in fp32, softmax.cuh:51-64): Q is multiplied by c and rounded to 16 bit once, on its way from LDS
+// into the accumulator file, so the MFMA delivers s c directly.  In the speculative first pass the item's reference
+// -(m c) rides in the C operand of each S tile's first MFMA (a 16-register splat per Q tile, constant over the item)
+// and the softmax unit is just exp2, row sum, pack: 160 instead of 224 vector instructions per visit.  The second pass
+// (running max, which moves) adds -(m c) with one v_add per logit where the exact kernel has its v_fma.
+template <int DT, bool MASK = false, int ABL = 0, bool RAG = false, bool SPEC = false, bool PSQ = false>
 __global__ void
 __launch_bounds__(256, 1)
 fa_fwd_kernel64(const KernelArgs args) {
     static_assert(!RAG || MASK, "the ragged form is a masked variant");
+    static_assert(!PSQ || !MASK, "the pre-scaled Q is built for the plain form");
     constexpr int QT = 2, NWAVES = 4, BC = 64, D = 128;
     constexpr bool SWZ = true, EAGER = true, PIPE = true, DMA = true;
 
@@ -284,6 +291,7 @@ fa_fwd_kernel64(const KernelArgs args) {
     auto barrier = [&]() { if (!(ABL & 8)) wg_barrier(); };
     // forward_kernel.cuh:150-151 (fp32 product of rsqrt(d) and log2 e)
     const float c = (float)((double)(1.0f / __builtin_sqrtf((float)D)) * 1.4426950408889634074);
+    const float cs = PSQ ? 1.0f : c;  // what turns an S element into a base-2 exponent (PSQ: the scale already sits in Q)
 
     // per-lane LDS read offsets
     //   K A-operand: row 32*nt + r31, chunk (2*ks + hi) ^ (r31 & 15)
@@ -417,10 +425,47 @@ fa_fwd_kernel64(const KernelArgs args) {
                 av.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((FA_LDS(s16x4) *)(vp + DSUB * 512));
                 return __builtin_bit_cast(vec8, av);
             };
+            // PSQ, speculative first pass: C operand of the first MFMA of every S tile = -(m c) of the row this lane
+            // owns, 16 equal registers per Q tile, constant over an item.  Zero while the NEXT item's S(0) is formed (an
+            // item's last visit, and the prologue): its reference is its own row max, subtracted once it is known.
+            f32x16 Cinit[2];
+            if constexpr (PSQ && FAST) {
+#pragma unroll
+                for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) Cinit[qt][r] = 0.0f;
+            }
+            auto zero_cinit = [&]() {
+                if constexpr (PSQ && FAST) {
+#pragma unroll
+                    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) Cinit[qt][r] = 0.0f;
+                    asm volatile("s_nop 1" : "+v"(Cinit[0]), "+v"(Cinit[1]));  // VALU write -> MFMA C read
+                }
+            };
+            auto set_cinit = [&](auto &S0) {  // S0 = the item's S(0), formed against C = 0: bring it to the reference too
+                if constexpr (PSQ && FAST) {
+#pragma unroll
+                    for (int qt = 0; qt < 2; ++qt) {
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) S0[qt][nt][r] = vadd(S0[qt][nt][r], neg_msc[qt]);
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) Cinit[qt][r] = neg_msc[qt];
+                    }
+                    asm volatile("s_nop 1" : "+v"(Cinit[0]), "+v"(Cinit[1]));
+                }
+            };
             auto qk_mfma = [&](auto &S, int step, int qt, vec8 a) {
                 const int ks = step >> 1, nt = step & 1;
-                if (ks == 0) E::mfma_acc_v_q0(S[qt][nt], a, Qr[qt][ks]);
-                else E::mfma_acc_v_q(S[qt][nt], a, Qr[qt][ks]);
+                if (ks == 0) {
+                    if constexpr (PSQ && FAST) E::mfma_acc_v_qc(S[qt][nt], a, Qr[qt][ks], Cinit[qt]);
+                    else E::mfma_acc_v_q0(S[qt][nt], a, Qr[qt][ks]);
+                } else {
+                    E::mfma_acc_v_q(S[qt][nt], a, Qr[qt][ks]);
+                }
             };
             // ---- persistent walk over items; the K / V tile stream runs on across item seams --------
             // This workgroup serves items blockIdx.x, + gridDim.x, ...  Tiles are numbered along the
@@ -557,6 +602,30 @@ fa_fwd_kernel64(const KernelArgs args) {
             auto read_q = [&](vec8 (&dst)[KS], unsigned stage) {  // this lane's chunks: row l % 32, chunk (2 ks + l/32) ^ (row & 15)
                 const int l_ = lane_now();
                 const unsigned base = stage + (l_ & 31) * 256, x = (unsigned)((l_ >> 5) ^ (l_ & 15));
+                if constexpr (PSQ) {
+                    // through VGPRs: Q * c in fp32, RNE to 16 bit (the one rounding this option adds), then into the
+                    // accumulator file.  Two chunks at a time (register pressure: S(0) of the next item may be live).
+#pragma unroll
+                    for (int ks = 0; ks < KS; ks += 2) {
+                        vec8 t0, t1;
+                        asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3\n\ts_waitcnt lgkmcnt(0)"
+                                     : "=&v"(t0), "=&v"(t1)
+                                     : "v"(base + ((x ^ (2 * ks)) << 4)), "v"(base + ((x ^ (2 * ks + 2)) << 4))
+                                     : "memory");
+                        float f0[8], f1[8];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            f0[j] = (float)t0[j] * c;
+                            f1[j] = (float)t1[j] * c;
+                        }
+                        dst[ks] = E::pack8(f0);
+                        dst[ks + 1] = E::pack8(f1);
+                    }
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+a"(dst[ks]));  // in the accumulator file from here on
+                    asm volatile("s_nop 3" ::: "memory");  // accvgpr write -> MFMA operand
+                    return;
+                }
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks)
                     asm volatile("ds_read_b128 %0, %1" : "=a"(dst[ks]) : "v"(base + ((x ^ (2 * ks)) << 4)) : "memory");
@@ -622,6 +691,7 @@ fa_fwd_kernel64(const KernelArgs args) {
                                 Qr[qt][ks] = Qr2[qt][ks];
                             }
                         asm volatile("s_nop 3" ::: "memory");  // accvgpr write -> MFMA operand
+                        zero_cinit();  // this visit forms the NEXT item's S(0): no reference yet
                     }
                 }
                 if constexpr (plan.barrier[2] == 0) {
@@ -636,10 +706,10 @@ fa_fwd_kernel64(const KernelArgs args) {
                     for (int qt = 0; qt < 2; ++qt) {
                         if (!(resc_any & (1u << qt))) continue;
                         const float m_new = fmaxf(m[qt], m_pend[qt]);
-                        const float alpha = __builtin_amdgcn_exp2f((m[qt] - m_new) * c);
+                        const float alpha = __builtin_amdgcn_exp2f((m[qt] - m_new) * cs);
                         m[qt] = m_new;
-                        neg_msc[qt] = -(finite_or_zero(m_new) * c);
-                        thr[qt] = m_new + TAU / c;
+                        neg_msc[qt] = -(finite_or_zero(m_new) * cs);
+                        thr[qt] = m_new + TAU / cs;
                         rs[qt][0] *= alpha;
                         rs[qt][1] *= alpha;
 #pragma unroll
@@ -671,6 +741,12 @@ fa_fwd_kernel64(const KernelArgs args) {
                     if constexpr (ABL & 2048) {  // (timing only: what a pre-scaled Q with -m c fed through the MFMA's C operand would save)
                         p0 = S_cur[qt][s16 >> 1][r];
                         p1 = S_cur[qt][s16 >> 1][r + 1];
+                    } else if constexpr (PSQ && FAST) {  // -(m c) came in through the C operand of the tile's first MFMA
+                        p0 = S_cur[qt][s16 >> 1][r];
+                        p1 = S_cur[qt][s16 >> 1][r + 1];
+                    } else if constexpr (PSQ) {
+                        p0 = vadd(S_cur[qt][s16 >> 1][r], neg_msc[qt]);
+                        p1 = vadd(S_cur[qt][s16 >> 1][r + 1], neg_msc[qt]);
                     } else {
                         p0 = __builtin_fmaf(S_cur[qt][s16 >> 1][r], c, neg_msc[qt]);
                         p1 = __builtin_fmaf(S_cur[qt][s16 >> 1][r + 1], c, neg_msc[qt]);
@@ -930,10 +1006,11 @@ fa_fwd_kernel64(const KernelArgs args) {
 #pragma unroll
                         for (int r = 0; r < 16; ++r) v = fmaxf(v, Sa[qt][nt][r]);
                     m[qt] = pair_max(v);
-                    neg_msc[qt] = -(finite_or_zero(m[qt]) * c);
-                    thr[qt] = m[qt] + TAU / c;
+                    neg_msc[qt] = -(finite_or_zero(m[qt]) * cs);
+                    thr[qt] = m[qt] + TAU / cs;
                     m_pend[qt] = m[qt];
                 }
+                set_cinit(Sa);
                 if (!(ABL & 8)) {  // K(1) landed (under S(0))
                     if (has_next) asm volatile("s_waitcnt vmcnt(28)" ::: "memory");
                     else asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
@@ -1086,11 +1163,12 @@ fa_fwd_kernel64(const KernelArgs args) {
 #pragma unroll
                 for (int qt = 0; qt < 2; ++qt) {
                     m[qt] = mraw[qt];
-                    neg_msc[qt] = -(finite_or_zero(m[qt]) * c);
-                    thr[qt] = m[qt] + TAU / c;
+                    neg_msc[qt] = -(finite_or_zero(m[qt]) * cs);
+                    thr[qt] = m[qt] + TAU / cs;
                     m_pend[qt] = m[qt];
                     rs[qt][0] = rs[qt][1] = 0.0f;
                 }
+                set_cinit(Sa);
 #if defined(FA_TRACE) && FA_TRACE >= 4
                 if (tl_seam) tl_at(55);  // row max of S(0), softmax state reset
 #endif

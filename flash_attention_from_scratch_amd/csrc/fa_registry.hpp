@@ -67,6 +67,16 @@ constexpr KernelEntry make_entry() {
     }
 }
 
+// The persistent kernel with the pre-scaled Q (fa_fwd_opts.prescaled_q): plain form only.
+template <int DT, bool OPT>
+constexpr KernelEntry make_entry_psq() {
+    using TR = FwdTraits<DT, 2, 4, 64, true, true, OPT, true, true, false, 128>;
+    static_assert(TR::kPersistent, "the 64-row pinned schedule");
+    return KernelEntry{DT, 64, 4, 64, 1, 1, OPT, 1, 1, 0, 128, TR::kThreads, TR::kLdsBytes, 1,
+                       (kernel_fn)&fa_fwd_kernel64<DT, false, 0, false, OPT, true>, nullptr,
+                       softmax_mode_of(true, OPT, true, true, false), 1};
+}
+
 // (B_r 64, B_c 64, 4 waves): the key-split form of the 32-rows-per-wave kernel (KSPLIT = 2 in
 // fa_fwd_kernel.hpp); registered under B_r / n_warps = 16 rows per wave, which is how configs find it
 template <int DT, bool SWZ, bool EAGER, bool OPT, bool PIPE>

@@ -456,6 +456,9 @@ def get_native_kernel_configs(dtypes=(DType.BF16, DType.FP16)):
                             out.append(NativeKernelConfig(*base, False, speculative_softmax=True))
                         else:
                             out.append(FlashForwardKernelConfig(*base, second))
+                        if (B_r, B_c, n_waves, dma, pipelined) == (256, 64, 4, True, True):
+                            # the persistent kernel with the pre-scaled Q, with / without the speculative softmax
+                            out.append(NativeKernelConfig(*base, False, speculative_softmax=second, prescaled_q=True))
     return out
 
 

@@ -226,10 +226,21 @@ def lint(path, window=3, raw=2, only=None):
             j = kinds.find("v" * 32 + "a" * 32, pos)
             if j < 0:
                 break
+            # (a copy that touches none of the visit's own matrix registers -- O, the accumulators, and Q, the B operands --
+            # is not one of those: the pre-scaled Q of the NEXT item is written into the spare Q set on the slow path of an
+            # item's first visits, through VGPRs, while the MFMAs work on the current set)
+            used = set()
+            for i in mf[j:j + 64]:
+                for tok in code[i].split()[1:]:
+                    used |= {r for r in regs2(tok) if r[0] == "a"}
             for i in range(mf[j + 2], mf[j + 63] + 1):
                 if code[i].startswith("v_accvgpr_"):
-                    findings.append(("AGPR", kidx, i, code[mf[j + 63]], code[i]))
-                    break
+                    touched = set()
+                    for tok in code[i].split()[1:]:
+                        touched |= {r for r in regs2(tok) if r[0] == "a"}
+                    if touched & used:
+                        findings.append(("AGPR", kidx, i, code[mf[j + 63]], code[i]))
+                        break
             pos = j + 64
     return findings
 

@@ -98,6 +98,7 @@ typedef struct {
     int dtype;
     int64_t batch, seq, heads, d;
     int64_t bs, ss, hs; /* strides in elements, flash_attention.cu:84-86 */
+    int prescale_q;     /* NOT the reference's arithmetic: logits from a 16-bit Q * c (the device's pre-scaled-Q option) */
 } tensors_t;
 
 /*
@@ -123,7 +124,10 @@ static void q_block_forward(const tensors_t *t, int64_t b, int64_t h, int64_t qb
         if (need < n_kv) n_kv = need;
     }
     /* forward_kernel.cuh:150-151: rsqrt(d) * M_LOG2E evaluated in fp32 */
-    const float c = (float)((double)(1.0f / sqrtf((float)d)) * M_LOG2E);
+    const float c_ref = (float)((double)(1.0f / sqrtf((float)d)) * M_LOG2E);
+    /* pre-scaled Q (fa_fwd_opts.prescaled_q): Q' = RNE16(Q * c) once, then the exponent is the raw dot
+     * product K . Q' -- c applied BEFORE the 16-bit rounding of Q instead of in fp32 behind the dot product */
+    const float c = t->prescale_q ? 1.0f : c_ref;
     for (int r = 0; r < B_r; ++r) { m[r] = -INFINITY; l[r] = 0.0f; }
     memset(O, 0, sizeof(float) * B_r * d);
 
@@ -133,7 +137,10 @@ static void q_block_forward(const tensors_t *t, int64_t b, int64_t h, int64_t qb
         for (int r = 0; r < rows; ++r) {
             const int64_t qi = qb * B_r + r;
             const uint16_t *qp = t->q + b * t->bs + qi * t->ss + h * t->hs;
-            for (int64_t x = 0; x < d; ++x) qrow[x] = b16_to_f32(qp[x], t->dtype);
+            for (int64_t x = 0; x < d; ++x) {
+                qrow[x] = b16_to_f32(qp[x], t->dtype);
+                if (t->prescale_q) qrow[x] = round_b16(qrow[x] * c_ref, t->dtype);
+            }
             for (int cidx = 0; cidx < B_c; ++cidx) {
                 const int64_t key = blk * B_c + cidx;
                 if (key >= t->seq || (causal && key > qi)) { S[r * B_c + cidx] = -INFINITY; continue; }
@@ -245,12 +252,13 @@ static int blockwise_impl(const uint16_t *q, const uint16_t *k, const uint16_t *
                           int64_t heads, int64_t d_head, int64_t batch_stride,
                           int64_t seq_stride, int64_t head_stride, int B_r, int B_c,
                           int round_p, int optimized_softmax, float *m_trace,
-                          float *l_trace, int n_threads, int masked, int causal, float lazy_tau) {
+                          float *l_trace, int n_threads, int masked, int causal, float lazy_tau,
+                          int prescale_q) {
     if (dtype != FA_ORACLE_FP16 && dtype != FA_ORACLE_BF16) return -1;
     if (B_r <= 0 || B_c <= 0 || seq <= 0) return -2;
     if (!masked && (seq % B_r != 0 || seq % B_c != 0)) return -2;
     tensors_t t = {q, k, v, o, dtype, batch, seq, heads, d_head,
-                   batch_stride, seq_stride, head_stride};
+                   batch_stride, seq_stride, head_stride, prescale_q};
     const int64_t n_heads_total = batch * heads;
     const int64_t n_q = (seq + B_r - 1) / B_r;
     int failed = 0;
@@ -300,7 +308,7 @@ int fa_oracle_forward_blockwise(const uint16_t *q, const uint16_t *k, const uint
                                 float *l_trace, int n_threads) {
     return blockwise_impl(q, k, v, o, dtype, batch, seq, heads, d_head, batch_stride, seq_stride,
                           head_stride, B_r, B_c, round_p, optimized_softmax, m_trace, l_trace,
-                          n_threads, 0, 0, 0.0f);
+                          n_threads, 0, 0, 0.0f, 0);
 }
 
 /* The lazy-rescale restatement (see q_block_forward): pins the 64-rows-per-wave device variant. */
@@ -310,7 +318,17 @@ int fa_oracle_forward_blockwise_lazy(const uint16_t *q, const uint16_t *k, const
                                      int64_t seq_stride, int64_t head_stride, int B_r, int B_c,
                                      float tau, int n_threads) {
     return blockwise_impl(q, k, v, o, dtype, batch, seq, heads, d_head, batch_stride, seq_stride,
-                          head_stride, B_r, B_c, 1, 0, NULL, NULL, n_threads, 0, 0, tau);
+                          head_stride, B_r, B_c, 1, 0, NULL, NULL, n_threads, 0, 0, tau, 0);
+}
+
+/* ... with the pre-scaled Q (tensors_t.prescale_q): the restatement of fa_fwd_opts.prescaled_q on the same kernel. */
+int fa_oracle_forward_blockwise_lazy_psq(const uint16_t *q, const uint16_t *k, const uint16_t *v,
+                                         uint16_t *o, int dtype, int64_t batch, int64_t seq,
+                                         int64_t heads, int64_t d_head, int64_t batch_stride,
+                                         int64_t seq_stride, int64_t head_stride, int B_r, int B_c,
+                                         float tau, int n_threads) {
+    return blockwise_impl(q, k, v, o, dtype, batch, seq, heads, d_head, batch_stride, seq_stride,
+                          head_stride, B_r, B_c, 1, 0, NULL, NULL, n_threads, 0, 0, tau, 1);
 }
 
 /* Widened modes (causal mask, any seq): same arithmetic, see q_block_forward. */
@@ -321,7 +339,7 @@ int fa_oracle_forward_blockwise_masked(const uint16_t *q, const uint16_t *k, con
                                        int optimized_softmax, int causal, int n_threads) {
     return blockwise_impl(q, k, v, o, dtype, batch, seq, heads, d_head, batch_stride, seq_stride,
                           head_stride, B_r, B_c, 1, optimized_softmax, NULL, NULL, n_threads, 1,
-                          causal, 0.0f);
+                          causal, 0.0f, 0);
 }
 
 /*

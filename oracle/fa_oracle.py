@@ -68,6 +68,8 @@ def lib():
             u16p, u16p, u16p, u16p, ctypes.c_int, i64, i64, i64, i64, i64, i64, i64,
             ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_int,
         ]
+        L.fa_oracle_forward_blockwise_lazy_psq.restype = ctypes.c_int
+        L.fa_oracle_forward_blockwise_lazy_psq.argtypes = L.fa_oracle_forward_blockwise_lazy.argtypes
         L.fa_oracle_forward_eager.restype = ctypes.c_int
         L.fa_oracle_forward_eager.argtypes = [
             u16p, u16p, u16p, u16p, ctypes.c_void_p, ctypes.c_int, i64, i64, i64, i64,
@@ -118,14 +120,17 @@ def blockwise_forward(q, k, v, B_r, B_c, round_p=True, optimized_softmax=False,
     return (o, m, l) if return_stats else o
 
 
-def blockwise_forward_lazy(q, k, v, B_r, B_c, tau=8.0, n_threads=0):
+def blockwise_forward_lazy(q, k, v, B_r, B_c, tau=8.0, n_threads=0, prescaled_q=False):
     """Lazy-rescale restatement (NOT the reference's arithmetic: the MI355X 64-rows-per-wave
     variant's): O and l stay relative to a reference max that moves only when a row's max rose by
-    more than `tau` in the base-2 exponent somewhere in its 32-row group."""
+    more than `tau` in the base-2 exponent somewhere in its 32-row group.
+    prescaled_q: the device's pre-scaled-Q option -- Q * c rounded to 16 bit once, the
+    exponent is then the raw dot product."""
     _check(q, k, v)
     B, S, H, D = q.shape
     o = torch.empty_like(q)
-    rc = lib().fa_oracle_forward_blockwise_lazy(
+    fn = lib().fa_oracle_forward_blockwise_lazy_psq if prescaled_q else lib().fa_oracle_forward_blockwise_lazy
+    rc = fn(
         q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), _code(q.dtype),
         B, S, H, D, q.stride(0), q.stride(1), q.stride(2), B_r, B_c, float(tau), n_threads,
     )
@@ -143,10 +148,12 @@ def blockwise_for_config(cfg, q, k, v, n_threads=0, masked=False):
     `masked`: the config's causal / ragged form (only the persistent kernel's is speculative)."""
     from flash_helpers import kernel_configs as kc
 
+    psq = bool(getattr(cfg, "prescaled_q", False))
     if kc.uses_speculative_softmax(cfg, masked):
-        return blockwise_forward_lazy(q, k, v, min(cfg.B_r, q.shape[1]), cfg.B_c, tau=SPEC_TAU, n_threads=n_threads)
+        return blockwise_forward_lazy(q, k, v, min(cfg.B_r, q.shape[1]), cfg.B_c, tau=SPEC_TAU, n_threads=n_threads,
+                                      prescaled_q=psq)
     if kc.uses_lazy_rescale(cfg):
-        return blockwise_forward_lazy(q, k, v, cfg.B_r, cfg.B_c, n_threads=n_threads)
+        return blockwise_forward_lazy(q, k, v, cfg.B_r, cfg.B_c, n_threads=n_threads, prescaled_q=psq)
     return blockwise_forward(q, k, v, cfg.B_r, cfg.B_c, optimized_softmax=cfg.optimized_softmax,
                              n_threads=n_threads)
 

@@ -110,7 +110,7 @@ def main():
             b=bi.astype(np.int16), r=ri.astype(np.int16), h=hi.astype(np.int16),
             o_b16=u16(o_b16[bi, ri, hi]), o_f32=u16(o_f32[bi, ri, hi]),
             # a checksum of the rebuilt inputs, so a different torch RNG cannot silently change the case
-            qkv_sum=np.array([float(t.float().sum()) for t in (q, k, v)]),
+            qkv_sum=np.array([float(t.double().sum()) for t in (q, k, v)]),   # (float64: independent of the summation order)
         )
     for dtype, tag in ((torch.bfloat16, "bf16"), (torch.float16, "fp16")):
         for name, (B, S, H, D, seed) in CASES.items():

@@ -39,8 +39,8 @@ def build_seam_inputs(dtype, z):
         u = (torch.randint(0, 2, (D,), generator=g2).float() * 2 - 1) * float(amp)
         k[int(b), int(key), int(h)] = u.to(dtype)
         q[int(b), int(row0):int(row0) + int(nrows), int(h)] = u.to(dtype)
-    sums = [float(t.float().sum()) for t in (q, k, v)]
-    assert np.allclose(sums, z["qkv_sum"], rtol=0, atol=1e-3), (sums, z["qkv_sum"])
+    sums = [float(t.double().sum()) for t in (q, k, v)]
+    assert np.allclose(sums, z["qkv_sum"], rtol=0, atol=1e-6), (sums, z["qkv_sum"])
     return q, k, v
 
 

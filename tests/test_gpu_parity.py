@@ -108,8 +108,27 @@ def test_seam_golden_with_spikes_and_the_redo_counter(tag):
     tol = TOL[dtype] * (1 + g["o_f32"].float().abs())
     sane = torch.isfinite(g["o_b16"].float()).all(dim=-1)   # (fp16: the reference's 16-bit eager overflows on the 30-sigma rows)
     n_items = {256: 3 * 24 * 4, 128: 3 * 24 * 8}
-    for cfg, redone in ((_persistent_cfg(name, True), 2 if tag == "bf16" else 3), (_persistent_cfg(name, False), 0),
-                        (_native(name, 128, 64, 4, True, True), 2 if tag == "bf16" else 3), (_native(name, 128, 64, 4, True, False), 0),
+
+    def predicted_redone(B_r):
+        """Items whose first pass must fail, from the fp32 logits: a row fails when l = sum_k 2^((s_k - m_first) c) reaches
+        the limit (spec_limit: bf16 2^64, fp16 2^15), m_first = the row's max over the LAST 64 keys (visited first); an
+        item fails when one of its rows does.  (A 30-sigma K row gives EVERY query of its head logits of ~+-43 binades, so
+        all Q blocks of the two spiked heads fail; the mild spike fails in fp16 only, and only in its own Q block.)"""
+        c = 1.4426950408889634 / 128 ** 0.5
+        limit = 2.0 ** 64 if tag == "bf16" else 2.0 ** 15
+        n = 0
+        for bb in range(q.shape[0]):
+            sc = torch.einsum("qhd,khd->hqk", q[bb].float(), k[bb].float())
+            m_first = sc[:, :, -64:].amax(dim=-1, keepdim=True)
+            l = torch.exp2((sc - m_first).double() * c).sum(dim=-1)          # (heads, rows)
+            bad = ~(l < limit)
+            n += int(bad.view(bad.shape[0], -1, B_r).any(dim=-1).sum())
+        return n
+
+    expect = {256: predicted_redone(256), 128: predicted_redone(128)}
+    assert expect[256] == (8 if tag == "bf16" else 9) and expect[128] == (16 if tag == "bf16" else 17), expect
+    for cfg, redone in ((_persistent_cfg(name, True), expect[256]), (_persistent_cfg(name, False), 0),
+                        (_native(name, 128, 64, 4, True, True), expect[128]), (_native(name, 128, 64, 4, True, False), 0),
                         (kc.FlashForwardKernelConfig(name, 128, 128, 64, 4, True, True, True, 2, 2, 0, True, True), 0)):
         stats = torch.zeros(2, dtype=torch.int32, device=DEV)
         out, _ = flash_attention_kernels.forward(cfg, q, k, v, None, stats=stats)
@@ -148,7 +167,8 @@ def test_optimized_softmax_keeps_the_reference_meaning(monkeypatch):
         monkeypatch.setenv("FA_ALLOW_SPECULATIVE", "1")
         stats.zero_()
         out2, _ = flash_attention_kernels.forward(cfg, q, k, v, None, stats=stats)
-        assert kc.softmax_mode(cfg) == "speculative" and stats[1].item() == 1
+        # (a 30-sigma K row sends EVERY query of its head ~+-43 binades off: all S / B_r workgroups of that head start over)
+        assert kc.softmax_mode(cfg) == "speculative" and stats[1].item() == 1024 // cfg.B_r
         ref = ut.py_flash_attention(q, k, v, upcast=True).float()
         for o in (out, out2):
             assert ((o.float() - ref).abs() <= TOL[dtype] * (1 + ref.abs())).all()
@@ -388,6 +408,16 @@ def _native(name, B_r, B_c, n_waves, buffer, speculative):
     13-field key's optimized_softmax keeps the reference's meaning and never selects it)."""
     return kc.NativeKernelConfig(name, 128, B_r, B_c, n_waves, True, True, True, 0, 0, 0, buffer, False,
                                  speculative_softmax=speculative)
+
+
+def _launch_ex(lib, args, cfg, causal=False, allow_ragged=False, stream=None):
+    """fa_fwd_launch_ex straight through the C ABI with the config's native options in fa_fwd_opts (the 13-field key
+    alone never selects them)."""
+    import ctypes
+    opts = _capi.make_opts(causal=causal, allow_ragged=allow_ragged, speculative=kc.wants_speculative(cfg),
+                           prescaled_q=bool(getattr(cfg, "prescaled_q", False)))
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream) if stream is None else stream
+    return _capi.check(lib.fa_fwd_launch_ex(ctypes.byref(args), ctypes.byref(opts), stream))
 
 
 def _persistent_cfg(name, speculative):
@@ -907,7 +937,8 @@ def test_c4_all_eight_shards_on_one_gpu():
 
 # ---- scope wideners beyond the reference: causal mask, ragged seq_len -----------
 # (a native config that asks for the speculative softmax has a masked form on the persistent kernel only)
-MASKED = [c for c in VARIANTS if _capi.ex_supported(c, allow_ragged=True, speculative=kc.wants_speculative(c))]
+MASKED = [c for c in VARIANTS if _capi.ex_supported(c, allow_ragged=True, speculative=kc.wants_speculative(c),
+                                                   prescaled_q=bool(getattr(c, "prescaled_q", False)))]
 
 
 def _rel_ok(out, ref, dtype):
@@ -1011,8 +1042,7 @@ def test_persistent_ragged_lengths(S):
                 args = _capi.FaFwdArgs(q=q.data_ptr(), k=k.data_ptr(), v=v.data_ptr(), o=o.data_ptr(), batch=B,
                                        seq_len=S, n_heads=H, d_head=128, batch_stride=q.stride(0),
                                        seq_stride=q.stride(1), head_stride=q.stride(2), cfg=_capi.make_config(cfg))
-                _capi.check(lib.fa_fwd_launch_masked(ctypes.byref(args), int(causal),
-                                                     ctypes.c_void_p(torch.cuda.current_stream().cuda_stream), None))
+                _launch_ex(lib, args, cfg, causal=causal, allow_ragged=True)
                 torch.cuda.synchronize()
                 assert bool((guard[:, S:] == 7.0).all()), (S, causal, "rows beyond seq_len were written")
                 runs.append(o.contiguous())
@@ -1102,7 +1132,7 @@ def test_c_abi_strided_views_and_long_sequence():
         args = _capi.FaFwdArgs(q=q.data_ptr(), k=k.data_ptr(), v=v.data_ptr(), o=o.data_ptr(), batch=B, seq_len=S,
                                n_heads=H, d_head=128, batch_stride=q.stride(0), seq_stride=q.stride(1),
                                head_stride=q.stride(2), cfg=_capi.make_config(cfg))
-        _capi.check(lib.fa_fwd_launch(ctypes.byref(args), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        _launch_ex(lib, args, cfg)
         torch.cuda.synchronize()
         ref = flash_attention.forward(cfg, q.contiguous(), k.contiguous(), v.contiguous())
         assert torch.equal(o, ref), str(cfg)

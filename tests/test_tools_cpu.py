@@ -114,7 +114,7 @@ def test_generated_variant_list_is_current_and_covers_every_config():
         # the variant's OPT template flag: the reference's first-block skip or the speculative softmax (softmax_mode says which)
         opt = _capi.SOFTMAX_MODES[info.softmax_mode] in ("first_block_skip", "speculative")
         key = (c.dtype, info.rows_per_wave, c.n_warps, c.B_c, bool(c.swizzled), bool(c.eager_load_blocks),
-               opt, bool(c.mma_double_buffer_loads), bool(c.async_copy), c.d_head)
+               opt, bool(c.mma_double_buffer_loads), bool(c.async_copy), c.d_head, bool(info.prescaled_q))
         (masked if info.masked else built).add(key)
     wanted = {gen.variant_of(cfg) for cfg in kc.get_all_supported_configs()}
     assert wanted == built
@@ -323,7 +323,8 @@ def test_visit_histogram_matches_the_committed_digest():
             assert v["v_accvgpr"] in (0, 64) or ("speculative" not in name or i >= 4), (name, i, v)
         if "speculative" in name:
             first_pass = visits[:4]
-            assert all(v["v_max3_f32"] == 0 and v["v_exp_f32"] == 64 and v["v_fmamk_f32"] == 64 and v["v_add_f32"] == 64 for v in first_pass), name
+            fmamk = 0 if "prescaled" in name else 64   # pre-scaled Q: no multiply per logit at all in the first pass
+            assert all(v["v_max3_f32"] == 0 and v["v_exp_f32"] == 64 and v["v_fmamk_f32"] == fmamk and v["v_add_f32"] == 64 for v in first_pass), name
             assert all(v["v_max3_f32"] > 0 for v in visits[4:]), name   # the second pass keeps the running max
     want = json.load(open(os.path.join(ROOT, "profiles", "r03", "toolchain.json")))
     assert got["hipcc"] == want["hipcc"], ("the compiler changed: every hand-placed schedule needs re-verification on the GPU "

@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""What the pre-scaled Q (fa_fwd_opts.prescaled_q) costs in accuracy: the same inputs through the exact-c
+kernel and the pre-scaled one (speculative and lazy softmax), against fp32 eager attention on the device.  Reports
+max |out - eager_f32|, the mean absolute error, and the reference's own rule (py/flash_helpers/test/test.py:57-61):
+lhs = max |out - eager_16bit|, rhs = 2 max |eager_16bit - eager_f32|, as a ratio lhs / rhs (<= 1 passes).
+Usage: python tools/psq_error.py  > profiles/r03/prescaled_q_error.txt"""
+import sys
+from dataclasses import replace
+
+import torch
+
+sys.path.insert(0, ".")
+import flash_attention  # noqa: E402
+from flash_helpers import kernel_configs as kc  # noqa: E402
+from flash_helpers.test import utils as ut  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def main():
+    print("# tools/psq_error.py: exact c (fp32 multiply per logit, the reference's arithmetic) vs pre-scaled 16-bit Q; N(0,1) inputs")
+    print("dtype  S      data   kernel                       max_err    mean_err   rule lhs/rhs  (lhs, rhs)")
+    for dtype, name in ((torch.bfloat16, kc.DType.BF16), (torch.float16, kc.DType.FP16)):
+        for S, B, H, scale in ((512, 4, 8, 1.0), (4096, 2, 8, 1.0), (16384, 1, 2, 1.0), (4096, 2, 8, 3.0)):
+            gen = torch.Generator(device=DEV).manual_seed(S + int(scale))
+            q, k, v = (torch.randn((B, S, H, 128), dtype=dtype, device=DEV, generator=gen) for _ in range(3))
+            if scale != 1.0:  # peaked logits: std 3 nats instead of 1
+                q = (q.float() * scale).to(dtype)
+            ref32 = ut.py_flash_attention(q, k, v, upcast=True).float()
+            ref16 = ut.py_flash_attention(q, k, v, upcast=False).float()
+            rhs = 2 * (ref16 - ref32).abs().max().item()
+            base = kc.NativeKernelConfig(name, 128, 256, 64, 4, True, True, True, 0, 0, 0, True, False)
+            for label, cfg in (("speculative, exact c", replace(base, speculative_softmax=True)),
+                               ("speculative, prescaled Q", replace(base, speculative_softmax=True, prescaled_q=True)),
+                               ("lazy, exact c", base), ("lazy, prescaled Q", replace(base, prescaled_q=True))):
+                out = flash_attention.forward(cfg, q, k, v).float()
+                err = (out - ref32).abs()
+                lhs = (out - ref16).abs().max().item()
+                print(f"{str(dtype).split('.')[-1]:8s} {S:6d} {'x%.0f' % scale:5s} {label:28s} {err.max().item():.3e}  {err.mean().item():.3e}  "
+                      f"{lhs / rhs:6.3f}        ({lhs:.3e}, {rhs:.3e})")
+
+
+if __name__ == "__main__":
+    main()
