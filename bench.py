@@ -766,6 +766,27 @@ def main():
                              "what": "512 MiB flush + idle spin + sync before every launch, events around the launch "
                                      "(tools/benchmark/pt_bench.py:145-174), 3 warm-ups"},
             }
+        if world == 1 and not args.kernel and hasattr(cfg, "prescaled_q") and not cfg.prescaled_q:
+            # the opt-in pre-scaled-Q form of the same kernel (NOT the reference's arithmetic: DESIGN.md 3.7), same steps
+            from dataclasses import replace as _replace
+
+            alt = _replace(cfg, prescaled_q=True)
+            try:
+                for _ in range(args.warmup):
+                    flash_attention.forward(alt, q, k, v, o)
+                sync()
+                t_a = time.perf_counter()
+                for _ in range(args.steps):
+                    flash_attention.forward(alt, q, k, v, o)
+                sync()
+                alt_s = (time.perf_counter() - t_a) / args.steps
+                line["variants"] = {"prescaled_q": {"tflops": flop_per_step_rank / alt_s / 1e12, "ms_per_step": alt_s * 1e3,
+                                                    "kernel": alt.short_form(),
+                                                    "note": "opt-in (fa_fwd_opts.prescaled_q): Q * log2(e)/sqrt(d) rounded to 16 bit once "
+                                                            "instead of an fp32 multiply per logit; inside the reference's tolerance "
+                                                            "rule (profiles/r03/prescaled_q_error.txt), not its arithmetic: NOT `value`"}}
+            except RuntimeError as exc:
+                line["variants"] = {"prescaled_q": {"error": str(exc)[:200]}}
         if world == 1 and not args.no_mfma_roof:
             del flush_buf
             roof = mfma_only_roof(local_rank)

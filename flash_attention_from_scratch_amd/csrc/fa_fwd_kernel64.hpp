@@ -559,6 +559,7 @@ fa_fwd_kernel64(const KernelArgs args) {
             // the counted waits allow -- 16 of them, or fewer (RAG: a wave whose rows reach beyond the sequence
             // skips stores; counted down to a multiple of 8, which only waits for more)
             int seam_st = 0;
+            int q_st_behind = 0;  // QEARLY: row stores issued BEHIND the next Q tile 0's request (8 after a seam, else 0)
             // ---- the next item's Q, through LDS -------------------------------------------------------
             // The MFMA wants a lane to hold one Q row's 16-byte chunk; fetched like that from global memory
             // a wave-instruction touches 32 rows (32 cache lines for 1 KiB), and 16 of them in a burst cost
@@ -670,7 +671,10 @@ fa_fwd_kernel64(const KernelArgs args) {
                     else asm volatile("s_waitcnt vmcnt(" FA_VM32 ")\n\ts_barrier" ::: "memory");
                     if constexpr (R == 1 || R == 2) {
                         if (it == R && has_next) {
-                            asm volatile("s_waitcnt vmcnt(" FA_VM8 ")" ::: "memory");  // Q tile R-1 landed (only pieces(R-1) are younger)
+                            // Q tile R-1 landed (only pieces(R-1) are younger -- and, QEARLY, the 8 row stores issued behind tile 0's request)
+                            if (R == 1 && q_st_behind) asm volatile("s_waitcnt vmcnt(" FA_VM16 ")" ::: "memory");
+                            else asm volatile("s_waitcnt vmcnt(" FA_VM8 ")" ::: "memory");
+                            if (R == 1) q_st_behind = 0;
                             read_next_q(Qr2[R - 1]);
                             if constexpr (R == 1) {
                                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // ... and read: its image may be overwritten
@@ -1028,7 +1032,11 @@ fa_fwd_kernel64(const KernelArgs args) {
             // area one 32-row Q tile at a time so that the global stores are whole 256-B rows (16 B per
             // lane, 4 rows per wave-instruction).  Wave-private: no barrier.  The 16-B chunk index is
             // XORed with (row & 15) so the 8-B writes and the 16-B reads are bank-conflict free.
-            auto store_item = [&]() {
+            // ABL & 65536 (experiment, tools/tune64.hip): the seam rotates to the next item FIRST and requests the item-after-
+            // next's Q tile 0 from inside the epilogue, in front of the last 8 row stores (the staging area is free as soon
+            // as the last tile's rows are back in registers): the request no longer queues behind all 16 stores.
+            constexpr bool QEARLY = (ABL & 65536) != 0 && !RAG;
+            auto store_item = [&](uint16_t *Oc, const int qb_c, const int ord, auto &&before_last_stores) {
                 asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // last P.V -> VALU reads of O
                 char *stage_o = smem + 2 * TR::kStages * TILE + wave * (32 * ROWB);
                 // lane-derived indices recomputed here from a volatile v_mbcnt: values derived from
@@ -1068,7 +1076,8 @@ fa_fwd_kernel64(const KernelArgs args) {
                             w[1] = E::pack2(hi2[0], hi2[1]);
                             *(u32x2 *)(wp + (((4 * t + rq) ^ swz_of(r31)) << 4)) = w;
                         }
-                        __builtin_amdgcn_sched_barrier(0);  // one d tile at a time: S(0) of the next item is live
+                        // one d tile at a time: S(0) of the next item is live (ABL & 131072, experiment: two at a time)
+                        if (!(ABL & 131072) || (t & 1)) __builtin_amdgcn_sched_barrier(0);
                     }
                     // rows RPP i + rsub of the tile: one scalar base for the 32 rows, a 32-bit lane offset per store;
                     // all reads first (the waits then count down), and the read address is one XOR per row
@@ -1081,6 +1090,14 @@ fa_fwd_kernel64(const KernelArgs args) {
 #pragma unroll
                     for (int i = 0; i < 32 / RPP; ++i)
                         v[i] = *(const s16x8 *)(stage_o + RPP * i * ROWB + (rd0 ^ (((RPP * i) & 15u) << 4)));
+                    if constexpr (QEARLY) {
+                        if (qt == 1) {
+#pragma unroll
+                            for (int i = 0; i < 32 / RPP; ++i) asm volatile("" : "+v"(v[i]));  // the reads are issued ...
+                            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 // ... and back: the staging area is free
+                            before_last_stores();
+                        }
+                    }
 #pragma unroll
                     for (int i = 0; i < 32 / RPP; ++i) {
                         // non-temporal: O is written once and not read again by this kernel (+1.3...2.8 % at
@@ -1114,29 +1131,50 @@ fa_fwd_kernel64(const KernelArgs args) {
                 const bool tl_seam = FA_TRACE == 5 && ord == 0;  // fine stamps of the first seam: slots 50 .. 55
                 if (tl_seam) tl_at(50);  // last visit done
 #endif
-                store_item();
+                bool q_requested = false;
+                const int qb_st = qb_c;  // the item being stored
+                (void)qb_st;
+                if constexpr (QEARLY) {
+                    // rotate to the next item first; the epilogue below still stores the item that just ended
+                    uint16_t *O_st = Oc;
+                    const int qb_done = qb_c, ord_done = ord;
+                    const bool had_next = has_next;
+                    if (had_next) {
+                        ord = ord_n;
+                        item = (int)blockIdx.x + ord * (int)gridDim.x;
+                        Kc = Kn; Vc = Vn; Oc = On; qb_c = qb_n;
+                        nkc = nkn;
+                        set_next();
+                    }
+                    store_item(O_st, qb_done, ord_done, [&]() {
+                        if (had_next && has_next) { request_next_q(0); q_requested = true; q_st_behind = 8; }
+                    });
+                    if (!had_next) break;
+                } else {
+                    store_item(Oc, qb_c, ord, []() {});
+                }
 #if defined(FA_TRACE) && FA_TRACE >= 4
                 if (tl_seam) tl_at(51);  // epilogue issued
 #endif
 #if defined(FA_TRACE) && FA_TRACE < 4
                 asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(te1)::"memory");
 #endif
+                if constexpr (!QEARLY) {
                 if (!has_next) break;
                 // ---- seam: the last visit left the next item's S(0) in Sa and its row max in mraw; its
                 // first tiles are landed or in flight, its first operands sit in the ring
-                const int qb_st = qb_c;  // the item just stored
-                (void)qb_st;
                 ord = ord_n;
                 item = (int)blockIdx.x + ord * (int)gridDim.x;
                 Kc = Kn; Vc = Vn; Oc = On; qb_c = qb_n;
                 nkc = nkn;
                 set_next();
+                }
 #if defined(FA_TRACE) && FA_TRACE >= 4
                 if (tl_seam) tl_at(53);  // coordinates of the item after
 #endif
                 kq = tile_g(Kc, Kn, 4);  // visit 0 requests K(4), V(3) (for n_kv == 4 that is already the item after)
                 vq = tile_g(Vc, Vn, 3);
-                if (has_next) request_next_q(0);  // (the staging area is free again: store_item's reads have retired)
+                if (has_next && !q_requested) request_next_q(0);  // (the staging area is free again: store_item's reads have retired)
                 seam_st = 16;
                 if constexpr (RAG) {  // stores the epilogue above issued: one per four rows inside the sequence (16 per 64 rows)
                     const int rows_in = args.seq_len - (qb_st * TR::kBr + wave * TR::kRowsPerWave);

@@ -18,6 +18,9 @@
 #define FA_TRACE 1
 #endif
 #include "../csrc/fa_fwd_kernel64.hpp"
+#ifndef TRACE_PSQ
+#define TRACE_PSQ 0  // 1: the pre-scaled-Q build
+#endif
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -51,7 +54,7 @@ int main(int argc, char **argv) {
 #ifndef TRACE_SPEC
 #define TRACE_SPEC 1
 #endif
-    auto kern = fa::fa_fwd_kernel64<15, false, 0, false, TRACE_SPEC != 0>;
+    auto kern = fa::fa_fwd_kernel64<15, false, 0, false, TRACE_SPEC != 0, TRACE_PSQ != 0>;
     CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
     hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
     const int n_items = B * H * (S / 256), per_wg = (n_items + grid - 1) / grid, nkv = S / 64;
@@ -132,7 +135,7 @@ int main(int argc, char **argv) {
 #ifndef TRACE_SPEC
 #define TRACE_SPEC 1  // 1: the speculative-softmax build (the default kernel), 0: the lazy-rescale build
 #endif
-    auto kern = fa::fa_fwd_kernel64<15, false, TRACE_ABL, false, TRACE_SPEC != 0>;
+    auto kern = fa::fa_fwd_kernel64<15, false, TRACE_ABL, false, TRACE_SPEC != 0, TRACE_PSQ != 0>;
     CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
     hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
     for (int mode = 0; mode < 2; ++mode) {  // 0: warm caches, back to back; 1: cache flushed before the launch
@@ -205,7 +208,7 @@ int main(int argc, char **argv) {
 #ifndef TRACE_SPEC
 #define TRACE_SPEC 1
 #endif
-    auto kern = fa::fa_fwd_kernel64<15, false, TRACE_ABL, false, TRACE_SPEC != 0>;
+    auto kern = fa::fa_fwd_kernel64<15, false, TRACE_ABL, false, TRACE_SPEC != 0, TRACE_PSQ != 0>;
     CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
     // persistent kernel: workgroup w serves items w, w + 256, ...; trace the second item of two workgroups
     const int items[2] = {256 + 100, 256 + 203};

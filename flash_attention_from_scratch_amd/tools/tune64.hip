@@ -20,7 +20,7 @@ static hipEvent_t e0, e1;
 
 // ABL bit 1 << 20: the speculative-softmax build (SPEC) of the same knobs
 template <int ABL> void launch(const fa::KernelArgs &a) {
-    auto kern = fa::fa_fwd_kernel64<15, false, (ABL & 0xfffff), false, ((ABL >> 20) & 1) != 0>;
+    auto kern = fa::fa_fwd_kernel64<15, false, (ABL & 0xfffff), false, ((ABL >> 20) & 1) != 0, ((ABL >> 21) & 1) != 0>;  // bit 21: the pre-scaled Q
     static bool init = false;
     if (!init) { CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 163840)); init = true; }
     fa::KernelArgs b = a;
@@ -52,9 +52,18 @@ static void time_all() {
         }
     }
     const double fl = 4.0 * Bx * H * (double)S * S * D;
-    for (auto &v : variants)
-        printf("%-40s abl=%5d S=%5d : mean %.4f ms  %7.1f TF   best %7.1f TF\n", v.name, v.abl, S, v.sum_ms / v.n,
-               fl / (v.sum_ms / v.n * 1e-3) / 1e12, fl / (v.best * 1e-3) / 1e12);
+    // a hash of each variant's output: variants that only move work around (not the arithmetic) must agree bit for bit
+    const size_t n_o = (size_t)Bx * S * H * D;
+    std::vector<uint16_t> ho(n_o);
+    for (auto &v : variants) {
+        CHECK(hipMemset(o, 0xff, n_o * 2));
+        v.launch(a);
+        CHECK(hipMemcpy(ho.data(), o, n_o * 2, hipMemcpyDeviceToHost));
+        unsigned long long hsh = 1469598103934665603ull;
+        for (size_t i = 0; i < n_o; ++i) hsh = (hsh ^ ho[i]) * 1099511628211ull;
+        printf("%-52s abl=%8d S=%5d : mean %.4f ms  %7.1f TF   best %7.1f TF   out %016llx\n", v.name, v.abl, S, v.sum_ms / v.n,
+               fl / (v.sum_ms / v.n * 1e-3) / 1e12, fl / (v.best * 1e-3) / 1e12, hsh);
+    }
 }
 
 int main(int argc, char **argv) {

@@ -19,7 +19,7 @@ import sys
 from setuptools import find_packages, setup
 from setuptools.command.build_py import build_py
 
-__version__ = "0.2.0"
+__version__ = "0.3.0"
 HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = "flash_attention_from_scratch_amd"
 

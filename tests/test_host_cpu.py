@@ -392,3 +392,16 @@ def test_the_two_distributions_build_and_import_outside_the_repo(tmp_path):
                          timeout=300)
     assert res.returncode == 0, res.stderr[-3000:]
     assert res.stdout.split()[0] == "80" and str(site) in res.stdout
+
+
+def test_py_distribution_ships_its_own_alias_package():
+    """py/ (the `flash_helpers` distribution, reference py/setup.py:6-9) carries the alias package inside its own project
+    root -- an sdist or an isolated build sees nothing above it -- and it is the same alias package the repository root
+    exposes for in-tree imports."""
+    for rel in ("__init__.py", "kernel_configs.py", os.path.join("test", "__init__.py"), os.path.join("test", "utils.py"),
+                os.path.join("test", "test.py")):
+        a = open(os.path.join(ROOT, "flash_helpers", rel)).read()
+        b = open(os.path.join(ROOT, "py", "flash_helpers", rel)).read()
+        assert a == b, rel
+    setup_py = open(os.path.join(ROOT, "py", "setup.py")).read()
+    assert "os.pardir" not in setup_py and "package_dir" not in setup_py
