@@ -935,6 +935,61 @@ fa_fwd_kernel64(const KernelArgs args) {
                 }
 #endif
             };
+            // ---- the speculative first pass's guard (see spec_guard in fa_fwd_kernel.hpp) -------------------------------
+            // Called between groups of four visits (outside the pinned stream) and once behind an item's last visit.
+            // Common path: two adds, a max, a compare, a ballot.  Rare path (some row of this wave has l above the
+            // threshold): each such row is brought down by an exact power of two -- O, the row sums and the row's reference --
+            // and the wave's O is looked at while it passes through the vector registers: a non-finite element, or a row
+            // sum at or beyond the limit, marks the item for the second pass (item_bad).  So a first pass is accepted only if
+            // at every checkpoint l was below the limit and, wherever l had risen above the threshold, O was finite.
+            bool item_bad = false;
+            auto guard = [&](auto &S_cur, const bool behind_last_visit) {
+                if constexpr (FAST && !(ABL & 262144)) {  // (ABL & 262144: tools/tune64.hip times the kernel without it)
+                    constexpr float kResc = spec_guard<DT>(), kLimit = spec_limit64<DT>();
+                    const float l0 = vadd(rs[0][0], rs[0][1]), l1 = vadd(rs[1][0], rs[1][1]);
+                    const float lm = vmax2(l0, l1);
+                    if (__builtin_expect(__ballot(!(lm <= kResc)) == 0, 1)) return;
+                    // ---- rare ----  (per ROW: a row that does not need it keeps its scale -- dragged along by its neighbours'
+                    // rescues it would sink towards l = 0 -- and a row that does is brought to l in [1, 2) in one step)
+                    asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");  // the last P.V MFMAs -> VALU reads of O
+                    float nonfinite = 0.0f;  // sum of (o - o): 0 while every element of O is finite, NaN otherwise
+#pragma unroll
+                    for (int qt = 0; qt < 2; ++qt) {
+                        const float lq = pair_max(qt ? l1 : l0);      // the two lanes of a row decide together
+                        if (__ballot(!(lq < kLimit)) != 0) item_bad = true;
+                        const bool big = !(lq <= kResc);
+                        int e = big ? __builtin_amdgcn_frexp_expf(lq) - 1 : 0;   // lq in [2^e, 2^(e+1))
+                        e = e < 0 ? 0 : (e > 126 ? 126 : e);                      // (inf / NaN: the item is marked already)
+                        const float sc = __builtin_ldexpf(1.0f, -e);              // a power of two: exact
+                        rs[qt][0] *= sc;
+                        rs[qt][1] *= sc;
+                        neg_msc[qt] -= (float)e;
+#pragma unroll
+                        for (int t = 0; t < DTILES; ++t) {
+                            asm volatile("" : "+a"(O[qt][t]));  // (the copies start behind the pads above and end behind the multiply)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                O[qt][t][r] *= sc;
+                                nonfinite += O[qt][t][r] - O[qt][t][r];
+                            }
+                            asm volatile("" : "+a"(O[qt][t]));
+                        }
+                        if constexpr (PSQ) {
+                            if (!behind_last_visit) {  // S(it) was formed against the old reference, and so would the next tiles be
+#pragma unroll
+                                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                                    for (int r = 0; r < 16; ++r) S_cur[qt][nt][r] = vadd(S_cur[qt][nt][r], -(float)e);
+#pragma unroll
+                                for (int r = 0; r < 16; ++r) Cinit[qt][r] = neg_msc[qt];
+                            }
+                        }
+                    }
+                    if constexpr (PSQ) asm volatile("s_nop 1" : "+v"(Cinit[0]), "+v"(Cinit[1]));
+                    if (__ballot(!(nonfinite == 0.0f)) != 0) item_bad = true;  // inf or NaN somewhere in O
+                    asm volatile("s_nop 3" ::: "memory");  // accvgpr write -> MFMA accumulator
+                }
+            };
             // ---- first item: prologue -------------------------------------------------------------
             auto set_next = [&]() {  // coordinates of the item after `item` (or `item` again)
                 ord_n = next_ord(ord);
@@ -1052,8 +1107,8 @@ fa_fwd_kernel64(const KernelArgs args) {
                         // every P of the row is <= l: below the limit nothing overflowed on the way (fp32 exp2, the
                         // 16-bit P, fp32 O); NaN fails the compare too.  A failed item is stored all the same (its
                         // rows are rewritten by the second pass).
-                        constexpr float kLimit = spec_limit<DT>();
-                        if (__ballot(!(l_row < kLimit)) != 0) failed |= 1ull << (ord < 63 ? ord : 63);
+                        constexpr float kLimit = spec_limit64<DT>();
+                        if (__ballot(!(l_row < kLimit)) != 0 || item_bad) failed |= 1ull << (ord < 63 ? ord : 63);
                     }
                     if constexpr (SPEC && !FAST) {
                         if (qt == 0) ++failed;  // (scalar: one more item of the second pass, for fa_fwd_stats)
@@ -1118,6 +1173,7 @@ fa_fwd_kernel64(const KernelArgs args) {
             // seq_len is a multiple of B_r = 256, so n_kv = seq_len / 64 is a multiple of 4 = ring depth
             for (;;) {
                 for (int it = 0; it < nkc; it += 4) {
+                    if (it) guard(Sa, false);
                     visit(it, Sa, Sb, IntTag<0>{});
                     visit(it + 1, Sb, Sa, IntTag<1>{});
                     visit(it + 2, Sa, Sb, IntTag<2>{});
@@ -1131,6 +1187,7 @@ fa_fwd_kernel64(const KernelArgs args) {
                 const bool tl_seam = FA_TRACE == 5 && ord == 0;  // fine stamps of the first seam: slots 50 .. 55
                 if (tl_seam) tl_at(50);  // last visit done
 #endif
+                guard(Sa, true);
                 bool q_requested = false;
                 const int qb_st = qb_c;  // the item being stored
                 (void)qb_st;
@@ -1206,6 +1263,7 @@ fa_fwd_kernel64(const KernelArgs args) {
                     m_pend[qt] = m[qt];
                     rs[qt][0] = rs[qt][1] = 0.0f;
                 }
+                item_bad = false;
                 set_cinit(Sa);
 #if defined(FA_TRACE) && FA_TRACE >= 4
                 if (tl_seam) tl_at(55);  // row max of S(0), softmax state reset
