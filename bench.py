@@ -121,6 +121,22 @@ def mfma_only_roof(device_index):
     return got if len(got) == 4 else {"error": "unparsed: " + out.strip()[:200]}
 
 
+class stdout_to_stderr:
+    """Within the block, file descriptor 1 points at stderr: the gloo transport prints its connection banner
+    ('[Gloo] Rank 0 is connected to ...') to the C stdout, and rank 0's stdout must carry ONE JSON line."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+        return False
+
+
 def shard_for_rank(global_batch, world, rank):
     """Contiguous batch shard [lo, hi) of rank `rank` (plain batch split)."""
     base, extra = divmod(global_batch, world)
@@ -452,7 +468,9 @@ def dry_run(args, rank, world):
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("gloo")
+        with stdout_to_stderr():
+            dist.init_process_group("gloo")
+            dist.barrier()
         barrier = dist.barrier
     else:
         def barrier():
@@ -553,10 +571,12 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.dist_backend == "nccl":
-            dist.init_process_group("nccl", device_id=device)  # RCCL; barrier + max only
-        else:
-            dist.init_process_group("gloo")
+        with stdout_to_stderr():  # (the transport's banner goes to stderr: stdout is the JSON line's)
+            if args.dist_backend == "nccl":
+                dist.init_process_group("nccl", device_id=device)  # RCCL; barrier + max only
+            else:
+                dist.init_process_group("gloo")
+            dist.barrier()
 
     if args.workload == "c2":
         if world != 1:

@@ -143,9 +143,11 @@ typedef struct fa_fwd_opts {
     uint32_t struct_size;    /* sizeof(fa_fwd_opts) of the caller's header */
     int32_t causal;          /* key j contributes to query i iff j <= i (masked variant of cfg) */
     int32_t allow_ragged;    /* accept seq_len that is not a multiple of B_r / B_c (masked variant of cfg) */
-    int32_t speculative;     /* 1: the speculative-softmax variant of cfg (FA_SOFTMAX_SPECULATIVE).  fp16: P must stay
-                                below 2^15, i.e. a row may rise ~10 nats above the max of its LAST 64 keys (visited
-                                first) before its item is redone; bf16: ~22 nats.  See INTEGRATION.md */
+    int32_t speculative;     /* 1: the speculative-softmax variant of cfg (FA_SOFTMAX_SPECULATIVE).  A row may rise, above the max of
+                                its LAST 64 keys (visited first), by ~44 nats (bf16) / ~10 nats (fp16) before its item is
+                                computed a second time; the persistent kernel also re-centres rising rows every four visits,
+                                so there only a JUMP of ~83 nats (bf16) / ~3-10 nats (fp16) inside 256 keys fails.  The result is
+                                right either way; fa_fwd_stats counts the items that ran twice.  See INTEGRATION.md 5 */
     int32_t prescaled_q;     /* 1: logits from a 16-bit Q * (log2 e / sqrt d) instead of an fp32 multiply per logit
                                 (perturbs every logit by <= 2^-9 relative (bf16) -- FA-3 / Triton practice, not the
                                 reference's arithmetic; inside the reference's tolerance rule) */

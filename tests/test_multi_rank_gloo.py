@@ -85,8 +85,8 @@ def test_bench_launches_its_own_ranks(n):
     res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n), "--steps", "5",
                           "--warmup", "2", "--cpu-dry-run"], env=env, capture_output=True, text=True, timeout=300)
     assert res.returncode == 0, res.stderr[-2000:]
-    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1
+    lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), res.stdout[:500]   # ONE JSON line and nothing else (the gloo banner goes to stderr)
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == n and rec["steps"] == 5 and rec["warmup"] == 2 and rec["scaling"] == "weak"
     assert len(rec["per_gpu_tflops"]) == n
