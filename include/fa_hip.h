@@ -148,9 +148,10 @@ typedef struct fa_fwd_opts {
                                 computed a second time; the persistent kernel also re-centres rising rows every four visits,
                                 so there only a JUMP of ~83 nats (bf16) / ~3-10 nats (fp16) inside 256 keys fails.  The result is
                                 right either way; fa_fwd_stats counts the items that ran twice.  See INTEGRATION.md 5 */
-    int32_t prescaled_q;     /* 1: logits from a 16-bit Q * (log2 e / sqrt d) instead of an fp32 multiply per logit
-                                (perturbs every logit by <= 2^-9 relative (bf16) -- FA-3 / Triton practice, not the
-                                reference's arithmetic; inside the reference's tolerance rule) */
+    int32_t prescaled_q;     /* 1: logits from a 16-bit Q * (log2 e / sqrt d) instead of an fp32 multiply per logit: a logit moves by
+                                ~|k| |q c| 2^-9 (bf16) / 2^-12 (fp16) -- FA-3 / Triton practice, not the reference's arithmetic;
+                                inside the reference's tolerance rule on benchmark-like data, outside it when keys of very
+                                large norm (~30 sigma) appear; see DESIGN.md 3.7 */
     float *ms;               /* HOST pointer or NULL: bracket the launch with events, block, return elapsed ms */
     fa_fwd_stats *stats;     /* DEVICE pointer or NULL */
 } fa_fwd_opts;
