@@ -44,7 +44,9 @@
 //   BC      keys per LDS tile (B_c)
 //   SWZ     XOR-swizzled K image             (cfg.swizzled)
 //   EAGER   prefetch next tile, 2 LDS buffers (cfg.eager_load_blocks)
-//   OPT     first KV block skips the rescale  (cfg.optimized_softmax)
+//   OPT     the reference's cfg.optimized_softmax -- first KV block skips the rescale -- on the single-stage, register-staged
+//           and masked variants; on the double-buffered LDS-DMA variants the speculative softmax (SPEC below), which only
+//           fa_fwd_opts.speculative selects (fa_registry.hpp: softmax_mode_of)
 //   DMA     K/V tiles by global->LDS DMA (cfg.async_copy = 1, the cp.async analogue) or,
 //           DMA = false, through registers: coalesced global_load_dwordx4 issued a visit
 //           ahead, written to LDS with ds_write_b128 after the barrier that frees the stage
@@ -111,7 +113,7 @@ template <int BEGIN, int END, class F> __device__ __forceinline__ void static_fo
 
 template <int DT> struct Elem;
 
-// Speculative softmax (optimized_softmax): a row of the first pass is accepted when its l = sum of P stays below this.
+// Speculative softmax (fa_fwd_opts.speculative): a row of the first pass is accepted when its l = sum of P stays below this.
 // Every P of the row is <= l, so below the limit fp32 exp2 did not overflow, the 16-bit P is in range (fp16: P < 65504)
 // and the fp32 accumulators hold |O| <= l max|V| -- finite for every fp16 V, and for bf16 V up to 2^63.  bf16: 2^64
 // (~44 nats above the first visited tile's max), fp16: 2^15 (~10 nats).  !(l < limit) is also true for NaN and +inf.
@@ -784,7 +786,7 @@ fa_fwd_kernel(const KernelArgs args) {
     using FalseTag = BoolTag<false>;
 
     static_assert(!(QT == 2 && PIPE), "the 64-rows-per-wave pipelined schedule lives in fa_fwd_kernel64.hpp");
-    // SPEC (cfg.optimized_softmax on the double-buffered plain variants): the speculative softmax of
+    // SPEC (the OPT build of the double-buffered plain variants; reached through fa_fwd_opts.speculative): the speculative softmax of
     // fa_fwd_kernel64.hpp on a one-item workgroup.  attempt<FAST> keeps the row max of the
     // FIRST visited tile as the reference for every tile -- no row max, no rescale factor, no O rescale --
     // and checks the row sums l >= every P against the overflow limit at the end; if any wave of the

@@ -124,7 +124,7 @@ fa_fwd_kernel16(const KernelArgs args) {
 
     int kv_block = args.n_kv_blocks - 1;
     if (EAGER) issue_tile(kv_block, 0);
-    // SPEC (cfg.optimized_softmax, double-buffered variants): the speculative softmax (see
+    // SPEC (the OPT build of the double-buffered variants; reached through fa_fwd_opts.speculative): the speculative softmax (see
     // fa_fwd_kernel.hpp): attempt<FAST> keeps the first visited tile's row max as the reference for all
     // tiles -- no quad reduction, no rescale -- and checks l at the end; a workgroup that fails starts over.
     constexpr bool SPEC = OPT && EAGER;

@@ -107,7 +107,7 @@ constexpr bool plan64_ok(const Plan64 &p) {
 // per-lane clamp in the request path) and the keys in front of the tile's own first key are masked, which
 // masks a tile that lies beyond the sequence whole; Q rows beyond the sequence are fetched from its last
 // row and not stored.
-// SPEC (cfg.optimized_softmax; every form): speculative softmax.  The per-tile row max exists
+// SPEC (fa_fwd_opts.speculative / NativeKernelConfig.speculative_softmax; every form): speculative softmax.  The per-tile row max exists
 // only to keep P = 2^((s - m) c) in range -- any reference m gives the same real result -- and its
 // end-of-visit chain (32 v_max3, a lane-pair exchange, two ballots) costs 15-20 % of the kernel
 // (tools/tune64.hip, knob 4096).  So an item is first run with m fixed at the row max of its FIRST tile,
