@@ -151,6 +151,43 @@ def test_opts_struct_size_is_checked():
     assert lib.fa_fwd_ex_supported(ctypes.byref(c), ctypes.byref(short)) == 1
 
 
+def test_launch_ex_validation_needs_no_gpu():
+    """fa_fwd_launch_ex validates like fa_fwd_launch (before any HIP call) and names what is missing when a native option
+    has no device variant: the pre-scaled Q exists on the persistent kernel's plain form only, the speculative softmax
+    not on the masked 32-rows-per-wave variants."""
+    lib = _capi.load()
+    persistent = kc.best_config(kc.DType.BF16)
+    small = kc.FlashForwardKernelConfig(kc.DType.BF16, 128, 128, 64, 4, True, True, True, 2, 2, 0, True, False)
+
+    def status(cfg, seq=256, **opts):
+        args = _args(cfg, seq=seq)
+        o = _capi.make_opts(**opts)
+        return lib.fa_fwd_launch_ex(ctypes.byref(args), ctypes.byref(o), None), _capi.last_error()
+
+    rc, msg = status(persistent, prescaled_q=True, causal=True)
+    assert rc == -3 and "requested options" in msg
+    rc, msg = status(small, prescaled_q=True)
+    assert rc == -3 and "requested options" in msg
+    rc, msg = status(small, speculative=True, allow_ragged=True)
+    assert rc == -3
+    rc, msg = status(small, seq=200)                       # not a multiple of the tiles, and no allow_ragged
+    assert rc == -4 and msg == "Only multiples of B_r are supported for seq_len Q currently"
+    args = _args(persistent)
+    o = _capi.make_opts(speculative=True, stats_ptr=4098)  # a misaligned device pointer for the counters
+    assert lib.fa_fwd_launch_ex(ctypes.byref(args), ctypes.byref(o), None) == -5 and "stats" in _capi.last_error()
+    # everything valid: the next step is the device, which this box does not have
+    if not torch.cuda.is_available():
+        for cfg, opts in ((persistent, dict(speculative=True)), (persistent, dict(speculative=True, prescaled_q=True)),
+                          (small, dict(allow_ragged=True, causal=True))):
+            rc, msg = status(cfg, **opts)
+            assert rc == -7 and "no HIP device" in msg, (rc, msg)
+    for cfg, opts, mode in ((persistent, dict(speculative=True), "speculative"), (persistent, {}, "lazy"),
+                            (small, {}, "eager"), (small, dict(speculative=True), "speculative"),
+                            (small, dict(allow_ragged=True), "eager")):
+        assert _capi.SOFTMAX_MODES[_capi.query(cfg, **opts).softmax_mode] == mode
+    assert _capi.query(persistent, speculative=True, prescaled_q=True).prescaled_q == 1
+
+
 def test_unsupported_configs_are_rejected():
     base = kc.get_kernels_to_build()[0]
     from dataclasses import replace
