@@ -458,8 +458,9 @@ def test_speculative_softmax_against_its_restatement():
             assert ((out.float().cpu() - oracle).abs() <= tol.cpu()).all()
 
 
+@pytest.mark.parametrize("psq", [False, True], ids=["exact_c", "prescaled_q"])
 @pytest.mark.parametrize("rise", ["overflow", "moderate"])
-def test_speculative_softmax_second_pass(rise):
+def test_speculative_softmax_second_pass(rise, psq):
     """An item whose logits rise far above its first tile's row max fails the epilogue's check and is
     run again by the lazy-rescale schedule after the walk: its 256 rows must then be BIT-identical to
     what the lazy-rescale build (speculative_softmax = False) computes, every other item keeps the
@@ -468,7 +469,7 @@ def test_speculative_softmax_second_pass(rise):
     `moderate`: ~20 binades -- fp16 fails (P would pass 65504), bf16 does not."""
     a = 30.0 if rise == "overflow" else 1.107
     for dtype, name in ((torch.bfloat16, kc.DType.BF16), (torch.float16, kc.DType.FP16)):
-        spec, safe = _persistent_cfg(name, True), _persistent_cfg(name, False)
+        spec, safe = (replace(_persistent_cfg(name, sp), prescaled_q=psq) for sp in (True, False))
         # 2 * 3 * 4 = 24 items on 24 workgroups, and 40 * 16 * 1 = 640 items on 256 (ordinals 0..2)
         for (B, H, S, b_, h_, rows, key) in ((2, 3, 1024, 1, 2, slice(300, 310), 0), (40, 16, 256, 33, 5, slice(17, 19), 70)):
             qc = ut.QKVConfig(n_heads=H, d_head=128, batch_size=B, seq_len=S, dtype=dtype, device=torch.device(DEV))
@@ -490,7 +491,8 @@ def test_speculative_softmax_second_pass(rise):
             if takes_second_pass:
                 assert torch.equal(out[blk], out_safe[blk]), (str(dtype), rise, B)
             ref = ut.py_flash_attention(q, k, v, upcast=True).float()
-            tol = TOL[dtype] * (1 + ref.abs())
+            # (the pre-scaled Q moves a logit by ~|k| |q c| 2^-9: with these 30-sigma keys its bar is wider)
+            tol = TOL[dtype] * (1 + ref.abs()) * (16 if psq else 1)
             assert ((out.float() - ref).abs() <= tol).all()
             assert ((out_safe.float() - ref).abs() <= tol).all()
             for _ in range(3):  # both passes are deterministic
