@@ -325,6 +325,31 @@ def test_config_name_round_trips_property():
 
     check()
 
+    native = st.builds(
+        kc.NativeKernelConfig,
+        dtype=st.sampled_from(list(kc.DType)), d_head=st.sampled_from([64, 128]),
+        B_r=st.sampled_from([64, 128, 256]), B_c=st.sampled_from([32, 64, 128]), n_warps=st.sampled_from([4, 8]),
+        async_copy=st.booleans(), eager_load_blocks=st.booleans(), swizzled=st.booleans(),
+        Q_mma_load_K_tiles=st.sampled_from([0, 2]), K_mma_load_K_tiles=st.sampled_from([0, 2]),
+        V_mma_load_K_tiles=st.sampled_from([0, 2]), mma_double_buffer_loads=st.booleans(),
+        optimized_softmax=st.booleans(), speculative_softmax=st.booleans(), prescaled_q=st.booleans(),
+    )
+
+    @settings(max_examples=200, deadline=None)
+    @given(native)
+    def check_native(cfg):
+        """The native extensions ride behind the reference's words in the short form and never enter the 13-field key."""
+        back = kc.parse_kernel_name_into_config(cfg.short_form())
+        assert kc.config_sort_key(back) == kc.config_sort_key(cfg)
+        assert isinstance(back, kc.NativeKernelConfig) == (cfg.speculative_softmax or cfg.prescaled_q)
+        assert cfg.to_c_abi_tuple() == cfg.base().to_c_abi_tuple() and len(cfg.to_c_abi_tuple()) == 13
+        assert cfg.base().short_form() == cfg.short_form().replace("+spec_softmax", "").replace("+prescaled_q", "")
+        assert kc.parse_kernel_name_into_config("void k<" + cfg.to_cpp_struct().replace("torch::kFloat16", "5").replace(
+            "torch::kBFloat16", "15") + ">(a)") == cfg.base()
+        assert kc.wants_speculative(cfg) == cfg.speculative_softmax
+
+    check_native()
+
 
 def test_best_config_selection_rules():
     """The default: the persistent 64-rows-per-wave kernel whenever seq_len is a multiple of its
