@@ -1047,11 +1047,15 @@ fa_fwd_kernel64(const KernelArgs args) {
                 dma_k(tile_g(Kc, Kn, 2), 2);
                 dma_v(tile_g(Vc, Vn, 1), 1);
                 barrier();  // every wave has read its Q tile 1 out of stages 3, which K(3) now overwrites
-                dma_k(tile_g(Kc, Kn, 3), 3);
-                dma_v(tile_g(Vc, Vn, 2), 2);
+                // (ABL & 524288, tools/tune64.hip, TIMING ONLY -- results are wrong: the upper bound of what deferring these
+                // 64 KB + 32 KB out of the prologue could buy: they are simply not requested)
+                if (!(ABL & 524288)) {
+                    dma_k(tile_g(Kc, Kn, 3), 3);
+                    dma_v(tile_g(Vc, Vn, 2), 2);
+                }
                 kq = tile_g(Kc, Kn, 4);
                 vq = tile_g(Vc, Vn, 3);
-                if (has_next) request_next_q(0);
+                if (has_next && !(ABL & 524288)) request_next_q(0);
                 FA_TLP(4);  // S(0) MFMAs and the remaining requests issued
                 asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // MFMA D -> VALU read
 #pragma unroll
