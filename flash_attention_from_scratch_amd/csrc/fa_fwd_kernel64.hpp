@@ -560,6 +560,12 @@ fa_fwd_kernel64(const KernelArgs args) {
             // skips stores; counted down to a multiple of 8, which only waits for more)
             int seam_st = 0;
             int q_st_behind = 0;  // QEARLY: row stores issued BEHIND the next Q tile 0's request (8 after a seam, else 0)
+            // the guard's common path (see guard() below) rides in the last gaps of every fourth visit, where the vector
+            // stream has room (all 32 softmax units have issued by gap 53): two adds, a max, a compare.  ABL & 32768
+            // (tools/tune64.hip): behind the visit instead, as first built.
+            constexpr bool GUARD_IN_VISIT = FAST && !(ABL & 32768) && !(ABL & 262144);
+            float g_l0 = 0.0f, g_l1 = 0.0f, g_lm = 0.0f;
+            bool guard_hit = false;
             // ---- the next item's Q, through LDS -------------------------------------------------------
             // The MFMA wants a lane to hold one Q row's 16-byte chunk; fetched like that from global memory
             // a wave-instruction touches 32 rows (32 cache lines for 1 KiB), and 16 of them in a burst cost
@@ -899,6 +905,12 @@ fa_fwd_kernel64(const KernelArgs args) {
                     static_for<0, plan.exp_n[g]>([&](auto i) { exp_unit(plan.exp_first[g] + decltype(i)::value); });
                     static_for<0, plan.max_n[g]>([&](auto i) { max_unit(plan.max_first[g] + decltype(i)::value); });
                     if constexpr (plan.tail[g] > 0) tail_step(plan.tail[g]);
+                    if constexpr (GUARD_IN_VISIT && R == 3) {
+                        if constexpr (g == 56) g_l0 = vadd(rs[0][0], rs[0][1]);
+                        if constexpr (g == 57) g_l1 = vadd(rs[1][0], rs[1][1]);
+                        if constexpr (g == 58) g_lm = vmax2(g_l0, g_l1);
+                        if constexpr (g == 60) guard_hit = __ballot(!(g_lm <= spec_guard<DT>())) != 0;
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                 });
                 if constexpr (FAST && MASK) {
@@ -946,6 +958,9 @@ fa_fwd_kernel64(const KernelArgs args) {
             auto guard = [&](auto &S_cur, const bool behind_last_visit) {
                 if constexpr (FAST && !(ABL & 262144)) {  // (ABL & 262144: tools/tune64.hip times the kernel without it)
                     constexpr float kResc = spec_guard<DT>(), kLimit = spec_limit64<DT>();
+                    if constexpr (GUARD_IN_VISIT) {
+                        if (__builtin_expect(!guard_hit, 1)) return;  // (decided inside the visit that just ended)
+                    }
                     const float l0 = vadd(rs[0][0], rs[0][1]), l1 = vadd(rs[1][0], rs[1][1]);
                     const float lm = vmax2(l0, l1);
                     if (__builtin_expect(__ballot(!(lm <= kResc)) == 0, 1)) return;
