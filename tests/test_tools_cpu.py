@@ -324,7 +324,9 @@ def test_visit_histogram_matches_the_committed_digest():
         if "speculative" in name:
             first_pass = visits[:4]
             fmamk = 0 if "prescaled" in name else 64   # pre-scaled Q: no multiply per logit at all in the first pass
-            assert all(v["v_max3_f32"] == 0 and v["v_exp_f32"] == 64 and v["v_fmamk_f32"] == fmamk and v["v_add_f32"] == 64 for v in first_pass), name
+            # (64 row-sum adds per visit; every fourth visit carries the guard's two more in its last gaps)
+            assert all(v["v_max3_f32"] == 0 and v["v_exp_f32"] == 64 and v["v_fmamk_f32"] == fmamk for v in first_pass), name
+            assert sorted(v["v_add_f32"] for v in first_pass) == [64, 64, 64, 66], name
             assert all(v["v_max3_f32"] > 0 for v in visits[4:]), name   # the second pass keeps the running max
     want = json.load(open(os.path.join(ROOT, "profiles", "r03", "toolchain.json")))
     assert got["hipcc"] == want["hipcc"], ("the compiler changed: every hand-placed schedule needs re-verification on the GPU "
