@@ -64,7 +64,8 @@ bool valid_load_tiles(int v) { return v == 0 || v == 2 || v == 4 || v == 8; }
 // rescale to skip (the result is the same either way).  The speculative softmax and the pre-scaled Q are this
 // library's extensions and are asked for explicitly (fa_fwd_opts).
 struct Want {
-    bool masked = false;
+    bool masked = false;       // the causal / ragged-length variant of the configuration
+    bool ragged = false;       // ... and seq_len may be off the tile sizes (fa_fwd_opts.allow_ragged)
     bool speculative = false;
     bool prescaled_q = false;
 };
@@ -195,12 +196,13 @@ int validate(const fa_fwd_args *a, const fa::KernelEntry **out, const Want &want
         return fail(FA_ERR_SHAPE, "batch, seq_len and n_heads must be positive");
     // masked == 2 (persistent kernel): a causal-only form for seq_len % B_r == 0 and a second form for every
     // other seq_len >= B_c, which fetches a tile that would reach beyond the sequence as its last B_c keys
-    if (masked && e->masked == 2 && a->seq_len % a->cfg.B_r != 0 && (a->seq_len < a->cfg.B_c || !e->fn_ragged))
+    if (masked && want.ragged && e->masked == 2 && a->seq_len % a->cfg.B_r != 0 && (a->seq_len < a->cfg.B_c || !e->fn_ragged))
         return fail(FA_ERR_SHAPE, "the masked variant of this configuration needs seq_len >= B_c (%d) when "
                                   "seq_len is not a multiple of B_r", a->cfg.B_c);
-    if (!masked && a->seq_len % a->cfg.B_r != 0)
+    // (a causal launch that did not also ask for allow_ragged keeps the reference's divisibility rules)
+    if (!(masked && want.ragged) && a->seq_len % a->cfg.B_r != 0)
         return fail(FA_ERR_SHAPE, "Only multiples of B_r are supported for seq_len Q currently");
-    if (!masked && a->seq_len % a->cfg.B_c != 0)
+    if (!(masked && want.ragged) && a->seq_len % a->cfg.B_c != 0)
         return fail(FA_ERR_SHAPE, "Only multiples of B_c are supported for seq_len K currently");
     if (a->seq_len > INT32_MAX - 1024 || a->batch * a->n_heads > INT32_MAX ||
         a->batch * a->n_heads * ((a->seq_len + a->cfg.B_r - 1) / a->cfg.B_r) > INT32_MAX)
@@ -381,6 +383,7 @@ int fa_fwd_ex_supported(const fa_fwd_config *cfg, const fa_fwd_opts *opts) {
     const char *why;
     Want w;
     w.masked = o.causal || o.allow_ragged;
+    w.ragged = o.allow_ragged != 0;
     w.speculative = o.speculative != 0;
     w.prescaled_q = o.prescaled_q != 0;
     return find_kernel(cfg, &why, w) != nullptr;
@@ -392,6 +395,7 @@ int fa_fwd_launch_ex(const fa_fwd_args *args, const fa_fwd_opts *opts, void *str
     if (rc != FA_OK) return rc;
     Want w;
     w.masked = o.causal || o.allow_ragged;
+    w.ragged = o.allow_ragged != 0;
     w.speculative = o.speculative != 0;
     w.prescaled_q = o.prescaled_q != 0;
     const fa::KernelEntry *e = nullptr;
@@ -414,6 +418,7 @@ int fa_fwd_query(const fa_fwd_config *cfg, const fa_fwd_opts *opts, fa_kernel_in
     if (rc != FA_OK) return rc;
     Want w;
     w.masked = o.causal || o.allow_ragged;
+    w.ragged = o.allow_ragged != 0;
     w.speculative = o.speculative != 0;
     w.prescaled_q = o.prescaled_q != 0;
     const char *why = "";

@@ -87,9 +87,9 @@ def forward(kernel_cfg, q, k, v, o=None, benchmark=False, causal=False, allow_ra
     if q.shape != v.shape:
         raise RuntimeError("Query and value tensors have same shape")
     batch, seq_len, n_heads, d_head = q.shape
-    if not masked and seq_len % cfg.B_r != 0:
+    if not allow_ragged and seq_len % cfg.B_r != 0:
         raise RuntimeError("Only multiples of B_r are supported for seq_len Q currently")
-    if not masked and seq_len % cfg.B_c != 0:
+    if not allow_ragged and seq_len % cfg.B_c != 0:
         raise RuntimeError("Only multiples of B_c are supported for seq_len K currently")
 
     if o is not None:

@@ -141,7 +141,8 @@ typedef struct fa_fwd_stats {
  * set struct_size = sizeof(fa_fwd_opts), then set what you need. */
 typedef struct fa_fwd_opts {
     uint32_t struct_size;    /* sizeof(fa_fwd_opts) of the caller's header */
-    int32_t causal;          /* key j contributes to query i iff j <= i (masked variant of cfg) */
+    int32_t causal;          /* key j contributes to query i iff j <= i (masked variant of cfg); seq_len still has to be a
+                                multiple of B_r and B_c unless allow_ragged is set too */
     int32_t allow_ragged;    /* accept seq_len that is not a multiple of B_r / B_c (masked variant of cfg) */
     int32_t speculative;     /* 1: the speculative-softmax variant of cfg (FA_SOFTMAX_SPECULATIVE).  A row may rise, above the max of
                                 its LAST 64 keys (visited first), by ~44 nats (bf16) / ~10 nats (fp16) before its item is

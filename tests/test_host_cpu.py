@@ -172,6 +172,10 @@ def test_launch_ex_validation_needs_no_gpu():
     assert rc == -3
     rc, msg = status(small, seq=200)                       # not a multiple of the tiles, and no allow_ragged
     assert rc == -4 and msg == "Only multiples of B_r are supported for seq_len Q currently"
+    rc, msg = status(small, seq=200, causal=True)          # causal alone does not buy ragged lengths either
+    assert rc == -4 and msg == "Only multiples of B_r are supported for seq_len Q currently"
+    rc, msg = status(small, seq=192, causal=True)          # (a multiple of B_c, not of B_r)
+    assert rc == -4 and "B_r" in msg
     args = _args(persistent)
     o = _capi.make_opts(speculative=True, stats_ptr=4098)  # a misaligned device pointer for the counters
     assert lib.fa_fwd_launch_ex(ctypes.byref(args), ctypes.byref(o), None) == -5 and "stats" in _capi.last_error()
