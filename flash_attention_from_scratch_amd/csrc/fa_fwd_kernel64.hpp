@@ -100,7 +100,13 @@ constexpr bool plan64_ok(const Plan64 &p) {
 }
 
 // (the reference's meaning of optimized_softmax -- the first tile skips the rescale -- holds here by
-// construction; the flag selects SPEC below instead)
+// construction, so the flag changes nothing on this kernel; SPEC and PSQ below are asked for through fa_fwd_opts)
+// ABL: 0 in the product.  tools/tune64.hip instantiates the kernel with experiment / timing-only bits so that a
+// measured claim in profiles/ can be re-run against the shipped code: 1 2 4 16 2048 4096 delete one part of the stream
+// (results wrong: timing only), 8 drops the waits and barriers (timing only), 256 512 1024 8192 16384 pick another filler
+// plan, 32768 the guard's check behind the visit instead of inside it, 65536 the next Q tile requested in front of the
+// epilogue's last stores, 131072 two d tiles per epilogue step, 262144 no guard, 524288 a prologue that requests only
+// what visit 0 needs (timing only).
 // RAG (a second MASK variant): any seq_len >= 64.  The host rounds the Q blocks up and passes
 // n_kv_blocks = 4 n_q_blocks (the ring arithmetic wants a multiple of four tiles); a tile that would reach
 // beyond the sequence is fetched as the window of its last 64 keys instead (always inside the tensor, no
