@@ -1275,3 +1275,62 @@ def test_d_head_64_widener(cfg):
     with pytest.raises(RuntimeError, match="d_head"):
         bad = torch.zeros((1, 512, 2, 128), dtype=dtype, device=DEV)
         flash_attention.forward(cfg, bad, bad, bad)
+
+
+@pytest.mark.parametrize("name", [kc.DType.BF16, kc.DType.FP16], ids=["bf16", "fp16"])
+def test_non_finite_inputs_propagate_like_fp32_attention(name):
+    """NaN / Inf in the inputs: the reference has no special case and neither has this build -- a NaN reaches exactly the
+    outputs it reaches in fp32 eager attention, everything else stays right.  (Speculative variants take the detour: a
+    NaN row sum fails the epilogue check, the item is computed again with the running max, and comes out NaN again.)
+      * a NaN in one K row  -> every logit of that key: all rows of that (batch, head) are NaN
+      * a NaN in one Q row  -> that output row only
+      * a NaN in V[j, d]    -> column d of every row of that (batch, head)
+      * +Inf in V[j, d]     -> column d is +Inf or NaN (NaN where the key's weight underflowed to 0), never finite-wrong
+    """
+    dtype = name.to_torch_dtype()
+    B, S, H = 2, 1024, 3
+    cfgs = [kc.best_config(name), _persistent_cfg(name, True), _persistent_cfg(name, False),
+            _native(name, 128, 64, 4, True, False), _native(name, 128, 64, 4, True, True)]
+    gen = torch.Generator(device=DEV).manual_seed(77)
+    base = [torch.randn(B, S, H, 128, device=DEV, dtype=dtype, generator=gen) for _ in range(3)]
+    want = ut.py_flash_attention(*base, upcast=True).to(dtype)
+
+    def run(cfg, q, k, v):
+        out = flash_attention.forward(cfg, q, k, v)
+        torch.cuda.synchronize()
+        return out
+
+    for cfg in cfgs:
+        # K: key 700 of (batch 1, head 2)
+        q, k, v = (t.clone() for t in base)
+        k[1, 700, 2, 5] = float("nan")
+        out = run(cfg, q, k, v)
+        assert torch.isnan(out[1, :, 2]).all(), str(cfg)
+        mask = torch.ones(B, S, H, dtype=torch.bool, device=DEV)
+        mask[1, :, 2] = False
+        assert torch.isfinite(out[mask]).all(), str(cfg)
+        assert (out[mask].float() - want[mask].float()).abs().max().item() <= 2 * TOL[dtype], str(cfg)
+        # Q: row 300 of (batch 0, head 1)
+        q, k, v = (t.clone() for t in base)
+        q[0, 300, 1, 127] = float("nan")
+        out = run(cfg, q, k, v)
+        assert torch.isnan(out[0, 300, 1]).all(), str(cfg)
+        mask = torch.ones(B, S, H, dtype=torch.bool, device=DEV)
+        mask[0, 300, 1] = False
+        assert torch.isfinite(out[mask]).all(), str(cfg)
+        assert (out[mask].float() - want[mask].float()).abs().max().item() <= 2 * TOL[dtype], str(cfg)
+        # V: element (key 9, d 64) of (batch 1, head 0): NaN, then +Inf
+        for bad in (float("nan"), float("inf")):
+            q, k, v = (t.clone() for t in base)
+            v[1, 9, 0, 64] = bad
+            out = run(cfg, q, k, v)
+            col = out[1, :, 0, 64]
+            assert not torch.isfinite(col).any(), (str(cfg), bad)
+            if bad != bad:
+                assert torch.isnan(col).all(), str(cfg)
+            else:
+                assert (torch.isnan(col) | (col == float("inf"))).all(), str(cfg)
+            mask = torch.ones(B, S, H, 128, dtype=torch.bool, device=DEV)
+            mask[1, :, 0, 64] = False
+            assert torch.isfinite(out[mask]).all(), (str(cfg), bad)
+            assert (out[mask].float() - want[mask].float()).abs().max().item() <= 2 * TOL[dtype], (str(cfg), bad)
