@@ -1334,3 +1334,35 @@ def test_non_finite_inputs_propagate_like_fp32_attention(name):
             mask[1, :, 0, 64] = False
             assert torch.isfinite(out[mask]).all(), (str(cfg), bad)
             assert (out[mask].float() - want[mask].float()).abs().max().item() <= 2 * TOL[dtype], (str(cfg), bad)
+
+
+def test_launch_ex_with_device_counters_is_capturable_too():
+    """fa_fwd_launch_ex with the native options and fa_fwd_stats is still one hipLaunchKernel on the caller's stream -- no
+    host read-back: the speculative softmax's second pass runs inside the same launch and the counters are device
+    atomics -- so several of them capture into one hipGraph (test_launch_is_capturable_into_a_hip_graph has the plain
+    launch).  Replays give the bits of the eager launch, also after the inputs changed in place, and count their items."""
+    cfgs = [kc.best_config(kc.DType.BF16), kc.best_config(kc.DType.FP16),
+            _native(kc.DType.BF16, 128, 64, 4, True, False)]
+    for cfg in cfgs:
+        dtype = cfg.dtype.to_torch_dtype()
+        gen = torch.Generator(device=DEV).manual_seed(5)
+        q, k, v = (torch.randn(2, 1024, 4, 128, device=DEV, dtype=dtype, generator=gen) for _ in range(3))
+        o = torch.empty_like(q)
+        stats = torch.zeros(2, dtype=torch.int32, device=DEV)
+        eager = flash_attention.forward(cfg, q, k, v).clone()   # (also the one-time per-device init, outside the capture)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            for _ in range(3):
+                flash_attention_kernels.forward(cfg, q, k, v, o, stats=stats)
+        o.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(o, eager), str(cfg)
+        n_items = 2 * 4 * (1024 // cfg.B_r)
+        assert stats.tolist() == [3 * n_items, 0], (str(cfg), stats.tolist())
+        q.copy_(torch.randn(q.shape, device=DEV, dtype=dtype, generator=gen))
+        want = flash_attention.forward(cfg, q, k, v).clone()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(o, want), str(cfg)
