@@ -104,7 +104,7 @@ constexpr bool plan64_ok(const Plan64 &p) {
 // ABL: 0 in the product.  tools/tune64.hip instantiates the kernel with experiment / timing-only bits so that a
 // measured claim in profiles/ can be re-run against the shipped code: 1 2 4 16 2048 4096 delete one part of the stream
 // (results wrong: timing only), 8 drops the waits and barriers (timing only), 256 512 1024 8192 16384 pick another filler
-// plan, 32768 the guard's check behind the visit instead of inside it, 65536 the next Q tile requested in front of the
+// plan, 64 the prologue's last 16 requests at visit 0's sync point instead, 32768 the guard's check behind the visit instead of inside it, 65536 the next Q tile requested in front of the
 // epilogue's last stores, 131072 two d tiles per epilogue step, 262144 no guard, 524288 a prologue that requests only
 // what visit 0 needs (timing only).
 // RAG (a second MASK variant): any seq_len >= 64.  The host rounds the Q blocks up and passes
@@ -565,6 +565,16 @@ fa_fwd_kernel64(const KernelArgs args) {
             // the counted waits allow -- 16 of them, or fewer (RAG: a wave whose rows reach beyond the sequence
             // skips stores; counted down to a multiple of 8, which only waits for more)
             int seam_st = 0;
+            // ABL & 64 (experiment, tools/tune64.hip; plain form only): the walk's prologue leaves K(3), V(2) and the next
+            // item's Q tile 0 -- 16 pieces per wave that visit 0 does not need -- to the sync point of visit 0.  Their place
+            // in the issue order is the same (behind K(2), V(1), in front of visit 0's own pieces), so every later counted
+            // wait holds and the output is bit-identical.  Measured with the variants' order rotating from round to round
+            // (profiles/r03/tune64_seam_and_guard.txt): -0.1 % at S = 512, -0.25 % at S = 1024, -0.4 % at C1 -- the
+            // start-up requests return at the fabric's rate whenever they are issued, and the 16 pieces cost more at the
+            // sync point than under S(0).  Not adopted.  (The timing-only knob 524288, which never fetches them, had read
+            // +2.6 %: that was the traffic it removed.)
+            constexpr bool DEFER = (ABL & 64) != 0 && !MASK;
+            int deferred = 0;  // 1: those pieces are still to be requested (first visit of the walk's first item only)
             int q_st_behind = 0;  // QEARLY: row stores issued BEHIND the next Q tile 0's request (8 after a seam, else 0)
             // the guard's common path (see guard() below) rides in the last gaps of every fourth visit, where the vector
             // stream has room (all 32 softmax units have issued by gap 53): two adds, a max, a compare.  ABL & 32768
@@ -674,6 +684,16 @@ fa_fwd_kernel64(const KernelArgs args) {
                     if (it >= 3) {
                         asm volatile("s_waitcnt vmcnt(" FA_VM8 ")\n\ts_barrier" ::: "memory");
                         return;
+                    }
+                    if constexpr (DEFER && R == 0) {
+                        if (deferred) {  // (it == 0) nothing is younger than K(2), V(1) yet
+                            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+                            dma_k(tile_g(Kc, Kn, 3), 3);
+                            dma_v(tile_g(Vc, Vn, 2), 2);
+                            if (has_next) request_next_q(0);
+                            deferred = 0;
+                            return;
+                        }
                     }
                     const int q8 = has_next ? 8 : 0;
                     const int allow = (it < 2) ? 8 + seam_st + q8 : 8 + q8;
@@ -1070,13 +1090,14 @@ fa_fwd_kernel64(const KernelArgs args) {
                 barrier();  // every wave has read its Q tile 1 out of stages 3, which K(3) now overwrites
                 // (ABL & 524288, tools/tune64.hip, TIMING ONLY -- results are wrong: the upper bound of what deferring these
                 // 64 KB + 32 KB out of the prologue could buy: they are simply not requested)
-                if (!(ABL & 524288)) {
+                if (!(ABL & 524288) && !DEFER) {
                     dma_k(tile_g(Kc, Kn, 3), 3);
                     dma_v(tile_g(Vc, Vn, 2), 2);
                 }
                 kq = tile_g(Kc, Kn, 4);
                 vq = tile_g(Vc, Vn, 3);
-                if (has_next && !(ABL & 524288)) request_next_q(0);
+                if (has_next && !(ABL & 524288) && !DEFER) request_next_q(0);
+                if constexpr (DEFER) deferred = 1;
                 FA_TLP(4);  // S(0) MFMAs and the remaining requests issued
                 asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // MFMA D -> VALU read
 #pragma unroll
@@ -1095,8 +1116,9 @@ fa_fwd_kernel64(const KernelArgs args) {
                     m_pend[qt] = m[qt];
                 }
                 set_cinit(Sa);
-                if (!(ABL & 8)) {  // K(1) landed (under S(0))
-                    if (has_next) asm volatile("s_waitcnt vmcnt(28)" ::: "memory");
+                if (!(ABL & 8)) {  // K(1) landed (under S(0)); younger: V(0), K(2), V(1) [, K(3), V(2) [, the next Q tile 0]]
+                    if constexpr (DEFER) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+                    else if (has_next) asm volatile("s_waitcnt vmcnt(28)" ::: "memory");
                     else asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
                 }
                 FA_TLP(5);  // row max done, K(1) landed

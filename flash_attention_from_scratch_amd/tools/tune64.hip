@@ -5,13 +5,14 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <algorithm>
 #include <vector>
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(e_), __LINE__); exit(2); } } while (0)
 
 static uint16_t *q, *k, *v, *o, *q_scaled;  // q_scaled = q * c (bit 2048 variants: exp2 of the raw logit)
 static const int B = 16, H = 16, D = 128;
 static int S = 4096;
-static int only_abl = -1;  // argv: only=<abl>
+static std::vector<int> only_list;  // argv: only=<abl>[,<abl>...]
 static int n_rep = 10;
 
 struct Variant { const char *name; int abl; void (*launch)(const fa::KernelArgs &); double sum_ms; int n; float best; };
@@ -28,7 +29,7 @@ template <int ABL> void launch(const fa::KernelArgs &a) {
     hipLaunchKernelGGL(kern, dim3(b.n_bh * b.n_q_blocks < 256 ? b.n_bh * b.n_q_blocks : 256), dim3(256), 163840, 0, b);
 }
 template <int ABL> void add(const char *name) {
-    if (only_abl >= 0 && ABL != only_abl) return;
+    if (!only_list.empty() && std::find(only_list.begin(), only_list.end(), ABL) == only_list.end()) return;
     variants.push_back({name, ABL, launch<ABL>, 0.0, 0, 1e9f});
 }
 // interleaved timing: the chip's clock drifts with temperature / power state by a few percent
@@ -40,8 +41,11 @@ static void time_all() {
     a.batch_stride = (int64_t)S * H * D; a.seq_stride = H * D; a.head_stride = D;
     a.seq_len = S; a.n_heads = H; a.n_bh = Bx * H; a.n_q_blocks = S / 256; a.n_kv_blocks = S / 64; a.causal = 0;
     for (auto &v : variants) { v.sum_ms = 0; v.n = 0; v.best = 1e9f; }
+    // (the order rotates from round to round: a variant's neighbour in time moves its mean by 1-2 % at S <= 1024)
+    const size_t nv = variants.size();
     for (int round = -1; round < n_rep; ++round) {
-        for (auto &v : variants) {
+        for (size_t vi = 0; vi < nv; ++vi) {
+            auto &v = variants[(vi + (size_t)(round + 1) * 3) % nv];
             for (int i = 0; i < 2; ++i) {
                 CHECK(hipEventRecord(e0));
                 v.launch(a);
@@ -74,7 +78,8 @@ int main(int argc, char **argv) {
     bool zeros = false;
     for (int i = 1; i < argc; ++i) {
         if (!strcmp(argv[i], "zeros")) zeros = true;
-        if (!strncmp(argv[i], "only=", 5)) only_abl = atoi(argv[i] + 5);
+        if (!strncmp(argv[i], "only=", 5))  // only=a,b,c
+            for (const char *p = argv[i] + 5; *p;) { only_list.push_back(atoi(p)); while (*p && *p != ',') ++p; if (*p) ++p; }
         if (!strncmp(argv[i], "reps=", 5)) n_rep = atoi(argv[i] + 5);
     }
     for (int t = 0; t < 3; ++t) {
