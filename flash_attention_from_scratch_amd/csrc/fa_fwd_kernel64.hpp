@@ -568,11 +568,9 @@ fa_fwd_kernel64(const KernelArgs args) {
             // ABL & 64 (experiment, tools/tune64.hip; plain form only): the walk's prologue leaves K(3), V(2) and the next
             // item's Q tile 0 -- 16 pieces per wave that visit 0 does not need -- to the sync point of visit 0.  Their place
             // in the issue order is the same (behind K(2), V(1), in front of visit 0's own pieces), so every later counted
-            // wait holds and the output is bit-identical.  Measured with the variants' order rotating from round to round
-            // (profiles/r03/tune64_seam_and_guard.txt): -0.1 % at S = 512, -0.25 % at S = 1024, -0.4 % at C1 -- the
-            // start-up requests return at the fabric's rate whenever they are issued, and the 16 pieces cost more at the
-            // sync point than under S(0).  Not adopted.  (The timing-only knob 524288, which never fetches them, had read
-            // +2.6 %: that was the traffic it removed.)
+            // wait holds and the output is bit-identical.  Measured (profiles/r03/tune64_seam_and_guard.txt, last table):
+            // -1.1 % at S = 512, -0.6 % at S = 1024, -0.2 % at C1 -- the start-up requests return at the fabric's rate whenever
+            // they are issued, and 16 pieces cost more at a sync point than under S(0).  Not adopted.
             constexpr bool DEFER = (ABL & 64) != 0 && !MASK;
             int deferred = 0;  // 1: those pieces are still to be requested (first visit of the walk's first item only)
             int q_st_behind = 0;  // QEARLY: row stores issued BEHIND the next Q tile 0's request (8 after a seam, else 0)
