@@ -594,8 +594,10 @@ def best_config(dtype=DType.BF16, seq_len=4096, masked=False) -> FlashForwardKer
     rounds of four 64-key tiles; measured ahead of the 32-rows-per-wave kernels from seq_len ~1000 up,
     profiles/r01/ragged_persistent.txt), otherwise 4 waves x 32 rows.
 
-    Softmax: bf16 takes the speculative softmax (a row may rise 32 binades = 22 nats above the max of
-    its last 64 keys before its item is redone); fp16 does NOT by default -- its 16-bit P leaves ~15
+    Softmax: bf16 takes the speculative softmax (the persistent kernel re-centres rising rows every four
+    visits, so only a JUMP of ~83 nats inside 256 keys sends an item to the second pass; the 32-row
+    fallback for other seq_len has no guard: ~44 nats above the max of the row's last 64 keys); fp16 does
+    NOT by default -- its 16-bit P leaves ~15
     binades (~10 nats) of headroom, which attention-sink-like logits at the first keys (visited last)
     exceed, and every such item then costs 2x (profiles/r03/sink_data.txt).  Ask for it explicitly
     (``replace(cfg, speculative_softmax=True)``) when the logits are known to be flat."""
