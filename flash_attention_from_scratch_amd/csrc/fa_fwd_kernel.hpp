@@ -115,8 +115,9 @@ template <int DT> struct Elem;
 
 // Speculative softmax (fa_fwd_opts.speculative): a row of the first pass is accepted when its l = sum of P stays below this.
 // Every P of the row is <= l, so below the limit fp32 exp2 did not overflow, the 16-bit P is in range (fp16: P < 65504)
-// and the fp32 accumulators hold |O| <= l max|V| -- finite for every fp16 V, and for bf16 V up to 2^63.  bf16: 2^64
-// (~44 nats above the first visited tile's max), fp16: 2^15 (~10 nats).  !(l < limit) is also true for NaN and +inf.
+// and the fp32 accumulators hold |O| <= l max|V| -- finite for every fp16 V; for bf16 (|V| up to 2^127) the verdict also
+// looks at the accumulators themselves.  bf16: 2^64 (~44 nats above the first visited tile's max), fp16: 2^15 (~10 nats).
+// !(l < limit) is also true for NaN and +inf.
 template <int DT> __device__ constexpr float spec_limit() { return DT == 5 ? 32768.0f : 18446744073709551616.0f; }
 // The persistent kernel's guard (fa_fwd_kernel64.hpp): every four visits a wave looks at its running row sums; a row
 // whose sum has passed this threshold (bf16 2^32; fp16 2^11: N(0, 1) rows reach 2^9 .. 2^12 on their own between S = 4096 and
@@ -1018,6 +1019,18 @@ fa_fwd_kernel(const KernelArgs args) {
         bool bad = false;
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) bad |= !(pair_sum(l[qt]) < kLimit);
+        if constexpr (DT == 15) {
+            // bf16: |O| <= l max|V| stays finite below the limit only for |V| < 2^63 -- so look at what the accumulators
+            // hold (o - o is 0 for a finite o, NaN for inf / NaN) instead of bounding it.  fp16: 2^15 * 65504 is finite.
+            float nonfinite = 0.0f;
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+                for (int t = 0; t < DTILES; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) nonfinite += O[qt][t][r] - O[qt][t][r];
+            bad |= !(nonfinite == 0.0f);
+        }
         const int wave_bad = __ballot(bad) != 0 ? 1 : 0;
         if (lane == 0) *(int *)(smem + wave * 4) = wave_bad;
         barrier();

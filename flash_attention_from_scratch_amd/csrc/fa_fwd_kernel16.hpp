@@ -265,7 +265,16 @@ fa_fwd_kernel16(const KernelArgs args) {
         wg_barrier();  // every wave is done with the K/V stages
         if constexpr (FAST) {  // l >= every P of the row: below the limit nothing overflowed; one verdict per workgroup
             constexpr float kLimit = spec_limit<DT>();
-            const int wave_bad = __ballot(!(quad_sum(l) < kLimit)) != 0 ? 1 : 0;
+            bool bad = !(quad_sum(l) < kLimit);
+            if constexpr (DT == 15) {  // bf16: the accumulators themselves (see spec_limit)
+                float nonfinite = 0.0f;
+#pragma unroll
+                for (int t = 0; t < DT16; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) nonfinite += O[t][r] - O[t][r];
+                bad |= !(nonfinite == 0.0f);
+            }
+            const int wave_bad = __ballot(bad) != 0 ? 1 : 0;
             if (lane == 0) *(int *)(smem + wave * 4) = wave_bad;
             wg_barrier();
             int any = 0;

@@ -1366,3 +1366,32 @@ def test_launch_ex_with_device_counters_is_capturable_too():
         graph.replay()
         torch.cuda.synchronize()
         assert torch.equal(o, want), str(cfg)
+
+
+def test_speculative_verdict_looks_at_the_accumulators_bf16():
+    """bf16 V reaches 2^127, so 'l below the limit' does not bound |O| <= l max|V|: a row whose logits rise
+    30 nats (l ~ 2^52 < 2^64: the row-sum check alone passes) with |V| = 2^90 overflows the fp32 accumulators of the
+    first pass.  Every speculative variant must notice (inf / NaN in O), run the item again with the running max and
+    return the finite values the non-speculative variant returns."""
+    B, S, H = 1, 1024, 2
+    q = torch.full((B, S, H, 128), 1.0, device=DEV, dtype=torch.bfloat16)
+    k = torch.full((B, S, H, 128), 30.0 * (128 ** 0.5) / 128, device=DEV, dtype=torch.bfloat16)
+    k[:, S - 64:] = 0.0                                     # the tile visited first: logit 0; every other key: 30 nats
+    gen = torch.Generator(device=DEV).manual_seed(3)
+    sign = (torch.randint(0, 2, (B, S, H, 128), device=DEV, generator=gen) * 2 - 1).to(torch.bfloat16)
+    v = sign * (2.0 ** 90)
+    want = None
+    for B_r, B_c, n_w in ((256, 64, 4), (128, 64, 4), (64, 32, 4)):
+        spec, safe = _native(kc.DType.BF16, B_r, B_c, n_w, True, True), _native(kc.DType.BF16, B_r, B_c, n_w, True, False)
+        stats = torch.zeros(2, dtype=torch.int32, device=DEV)
+        out = flash_attention_kernels.forward(spec, q, k, v, None, stats=stats)[0]   # (plain form: no mask, no ragged length)
+        ref = flash_attention.forward(safe, q, k, v)
+        torch.cuda.synchronize()
+        assert torch.isfinite(ref.float()).all() and torch.isfinite(out.float()).all(), (B_r, B_c)
+        items = stats.tolist()
+        assert items[1] == items[0] > 0, (B_r, B_c, items)    # every item overflowed and was redone
+        scale = 2.0 ** -90
+        assert ((out.float() * scale) - (ref.float() * scale)).abs().max().item() <= 2.0 ** -6, (B_r, B_c)
+        if want is None:
+            want = ref
+        assert ((ref.float() * scale) - (want.float() * scale)).abs().max().item() <= 2.0 ** -6, (B_r, B_c)
