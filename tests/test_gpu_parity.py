@@ -1395,3 +1395,16 @@ def test_speculative_verdict_looks_at_the_accumulators_bf16():
         if want is None:
             want = ref
         assert ((ref.float() * scale) - (want.float() * scale)).abs().max().item() <= 2.0 ** -6, (B_r, B_c)
+
+
+def test_plain_c_client_runs(tmp_path):
+    """examples/c_client.c: the forward from a C99 program -- hipMalloc, fa_fwd_query, fa_fwd_launch_ex with the device
+    counters and event timing -- checked in double precision on the host (exit code 0)."""
+    import subprocess
+    from tests.test_host_cpu import build_c_client
+
+    exe = build_c_client(tmp_path)
+    env = dict(os.environ, LD_LIBRARY_PATH=os.path.dirname(_capi.LIB_PATH) + ":/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
+    done = subprocess.run([exe], capture_output=True, text=True, env=env, timeout=300)
+    assert done.returncode == 0, done.stdout + done.stderr
+    assert "computed twice 0" in done.stdout and "0 outside" in done.stdout, done.stdout

@@ -471,3 +471,25 @@ def test_py_distribution_ships_its_own_alias_package():
         assert a == b, rel
     setup_py = open(os.path.join(ROOT, "py", "setup.py")).read()
     assert "os.pardir" not in setup_py and "package_dir" not in setup_py
+
+
+def build_c_client(out_dir):
+    """examples/c_client.c with gcc -std=c99 (no C++, no torch): the boundary is a C ABI."""
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(str(out_dir), "c_client")
+    cmd = ["gcc", "-std=c99", "-O2", "-Wall", "-Werror", "-D__HIP_PLATFORM_AMD__", "-I" + os.path.join(root, "include"),
+           "-I/opt/rocm/include", os.path.join(root, "examples", "c_client.c"),
+           "-L" + os.path.dirname(_capi.LIB_PATH), "-lfa_hip", "-L/opt/rocm/lib", "-lamdhip64", "-lm", "-o", exe]
+    done = subprocess.run(cmd, capture_output=True, text=True)
+    assert done.returncode == 0, done.stderr
+    return exe
+
+
+def test_plain_c_client_compiles_and_links(tmp_path):
+    """include/fa_hip.h is C: a C99 translation unit that fills fa_fwd_args / fa_fwd_opts, calls fa_fwd_query and
+    fa_fwd_launch_ex and reads fa_fwd_stats builds with gcc and links against libfa_hip.so (the GPU tier runs it)."""
+    _capi.load()
+    exe = build_c_client(tmp_path)
+    assert os.path.getsize(exe) > 0
