@@ -1408,3 +1408,28 @@ def test_plain_c_client_runs(tmp_path):
     done = subprocess.run([exe], capture_output=True, text=True, env=env, timeout=300)
     assert done.returncode == 0, done.stdout + done.stderr
     assert "computed twice 0" in done.stdout and "0 outside" in done.stdout, done.stdout
+
+
+def test_reference_side_binding_runs(tmp_path):
+    """examples/torch_binding.cpp (the C++ pybind function of INTEGRATION.md 2, over the C ABI): same bits as this
+    repository's ctypes path for reference configs, the caller's `o` written in place, event timing, the reference's
+    error texts from behind the ABI."""
+    from tests.test_host_cpu import build_torch_binding
+
+    ext = build_torch_binding(tmp_path)
+    gen = torch.Generator(device=DEV).manual_seed(21)
+    for cfg in (kc.get_kernels_to_build()[0], kc.get_kernels_to_build()[-1],
+                kc.FlashForwardKernelConfig(kc.DType.BF16, 128, 256, 64, 4, True, True, True, 0, 0, 0, True, False)):
+        dtype = cfg.dtype.to_torch_dtype()
+        q, k, v = (torch.randn(2, 512, 3, 128, device=DEV, dtype=dtype, generator=gen) for _ in range(3))
+        want = flash_attention.forward(cfg, q, k, v)
+        out, ms = ext.forward(cfg, q, k, v, None)
+        assert ms == 0.0 and torch.equal(out, want), str(cfg)
+        o = torch.zeros_like(q)
+        out2, ms2 = ext.forward(cfg, q, k, v, o, True)
+        assert out2.data_ptr() == o.data_ptr() and ms2 > 0.0 and torch.equal(o, want), str(cfg)
+        with pytest.raises(RuntimeError, match="Only multiples of B_r are supported for seq_len Q currently"):
+            ext.forward(cfg, q[:, :500].contiguous(), k[:, :500].contiguous(), v[:, :500].contiguous(), None)
+        with pytest.raises(RuntimeError, match="Kernel configuration dtype does not match input dtype"):
+            other = torch.float16 if dtype == torch.bfloat16 else torch.bfloat16
+            ext.forward(cfg, q.to(other), k.to(other), v.to(other), None)

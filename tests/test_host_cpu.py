@@ -493,3 +493,30 @@ def test_plain_c_client_compiles_and_links(tmp_path):
     _capi.load()
     exe = build_c_client(tmp_path)
     assert os.path.getsize(exe) > 0
+
+
+def build_torch_binding(out_dir):
+    """examples/torch_binding.cpp -- the pybind function a maintainer of the reference would compile instead of
+    src/flash_attention.cu -- JIT-built by torch.utils.cpp_extension with g++ (no device code)."""
+    from torch.utils.cpp_extension import load
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib_dir = os.path.dirname(_capi.LIB_PATH)
+    torch_lib = os.path.join(os.path.dirname(torch.__file__), "lib")
+    return load("fa_ref_binding", [os.path.join(root, "examples", "torch_binding.cpp")],
+                extra_include_paths=[os.path.join(root, "include"), "/opt/rocm/include"],
+                extra_cflags=["-D__HIP_PLATFORM_AMD__", "-O2"],
+                extra_ldflags=["-L" + lib_dir, "-lfa_hip", "-Wl,-rpath," + lib_dir, "-L" + torch_lib, "-lc10_hip"],
+                build_directory=str(out_dir), verbose=False)
+
+
+def test_reference_side_binding_builds(tmp_path):
+    """The binding of INTEGRATION.md 2 is a file that compiles: a torch extension with the reference module's signature over
+    the C ABI.  Without a GPU its tensor checks still answer (the reference's CHECK_INPUT); the GPU tier runs it."""
+    _capi.load()
+    ext = build_torch_binding(tmp_path)
+    assert ext.version() == _capi.load().fa_version().decode()
+    cfg = kc.get_kernels_to_build()[0]
+    x = torch.zeros(1, 128, 1, 128, dtype=cfg.dtype.to_torch_dtype())
+    with pytest.raises(RuntimeError, match="must be a CUDA tensor"):
+        ext.forward(cfg, x, x, x, None)
