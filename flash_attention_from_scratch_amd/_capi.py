@@ -9,7 +9,9 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libfa_hip.so")
+# FA_HIP_LIB: another build of the same library (tests/test_gpu_parity.py runs the timing-perturbed FA_JITTER build,
+# lib/libfa_hip_jitter.so, through the same binding).  Not a fallback: the named file must exist.
+LIB_PATH = os.environ.get("FA_HIP_LIB") or os.path.join(_HERE, "lib", "libfa_hip.so")
 
 FA_FP16, FA_BF16 = 5, 15
 
@@ -25,7 +27,10 @@ EXPORTED_SYMBOLS = (
     "fa_fwd_launch_timed", "fa_num_kernels", "fa_get_kernel", "fa_last_error", "fa_version",
     "fa_fwd_masked_supported", "fa_fwd_launch_masked", "fa_device_state",
     "fa_fwd_ex_supported", "fa_fwd_launch_ex", "fa_fwd_query",
+    "fa_adaptive_state", "fa_adaptive_reset", "fa_get_kernel_sized", "fa_fwd_query_sized", "fa_abi_version",
 )
+FA_SPECULATIVE_OFF, FA_SPECULATIVE_ALWAYS, FA_SPECULATIVE_ADAPTIVE = 0, 1, 2  # fa_speculative_mode
+FA_ABI_VERSION = 4
 SOFTMAX_MODES = ("eager", "first_block_skip", "lazy", "speculative")  # fa_softmax_mode
 
 
@@ -70,11 +75,21 @@ class FaFwdOpts(ctypes.Structure):
     ]
 
 
+class FaAdaptiveInfo(ctypes.Structure):
+    """fa_adaptive_info: the adaptive speculative mode's record on one device."""
+
+    _fields_ = [(name, ctypes.c_uint32) for name in
+                ("available", "launches", "demoted", "reports", "hold", "demote_until", "last_report")]
+
+
 def make_opts(causal=False, allow_ragged=False, speculative=False, prescaled_q=False, ms=None, stats_ptr=None):
+    """`speculative`: False / True, or "adaptive" (= 2, FA_SPECULATIVE_ADAPTIVE)."""
     o = FaFwdOpts()
     o.struct_size = ctypes.sizeof(FaFwdOpts)
     o.causal, o.allow_ragged = int(bool(causal)), int(bool(allow_ragged))
-    o.speculative, o.prescaled_q = int(bool(speculative)), int(bool(prescaled_q))
+    o.speculative = FA_SPECULATIVE_ADAPTIVE if speculative in ("adaptive", FA_SPECULATIVE_ADAPTIVE) and speculative is not True \
+        else int(bool(speculative))
+    o.prescaled_q = int(bool(prescaled_q))
     if ms is not None:
         o.ms = ctypes.pointer(ms)
     o.stats = stats_ptr
@@ -132,6 +147,16 @@ def load():
     lib.fa_num_kernels.argtypes = []
     lib.fa_get_kernel.restype = ctypes.c_int
     lib.fa_get_kernel.argtypes = [ctypes.c_int, ctypes.POINTER(FaKernelInfo)]
+    lib.fa_adaptive_state.restype = ctypes.c_int
+    lib.fa_adaptive_state.argtypes = [ctypes.c_int, ctypes.POINTER(FaAdaptiveInfo)]
+    lib.fa_adaptive_reset.restype = ctypes.c_int
+    lib.fa_adaptive_reset.argtypes = [ctypes.c_int]
+    lib.fa_get_kernel_sized.restype = ctypes.c_int
+    lib.fa_get_kernel_sized.argtypes = [ctypes.c_int, ctypes.POINTER(FaKernelInfo), ctypes.c_uint32]
+    lib.fa_fwd_query_sized.restype = ctypes.c_int
+    lib.fa_fwd_query_sized.argtypes = [cfg_p, ctypes.POINTER(FaFwdOpts), ctypes.POINTER(FaKernelInfo), ctypes.c_uint32]
+    lib.fa_abi_version.restype = ctypes.c_int
+    lib.fa_abi_version.argtypes = []
     lib.fa_last_error.restype = ctypes.c_char_p
     lib.fa_last_error.argtypes = []
     lib.fa_version.restype = ctypes.c_char_p
@@ -211,3 +236,14 @@ def device_state(device: int):
     a, b, c = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
     check(load().fa_device_state(int(device), ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
     return bool(a.value), b.value, c.value
+
+
+def adaptive_state(device: int) -> dict:
+    """fa_adaptive_state: the adaptive speculative mode's record on `device` as a dict."""
+    info = FaAdaptiveInfo()
+    check(load().fa_adaptive_state(int(device), ctypes.byref(info)))
+    return {name: int(getattr(info, name)) for name, _ in FaAdaptiveInfo._fields_}
+
+
+def adaptive_reset(device: int) -> None:
+    check(load().fa_adaptive_reset(int(device)))

@@ -112,11 +112,33 @@ const fa::KernelEntry *find_kernel(const fa_fwd_config *c, const char **why, con
 // kernel function all belong to the device that is current at the call, so a process that drives several
 // GPUs gets each of them initialised at its first launch there, and a failure on one device (not a gfx950)
 // does not stick to the others.
+// Adaptive speculative softmax (fa_fwd_opts.speculative == FA_SPECULATIVE_ADAPTIVE).  A speculative launch whose
+// first pass fails some item computes that item twice, and a launch ends with its slowest workgroup: ONE failing item
+// costs a whole item time.  The kernels report such a launch by storing its sequence number into one
+// word of pinned host memory (KernelArgs::redo_flag; nothing is written by a launch without failures).  The library
+// looks at that word -- a plain host read, no synchronisation: it sees what has completed so far -- when the next
+// adaptive launch is enqueued, and after a reported failure enqueues the NON-speculative variant of the configuration
+// for the next `hold` adaptive launches on that device, then probes again; a probe that fails as well doubles `hold`
+// (32 ... 4096), a long quiet stretch resets it.  Both variants give a valid result (they differ in the rounding point
+// of P); which one served a given launch depends on when the report arrived, so bit-reproducible callers ask for
+// speculative = 0 or 1 instead.
+struct AdaptiveState {
+    std::mutex mu;
+    uint32_t *flag_host = nullptr;  // hipHostMalloc'ed (mapped, coherent) word; null: no pinned memory -> always speculative
+    uint32_t *flag_dev = nullptr;   // the same word as the device addresses it
+    uint32_t seq = 0;               // adaptive launches enqueued on this device so far
+    uint32_t seen = 0;              // the last report acted on
+    uint32_t demote_until = 0;      // launches with seq <= this take the non-speculative variant
+    uint32_t hold = 32;
+    uint32_t demoted = 0;           // adaptive launches that took the non-speculative variant
+    uint32_t reports = 0;           // distinct failure reports seen
+};
 struct DeviceState {
     std::once_flag once;
     int status = FA_OK;
     char err[256] = "";
     int num_cus = 256;  // persistent variants launch one workgroup per CU
+    AdaptiveState adaptive;
     std::atomic<int> inited{0};  // published LAST (release): a reader that sees 1 sees the final status and num_cus
 };
 constexpr int kMaxDevices = 64;
@@ -158,6 +180,18 @@ void do_init_body(int dev, DeviceState *st) {
 
 void do_init(int dev, DeviceState *st) {
     do_init_body(dev, st);
+    if (st->status == FA_OK) {  // the adaptive mode's report word (see AdaptiveState); without it the mode stays speculative
+        void *h = nullptr, *d = nullptr;
+        if (hipHostMalloc(&h, 64, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess && h &&
+            hipHostGetDevicePointer(&d, h, 0) == hipSuccess && d) {
+            memset(h, 0, 64);
+            st->adaptive.flag_host = (uint32_t *)h;
+            st->adaptive.flag_dev = (uint32_t *)d;
+        } else {
+            (void)hipGetLastError();
+            if (h) (void)hipHostFree(h);
+        }
+    }
     st->inited.store(1, std::memory_order_release);
 }
 
@@ -230,9 +264,11 @@ int validate(const fa_fwd_args *a, const fa::KernelEntry **out, const Want &want
 }
 
 int launch(const fa_fwd_args *a, const fa::KernelEntry *e, const DeviceState *dev, hipStream_t stream, int causal = 0,
-           fa_fwd_stats *stats = nullptr) {
+           fa_fwd_stats *stats = nullptr, uint32_t *redo_flag = nullptr, uint32_t redo_seq = 0) {
     fa::KernelArgs ka;
     ka.stats = (uint32_t *)stats;
+    ka.redo_flag = redo_flag;
+    ka.redo_seq = redo_seq;
     ka.q = a->q;
     ka.k = a->k;
     ka.v = a->v;
@@ -305,15 +341,16 @@ int fa_fwd_lds_bytes(const fa_fwd_config *cfg) {
 // Enqueue (ms == nullptr) or enqueue between two events on the stream and wait for the second one
 // (flash_attention.cu:119-132).  Whatever was created is destroyed on every path.
 static int launch_maybe_timed(const fa_fwd_args *args, const fa::KernelEntry *e, const DeviceState *dev,
-                              hipStream_t s, int causal, float *ms, fa_fwd_stats *stats = nullptr) {
-    if (!ms) return launch(args, e, dev, s, causal, stats);
+                              hipStream_t s, int causal, float *ms, fa_fwd_stats *stats = nullptr,
+                              uint32_t *redo_flag = nullptr, uint32_t redo_seq = 0) {
+    if (!ms) return launch(args, e, dev, s, causal, stats, redo_flag, redo_seq);
     hipEvent_t start = nullptr, stop = nullptr;
     hipError_t hrc = hipEventCreate(&start);
     if (hrc == hipSuccess) hrc = hipEventCreate(&stop);
     if (hrc == hipSuccess) hrc = hipEventRecord(start, s);
     int rc = FA_OK;
     if (hrc == hipSuccess) {
-        rc = launch(args, e, dev, s, causal, stats);
+        rc = launch(args, e, dev, s, causal, stats, redo_flag, redo_seq);
         hrc = hipEventRecord(stop, s);  // (recorded even if the launch failed: nothing is left pending)
         if (hrc == hipSuccess) hrc = hipEventSynchronize(stop);
     }
@@ -398,13 +435,81 @@ int fa_fwd_launch_ex(const fa_fwd_args *args, const fa_fwd_opts *opts, void *str
     w.ragged = o.allow_ragged != 0;
     w.speculative = o.speculative != 0;
     w.prescaled_q = o.prescaled_q != 0;
+    if (o.speculative < 0 || o.speculative > FA_SPECULATIVE_ADAPTIVE)
+        return fail(FA_ERR_SHAPE, "fa_fwd_opts.speculative must be 0, 1 (always) or 2 (adaptive), not %d", o.speculative);
     const fa::KernelEntry *e = nullptr;
     rc = validate(args, &e, w);
     if (rc != FA_OK) return rc;
     if (o.stats && ((uintptr_t)o.stats & 3)) return fail(FA_ERR_ALIGN, "fa_fwd_opts.stats must be 4-byte aligned");
-    const DeviceState *dev = current_device(&rc);
+    DeviceState *dev = current_device(&rc);
     if (!dev) return rc;
-    return launch_maybe_timed(args, e, dev, (hipStream_t)stream, o.causal != 0, o.ms, o.stats);
+    uint32_t *redo_flag = nullptr;
+    uint32_t redo_seq = 0;
+    if (o.speculative == FA_SPECULATIVE_ADAPTIVE) {
+        // (the speculative variant exists: validated above.  Its non-speculative sibling serves a demoted launch)
+        AdaptiveState &ad = dev->adaptive;
+        bool demote = false;
+        {
+            std::lock_guard<std::mutex> lock(ad.mu);
+            const uint32_t seq = ++ad.seq;
+            const uint32_t rep = ad.flag_host ? __atomic_load_n(ad.flag_host, __ATOMIC_RELAXED) : 0u;
+            if (rep != ad.seen) {  // a speculative launch that has completed since computed items twice
+                ad.seen = rep;
+                ++ad.reports;
+                if (ad.demote_until != 0 && rep > ad.demote_until && ad.hold < 4096) ad.hold *= 2;  // a probe behind a hold failed too
+                ad.demote_until = seq + ad.hold;
+            } else if (ad.demote_until != 0 && seq > ad.demote_until + 8u * ad.hold) {
+                ad.hold = 32;  // long quiet: forget the back-off
+                ad.demote_until = 0;
+            }
+            demote = ad.demote_until != 0 && seq <= ad.demote_until;
+            if (demote) ++ad.demoted;
+            redo_flag = ad.flag_dev;
+            redo_seq = seq;
+        }
+        if (demote) {
+            Want w2 = w;
+            w2.speculative = false;
+            const fa::KernelEntry *e2 = nullptr;
+            if (validate(args, &e2, w2) == FA_OK) {
+                e = e2;
+                redo_flag = nullptr;
+            }  // (no such sibling: the speculative variant stays)
+        }
+    }
+    return launch_maybe_timed(args, e, dev, (hipStream_t)stream, o.causal != 0, o.ms, o.stats, redo_flag, redo_seq);
+}
+
+int fa_adaptive_state(int device, fa_adaptive_info *out) {
+    if (!out) return fail(FA_ERR_NULL, "null output");
+    if (device < 0 || device >= kMaxDevices) return fail(FA_ERR_DEVICE, "device ordinal %d out of range", device);
+    memset(out, 0, sizeof(*out));
+    DeviceState &st = g_dev[device];
+    if (!st.inited.load(std::memory_order_acquire)) return FA_OK;
+    AdaptiveState &ad = st.adaptive;
+    std::lock_guard<std::mutex> lock(ad.mu);
+    out->launches = ad.seq;
+    out->demoted = ad.demoted;
+    out->reports = ad.reports;
+    out->hold = ad.hold;
+    out->demote_until = ad.demote_until;
+    out->last_report = ad.flag_host ? __atomic_load_n(ad.flag_host, __ATOMIC_RELAXED) : 0u;
+    out->available = ad.flag_host != nullptr;
+    return FA_OK;
+}
+
+int fa_adaptive_reset(int device) {
+    if (device < 0 || device >= kMaxDevices) return fail(FA_ERR_DEVICE, "device ordinal %d out of range", device);
+    DeviceState &st = g_dev[device];
+    if (!st.inited.load(std::memory_order_acquire)) return FA_OK;
+    AdaptiveState &ad = st.adaptive;
+    std::lock_guard<std::mutex> lock(ad.mu);
+    ad.seen = ad.flag_host ? __atomic_load_n(ad.flag_host, __ATOMIC_RELAXED) : 0u;
+    ad.demote_until = 0;
+    ad.hold = 32;
+    ad.demoted = 0;
+    ad.reports = 0;
+    return FA_OK;
 }
 
 int fa_num_kernels(void) { return (int)registry().size(); }
@@ -464,8 +569,28 @@ static void fill_info(const fa::KernelEntry &e, fa_kernel_info *out) {
     }
 }
 
+int fa_get_kernel_sized(int index, fa_kernel_info *out, uint32_t out_size) {
+    if (!out) return fail(FA_ERR_NULL, "null output");
+    fa_kernel_info full;
+    const int rc = fa_get_kernel(index, &full);
+    if (rc != FA_OK) return rc;
+    memcpy(out, &full, out_size < sizeof(full) ? out_size : sizeof(full));
+    return FA_OK;
+}
+
+int fa_fwd_query_sized(const fa_fwd_config *cfg, const fa_fwd_opts *opts, fa_kernel_info *out, uint32_t out_size) {
+    if (!out) return fail(FA_ERR_NULL, "null pointer argument");
+    fa_kernel_info full;
+    const int rc = fa_fwd_query(cfg, opts, &full);
+    if (rc != FA_OK) return rc;
+    memcpy(out, &full, out_size < sizeof(full) ? out_size : sizeof(full));
+    return FA_OK;
+}
+
+int fa_abi_version(void) { return FA_ABI_VERSION; }
+
 const char *fa_last_error(void) { return g_err; }
 
-const char *fa_version(void) { return "fa_hip 0.3 gfx950"; }
+const char *fa_version(void) { return "fa_hip 0.4 gfx950"; }
 
 }  // extern "C"

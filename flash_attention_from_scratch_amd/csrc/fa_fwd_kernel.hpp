@@ -80,6 +80,11 @@ struct KernelArgs {
     int32_t n_kv_blocks;
     int32_t causal;        // MASK variants only: key j contributes to query i iff j <= i
     uint32_t *stats = nullptr;  // nullptr, or two device counters the kernel adds to (fa_fwd_stats: items, items_redone)
+    // adaptive speculative softmax (fa_fwd_opts.speculative == 2): nullptr, or one word of pinned HOST memory into which a
+    // workgroup that had to compute an item twice stores this launch's sequence number -- written only then, so a
+    // launch without failures costs nothing; the library reads it, without waiting, at its next launches
+    uint32_t *redo_flag = nullptr;
+    uint32_t redo_seq = 0;
 #ifdef FA_TRACE
     unsigned long long *trace;  // tools/segment_timer.hip only: [wave][visit][8] s_memtime stamps
     int32_t trace_block;
@@ -98,6 +103,11 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 #define FA_LDS(type) __attribute__((address_space(3))) type
 #define FA_DEV __device__ __forceinline__
+
+// (see KernelArgs::redo_flag)  Every writer of a launch stores the same value: a plain system-scope store, no atomic
+FA_DEV void report_redo(const KernelArgs &args) {
+    if (args.redo_flag) __hip_atomic_store(args.redo_flag, args.redo_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 
 template <bool B> struct BoolTag { static constexpr bool value = B; };
 template <int I> struct IntTag { static constexpr int value = I; };
@@ -1045,6 +1055,7 @@ fa_fwd_kernel(const KernelArgs args) {
     };  // attempt
     bool done = false;
     if constexpr (SPEC) done = attempt(TrueTag{});
+    if (SPEC && !done && threadIdx.x == 0) report_redo(args);
     if (args.stats && threadIdx.x == 0) {  // fa_fwd_stats: one item per workgroup; redone = the speculative pass failed
         atomicAdd(args.stats, 1u);
         if (SPEC && !done) atomicAdd(args.stats + 1, 1u);

@@ -288,6 +288,7 @@ fa_fwd_kernel16(const KernelArgs args) {
     };
     bool done = false;
     if constexpr (SPEC) done = attempt(TrueTag{});
+    if (SPEC && !done && threadIdx.x == 0) report_redo(args);
     if (args.stats && threadIdx.x == 0) {  // fa_fwd_stats: one item per workgroup; redone = the speculative pass failed
         atomicAdd(args.stats, 1u);
         if (SPEC && !done) atomicAdd(args.stats + 1, 1u);

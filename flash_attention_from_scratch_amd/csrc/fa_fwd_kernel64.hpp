@@ -18,13 +18,23 @@ struct Plan64 {
     signed char dma[64];                   // DMA piece 0..7 (even = K, odd = V) or -1
     signed char tail[64];                  // end-of-visit chain step 1.. or 0
     signed char barrier[64];               // 1: the visit's counted DMA wait + workgroup barrier
+    signed char early_first[64], early_n[64];  // rotated plan: softmax units of the NEXT tile (S(it+1)), first rot_k of its 32
 };
 // variant bits (tools/tune64.hip): 1 barrier at the visit top instead of inside the MFMA stream,
 // 2 DMA pieces late in phase 2 instead of early in phase 1
 #ifndef FA_RING_SLOTS
 #define FA_RING_SLOTS 4
 #endif
-constexpr Plan64 make_plan64(int variant, int n_phase1) {
+#ifndef FA_ROT_DEFAULT
+#define FA_ROT_DEFAULT 4   // softmax units of the next tile carried in a visit's last gaps (speculative plain forms)
+#endif
+// rot_k (speculative schedule only, DESIGN.md 3.5 "rotated units"): the last gaps of a visit run at the matrix pipe's own
+// rate with issue slots to spare (the P.V MFMAs of the last 16-key slice; every unit of tile `it` has to be done two gaps
+// before its slice is consumed, i.e. by gap 54), while phase 1 is issue bound.  So the first rot_k units of the NEXT tile
+// -- S(it+1) is complete from gap 32 on, and P's slice 0 registers are free once gap 40 has issued -- ride in those last
+// gaps, and a visit carries units rot_k .. 31 of its own tile + units 0 .. rot_k-1 of the next.  chain_gap: the gap that
+// carries the next request pointers (the end-of-visit chain's last step; 63 = behind the last MFMA, as first built).
+constexpr Plan64 make_plan64(int variant, int n_phase1, int rot_k = 0, int chain_gap = 63) {
     Plan64 p{};
     const bool bar_top = variant & 1, dma_late = variant & 2, masked = variant & 4, nomax = variant & 8, even = variant & 16;
     // nomax (the speculative schedule): no row-max units, no end-of-visit chain (only its last step, the
@@ -34,7 +44,10 @@ constexpr Plan64 make_plan64(int variant, int n_phase1) {
     // masked: gaps 32..35 of a diagonal visit rewrite S(it+1) (causal mask) before its row max is
     // taken, so the 32 row-max units start 4 gaps later and the end-of-visit chain runs in 5 steps
     const int m0 = masked ? 4 : 0, odd0 = masked ? 11 : 9, mend = masked ? 27 : 24;
-    int e = 0, m = 0, d = 0, slot_nm = 0;
+    int e = rot_k, m = 0, d = 0, slot_nm = 0, ee = 0;
+    const int e1_end = rot_k + n_phase1;   // phase 1 carries units rot_k .. e1_end - 1
+    // early units, one per gap: the odd gaps 55 .. 63 first (no operand reads there), then the even ones
+    constexpr int early_order[10] = {55, 57, 59, 61, 63, 54, 56, 58, 60, 62};
     int n_slots_nm = 0;
     for (int g = 1; g <= 54; ++g) n_slots_nm += ((g & 3) != 0 && g != 2) ? 1 : 0;
     for (int g = 0; g < 64; ++g) {
@@ -53,7 +66,7 @@ constexpr Plan64 make_plan64(int variant, int n_phase1) {
             // pieces follow it, one per four gaps
             if ((g & 3) == 0) {
                 if (!dma_late && (bar_top || g >= 4)) dm = d++;
-            } else if (e < n_phase1 && (bar_top || g != 2)) {
+            } else if (e < e1_end && (bar_top || g != 2)) {
                 const int slot = (g >> 2) * 3 + (g & 3) - 1;          // 0..23 over the gaps with g % 4 != 0
                 if ((slot + 1) * n_phase1 / 24 > slot * n_phase1 / 24) ne = 1;
             }
@@ -70,8 +83,11 @@ constexpr Plan64 make_plan64(int variant, int n_phase1) {
             if (dma_late && h >= 24) dm = d++;
             if (masked) { if (h >= 27) tl = 10 + (h - 27); }          // merged chain steps 10..14
             else if (h >= 24) tl = h - 23;                            // chain steps 1..8
-            if (nomax) { nm = 0; tl = (h == 31) ? 8 : 0; }
+            if (nomax) { nm = 0; tl = (g == chain_gap) ? 8 : 0; }
         }
+        int nearly = 0;
+        for (int i = 0; i < rot_k && i < 10; ++i) nearly += early_order[i] == g ? 1 : 0;
+        p.early_first[g] = (signed char)ee; p.early_n[g] = (signed char)nearly; ee += nearly;
         p.exp_first[g] = (signed char)e; p.exp_n[g] = (signed char)ne; e += ne;
         p.max_first[g] = (signed char)m; p.max_n[g] = (signed char)nm; m += nm;
         p.dma[g] = (signed char)dm; p.tail[g] = (signed char)tl;
@@ -79,13 +95,18 @@ constexpr Plan64 make_plan64(int variant, int n_phase1) {
     }
     return p;
 }
-constexpr bool plan64_ok(const Plan64 &p) {
-    int e = 0, m = 0, d = 0, bar = -1;
+constexpr bool plan64_ok(const Plan64 &p, int rot_k = 0) {
+    int e = rot_k, m = 0, d = 0, bar = -1, ee = 0;
     bool chain = false;  // the plan carries the row max + the end-of-visit chain (not the speculative schedule)
     for (int g = 0; g < 64; ++g) {
         // P of 16-key slice s16 is consumed from gap 32 + 8 s16 on: its units must be >= 2 gaps older
         for (int u = p.exp_first[g]; u < p.exp_first[g] + p.exp_n[g]; ++u)
             if (g + 2 > 32 + 8 * (u >> 3)) return false;
+        // an early unit (of the next tile) writes P's slice u >> 3, last read by the MFMA of gap 32 + 8 (u >> 3) + 7 (whose
+        // operands stay allocated until the next MFMA has issued), and reads S(it+1), complete two MFMAs behind gap 31
+        for (int u = p.early_first[g]; u < p.early_first[g] + p.early_n[g]; ++u)
+            if (g < 32 + 8 * (u >> 3) + 9 || g < 34 || u >= 16) return false;
+        ee += p.early_n[g];
         // S(it+1) tiles: nt = 0 last written at gap 29, nt = 1 at gap 31; read >= 2 MFMAs later
         for (int u = p.max_first[g]; u < p.max_first[g] + p.max_n[g]; ++u)
             if (g < ((u >> 4) ? 34 : 32)) return false;
@@ -96,7 +117,7 @@ constexpr bool plan64_ok(const Plan64 &p) {
         if (p.barrier[g] && g >= 28) return false;                    // V(it+1) is first read at gap 30
         e += p.exp_n[g]; m += p.max_n[g]; d += p.dma[g] >= 0;
     }
-    return e == 32 && m == (chain ? 32 : 0) && d == 8;
+    return e == 32 && ee == rot_k && m == (chain ? 32 : 0) && d == 8;
 }
 
 // (the reference's meaning of optimized_softmax -- the first tile skips the rescale -- holds here by
@@ -407,9 +428,14 @@ fa_fwd_kernel64(const KernelArgs args) {
             static_assert(DMA && D == 128 && BC == 64 && NT == 2 && NWAVES == 4, "64-row pinned schedule");
             static_assert(TR::kStages == 4, "ring depth");
             constexpr float TAU = 8.0f;
+            // rotated units (make_plan64): ABL bits 24..27 = rot_k for tools/tune64.hip (15 = off, 0 = the shipped value),
+            // bit 28 = the next request pointers in gap 58 instead of behind the last MFMA
+            constexpr int ROT_REQ = (ABL >> 24) & 15;
+            constexpr int ROT_K = (FAST && !MASK) ? (ROT_REQ == 15 ? 0 : (ROT_REQ ? ROT_REQ : FA_ROT_DEFAULT)) : 0;
+            constexpr int CHAIN_GAP = (FAST && (ABL & (1 << 28))) ? 58 : 63;
             constexpr Plan64 plan = make_plan64(((ABL >> 8) & 3) | (MASK ? 4 : 0) | (FAST ? 8 : 0) | ((ABL & 8192) ? 16 : 0),
-                                                (ABL & 1024) ? 20 : ((ABL & 16384) ? 23 : 22));
-            static_assert(plan64_ok(plan), "filler plan violates a wait-state distance");
+                                                ((ABL & 1024) ? 20 : ((ABL & 16384) ? 23 : 22)) - ROT_K, ROT_K, CHAIN_GAP);
+            static_assert(plan64_ok(plan, ROT_K), "filler plan violates a wait-state distance");
             f32x16 Sa[2][NT], Sb[2][NT];
             u32x4 Pw[2][4] = {};     // P[qt][16-key slice]: B operand of O^T += V^T P^T
             float neg_msc[2];        // -(m c)
@@ -653,6 +679,66 @@ fa_fwd_kernel64(const KernelArgs args) {
             };
             auto request_next_q = [&](int qt) { request_q(Qn, qb_n, qt, q_stage); };
             auto read_next_q = [&](vec8 (&dst)[KS]) { read_q(dst, q_stage); };
+            // one softmax unit = two elements of a tile's P: u = 8*s16 + 2*j + qt, in the order P.V consumes P.  Where its two
+            // values go: SUM_RS the running row sums; SUM_EARLY the side sums rs_e of the rotated plan's early units (SET_EARLY:
+            // the first unit of a Q tile starts them: no add), folded into rs by the next visit; SUM_NONE nowhere (the guard's
+            // rare path forming the early units' packed P again)
+            constexpr int SUM_RS = 0, SUM_EARLY = 1, SET_EARLY = 2, SUM_NONE = 3;
+            float rs_e[2][2] = {{0.0f, 0.0f}, {0.0f, 0.0f}};
+            auto exp_unit_on = [&](auto &S_src, int u, auto sum_tag) {
+                constexpr int SUM = decltype(sum_tag)::value;
+                if constexpr (ABL & 2) return;
+                const int qt = u & 1, j = (u >> 1) & 3, s16 = u >> 3, r = 8 * (s16 & 1) + 2 * j;
+                // exp2(s c - m c), softmax.cuh:51-64.  Scalar f32 forms on purpose: v_pk_fma_f32 /
+                // v_pk_add_f32 here measured -6 % / -12 %; splitting the unit into stages over three
+                // gaps (no dependent pair inside a gap) measured -1.5 %.
+                float p0, p1;
+                if constexpr (ABL & 2048) {  // (timing only: what a pre-scaled Q with -m c fed through the MFMA's C operand would save)
+                    p0 = S_src[qt][s16 >> 1][r];
+                    p1 = S_src[qt][s16 >> 1][r + 1];
+                } else if constexpr (PSQ && FAST) {  // -(m c) came in through the C operand of the tile's first MFMA
+                    p0 = S_src[qt][s16 >> 1][r];
+                    p1 = S_src[qt][s16 >> 1][r + 1];
+                } else if constexpr (PSQ) {
+                    p0 = vadd(S_src[qt][s16 >> 1][r], neg_msc[qt]);
+                    p1 = vadd(S_src[qt][s16 >> 1][r + 1], neg_msc[qt]);
+                } else {
+                    p0 = __builtin_fmaf(S_src[qt][s16 >> 1][r], c, neg_msc[qt]);
+                    p1 = __builtin_fmaf(S_src[qt][s16 >> 1][r + 1], c, neg_msc[qt]);
+                }
+                if (!(ABL & 1)) {
+                    p0 = __builtin_amdgcn_exp2f(p0);
+                    p1 = __builtin_amdgcn_exp2f(p1);
+                }
+                if constexpr (SUM == SUM_RS && !(ABL & 32)) {  // (ABL & 32, tools/tune64.hip, TIMING ONLY: no row sums)
+                    rs[qt][0] += p0;  // fp32 P, before rounding (softmax.cuh:66-83)
+                    rs[qt][1] += p1;
+                    // pin the adds to this gap: hipcc otherwise sinks the whole row-sum chain (and keeps
+                    // every p alive) to the first use of l, behind the next visit's barrier
+                    asm volatile("" : "+v"(rs[qt][0]), "+v"(rs[qt][1]));
+                }
+                if constexpr (SUM == SUM_EARLY && !(ABL & 32)) {
+                    rs_e[qt][0] += p0;
+                    rs_e[qt][1] += p1;
+                    asm volatile("" : "+v"(rs_e[qt][0]), "+v"(rs_e[qt][1]));
+                }
+                if constexpr (SUM == SET_EARLY) {
+                    rs_e[qt][0] = p0;
+                    rs_e[qt][1] = p1;
+                    asm volatile("" : "+v"(rs_e[qt][0]), "+v"(rs_e[qt][1]));
+                }
+                unsigned pk = E::pack2(p0, p1);
+                // ... and the pack: sunk below a branch of the stream it would sit right in front of the
+                // MFMA that reads it, which hipcc does not pad (the MFMAs are opaque asm)
+                asm volatile("" : "+v"(pk));
+                Pw[qt][s16][j] = pk;
+            };
+            // rotated plan: units 0 .. ROT_K-1 of an item's FIRST tile, which no visit's last gaps could carry (the item's
+            // reference was not known yet): straight code behind the prologue / the seam, once per item
+            auto head_units = [&](auto &S0) {
+                                if constexpr (ROT_K > 0)
+                    static_for<0, ROT_K>([&](auto i) { exp_unit_on(S0, decltype(i)::value, IntTag<(decltype(i)::value < 2 ? SET_EARLY : SUM_EARLY)>{}); });
+            };
             auto visit = [&](int it, auto &S_cur, auto &S_nxt, auto r_tag) {
                 constexpr int R = decltype(r_tag)::value;  // it & 3
 #if defined(FA_TRACE) && FA_TRACE < 4
@@ -765,41 +851,6 @@ fa_fwd_kernel64(const KernelArgs args) {
                 const char *vt = smem + V_BASE + R * TILE;
                 float vm[2][2];
                 unsigned any01 = 0;
-                auto exp_unit = [&](int u) {  // u = 8*s16 + 2*j + qt: in the order P.V consumes P
-                    if constexpr (ABL & 2) return;
-                    const int qt = u & 1, j = (u >> 1) & 3, s16 = u >> 3, r = 8 * (s16 & 1) + 2 * j;
-                    // exp2(s c - m c), softmax.cuh:51-64.  Scalar f32 forms on purpose: v_pk_fma_f32 /
-                    // v_pk_add_f32 here measured -6 % / -12 %; splitting the unit into stages over three
-                    // gaps (no dependent pair inside a gap) measured -1.5 %.
-                    float p0, p1;
-                    if constexpr (ABL & 2048) {  // (timing only: what a pre-scaled Q with -m c fed through the MFMA's C operand would save)
-                        p0 = S_cur[qt][s16 >> 1][r];
-                        p1 = S_cur[qt][s16 >> 1][r + 1];
-                    } else if constexpr (PSQ && FAST) {  // -(m c) came in through the C operand of the tile's first MFMA
-                        p0 = S_cur[qt][s16 >> 1][r];
-                        p1 = S_cur[qt][s16 >> 1][r + 1];
-                    } else if constexpr (PSQ) {
-                        p0 = vadd(S_cur[qt][s16 >> 1][r], neg_msc[qt]);
-                        p1 = vadd(S_cur[qt][s16 >> 1][r + 1], neg_msc[qt]);
-                    } else {
-                        p0 = __builtin_fmaf(S_cur[qt][s16 >> 1][r], c, neg_msc[qt]);
-                        p1 = __builtin_fmaf(S_cur[qt][s16 >> 1][r + 1], c, neg_msc[qt]);
-                    }
-                    if (!(ABL & 1)) {
-                        p0 = __builtin_amdgcn_exp2f(p0);
-                        p1 = __builtin_amdgcn_exp2f(p1);
-                    }
-                    rs[qt][0] += p0;  // fp32 P, before rounding (softmax.cuh:66-83)
-                    rs[qt][1] += p1;
-                    // pin the adds to this gap: hipcc otherwise sinks the whole row-sum chain (and keeps
-                    // every p alive) to the first use of l, behind the next visit's barrier
-                    asm volatile("" : "+v"(rs[qt][0]), "+v"(rs[qt][1]));
-                    unsigned pk = E::pack2(p0, p1);
-                    // ... and the pack: sunk below a branch of the stream it would sit right in front of the
-                    // MFMA that reads it, which hipcc does not pad (the MFMAs are opaque asm)
-                    asm volatile("" : "+v"(pk));
-                    Pw[qt][s16][j] = pk;
-                };
                 auto max_unit = [&](int u) {  // u = 0..31: tile (nt = u>>4, qt = (u>>3)&1), elements 2(u&7), +1
                     const int nt = u >> 4, qt = (u >> 3) & 1, e = 2 * (u & 7), a = u & 1;  // two chains per Q tile
                     if constexpr (ABL & 2) { vm[qt][a] = 0.0f; return; }
@@ -863,7 +914,7 @@ fa_fwd_kernel64(const KernelArgs args) {
                     if constexpr (ABL & 4) return __builtin_bit_cast(vec8, Pw[u & 1][(u >> 1) & 3]);
                     return u < 16 ? k_frag(kt, u) : (u < 32 ? v_frag(vt, u - 16) : k_frag(kt_next, u - 32));
                 };
-                static_for<0, 64>([&](auto gap_tag) {
+                auto gap_body = [&](auto gap_tag) {
                     constexpr int g = decltype(gap_tag)::value;
                     constexpr int step = g >> 1, qt = g & 1;
                     // An MFMA reads its A / B registers for a few cycles after it issues, and hipcc -- to
@@ -926,7 +977,20 @@ fa_fwd_kernel64(const KernelArgs args) {
                         if constexpr ((plan.dma[g] & 1) == 0) glds16_issue(kq, k_off[j]);
                         else glds16_issue(vq, v_off[j]);
                     }
-                    static_for<0, plan.exp_n[g]>([&](auto i) { exp_unit(plan.exp_first[g] + decltype(i)::value); });
+                    static_for<0, plan.exp_n[g]>([&](auto i) { exp_unit_on(S_cur, plan.exp_first[g] + decltype(i)::value, IntTag<SUM_RS>{}); });
+                    if constexpr (ROT_K > 0) {
+                        // (rotated plan) the side sums of this tile's early units -- formed in the previous visit's last gaps,
+                        // or by head_units -- join the row sums, in the last gaps before the next early units start them again
+                        if constexpr (g == 52 && !(ABL & 32)) { rs[0][0] += rs_e[0][0]; rs[0][1] += rs_e[0][1]; asm volatile("" : "+v"(rs[0][0]), "+v"(rs[0][1])); }
+                        if constexpr (g == 53 && !(ABL & 32)) { rs[1][0] += rs_e[1][0]; rs[1][1] += rs_e[1][1]; asm volatile("" : "+v"(rs[1][0]), "+v"(rs[1][1])); }
+                        // ... and the next tile's first units, against the same reference.  In an item's LAST visit that tile
+                        // is the next item's S(0), whose reference is not known yet: what the units leave then (packed P, side
+                        // sums) is formed again by head_units behind the seam, nothing else is touched
+                        static_for<0, plan.early_n[g]>([&](auto i) {
+                            constexpr int u = plan.early_first[g] + decltype(i)::value;
+                            exp_unit_on(S_nxt, u, IntTag<(u < 2 ? SET_EARLY : SUM_EARLY)>{});
+                        });
+                    }
                     static_for<0, plan.max_n[g]>([&](auto i) { max_unit(plan.max_first[g] + decltype(i)::value); });
                     if constexpr (plan.tail[g] > 0) tail_step(plan.tail[g]);
                     if constexpr (GUARD_IN_VISIT && R == 3) {
@@ -936,7 +1000,8 @@ fa_fwd_kernel64(const KernelArgs args) {
                         if constexpr (g == 60) guard_hit = __ballot(!(g_lm <= spec_guard<DT>())) != 0;
                     }
                     __builtin_amdgcn_sched_barrier(0);
-                });
+                };
+                static_for<0, 64>([&](auto gap_tag) { gap_body(gap_tag); });
                 if constexpr (FAST && MASK) {
                     // masked forms, speculative: a wave's reference is the row max of the FIRST tile it visits that is
                     // not masked whole -- causal: its diagonal tile 4 qb + wave; ragged: the last tile that holds keys
@@ -1002,6 +1067,7 @@ fa_fwd_kernel64(const KernelArgs args) {
                         const float sc = __builtin_ldexpf(1.0f, -e);              // a power of two: exact
                         rs[qt][0] *= sc;
                         rs[qt][1] *= sc;
+                        if constexpr (ROT_K > 0) { rs_e[qt][0] *= sc; rs_e[qt][1] *= sc; }
                         neg_msc[qt] -= (float)e;
 #pragma unroll
                         for (int t = 0; t < DTILES; ++t) {
@@ -1025,6 +1091,12 @@ fa_fwd_kernel64(const KernelArgs args) {
                         }
                     }
                     if constexpr (PSQ) asm volatile("s_nop 1" : "+v"(Cinit[0]), "+v"(Cinit[1]));
+                    // rotated plan: the next visit's first ROT_K units were exponentiated against the old references in the last
+                    // gaps of the visit that just ended -- their share of the row sums was scaled with the rest above, their packed
+                    // P is formed again against the new ones (everything at the old scale moves exactly once: guide T13)
+                    if constexpr (ROT_K > 0) {
+                        if (!behind_last_visit) static_for<0, ROT_K>([&](auto i) { exp_unit_on(S_cur, decltype(i)::value, IntTag<SUM_NONE>{}); });
+                    }
                     if (__ballot(!(nonfinite == 0.0f)) != 0) item_bad = true;  // inf or NaN somewhere in O
                     asm volatile("s_nop 3" ::: "memory");  // accvgpr write -> MFMA accumulator
                 }
@@ -1114,6 +1186,7 @@ fa_fwd_kernel64(const KernelArgs args) {
                     m_pend[qt] = m[qt];
                 }
                 set_cinit(Sa);
+                head_units(Sa);
                 if (!(ABL & 8)) {  // K(1) landed (under S(0)); younger: V(0), K(2), V(1) [, K(3), V(2) [, the next Q tile 0]]
                     if constexpr (DEFER) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
                     else if (has_next) asm volatile("s_waitcnt vmcnt(28)" ::: "memory");
@@ -1310,6 +1383,7 @@ fa_fwd_kernel64(const KernelArgs args) {
                 }
                 item_bad = false;
                 set_cinit(Sa);
+                head_units(Sa);
 #if defined(FA_TRACE) && FA_TRACE >= 4
                 if (tl_seam) tl_at(55);  // row max of S(0), softmax state reset
 #endif
@@ -1357,6 +1431,7 @@ fa_fwd_kernel64(const KernelArgs args) {
             barrier();  // (all four slots read before the second pass requests its first Q tile into one of them)
             redone = (unsigned)walk(BoolTag<false>{}, all);
         }
+        if (redone && threadIdx.x == 0) report_redo(args);
         if (args.stats && threadIdx.x == 0) {  // fa_fwd_stats: this workgroup's items, and how many of them ran twice
             const long long n_items = (long long)args.n_bh * args.n_q_blocks;
             atomicAdd(args.stats, (unsigned)((n_items - (long long)blockIdx.x + (long long)gridDim.x - 1) / (long long)gridDim.x));

@@ -26,6 +26,9 @@ import torch
 from . import _capi
 
 
+_STATS_DTYPES = tuple(d for d in (torch.int32, getattr(torch, "uint32", None)) if d is not None)  # (torch.uint32: torch >= 2.3)
+
+
 def _check_input(t, name):
     # CHECK_INPUT, src/include/cuda_utils.cuh:5-11
     if not t.is_cuda:
@@ -35,7 +38,11 @@ def _check_input(t, name):
 
 
 def _native_options(kernel_cfg):
+    """-> (speculative, prescaled_q); speculative is False, True, "adaptive" (fa_speculative_mode) or None = "where the
+    config has a speculative variant" (FA_ALLOW_SPECULATIVE=1 on a plain config)."""
     spec = bool(getattr(kernel_cfg, "speculative_softmax", False))
+    if spec and getattr(kernel_cfg, "adaptive_softmax", False):
+        spec = "adaptive"
     if not spec and getattr(kernel_cfg, "optimized_softmax", False) and os.environ.get("FA_ALLOW_SPECULATIVE", "") == "1":
         spec = None  # "if the config has a speculative variant": resolved against the registry below
     return spec, bool(getattr(kernel_cfg, "prescaled_q", False))
@@ -71,6 +78,14 @@ def forward(kernel_cfg, q, k, v, o=None, benchmark=False, causal=False, allow_ra
     if speculative is None:  # FA_ALLOW_SPECULATIVE=1: where the variant exists
         probe = _capi.make_opts(causal=causal, allow_ragged=allow_ragged, speculative=True, prescaled_q=prescaled_q)
         speculative = bool(lib.fa_fwd_ex_supported(ctypes.byref(cfg), ctypes.byref(probe)))
+    if speculative and masked:
+        # the masked forms of the 32- / 16-rows-per-wave kernels keep the running max (no speculative build): the request is
+        # dropped there, as kc.softmax_mode(cfg, masked=True) and the oracle's blockwise_for_config report
+        probe = _capi.make_opts(causal=causal, allow_ragged=allow_ragged, speculative=True, prescaled_q=prescaled_q)
+        if not lib.fa_fwd_ex_supported(ctypes.byref(cfg), ctypes.byref(probe)):
+            plain = _capi.make_opts(causal=causal, allow_ragged=allow_ragged, speculative=False, prescaled_q=prescaled_q)
+            if lib.fa_fwd_ex_supported(ctypes.byref(cfg), ctypes.byref(plain)):
+                speculative = False
     if speculative or prescaled_q:
         probe = _capi.make_opts(causal=causal, allow_ragged=allow_ragged, speculative=speculative, prescaled_q=prescaled_q)
         if not lib.fa_fwd_ex_supported(ctypes.byref(cfg), ctypes.byref(probe)):
@@ -109,7 +124,7 @@ def forward(kernel_cfg, q, k, v, o=None, benchmark=False, causal=False, allow_ra
     )
     stats_ptr = None
     if stats is not None:
-        if not stats.is_cuda or stats.device != q.device or stats.dtype not in (torch.int32, torch.uint32) \
+        if not stats.is_cuda or stats.device != q.device or stats.dtype not in _STATS_DTYPES \
                 or stats.numel() < 2 or not stats.is_contiguous():
             raise RuntimeError("stats must be a contiguous int32 / uint32 tensor of >= 2 elements on q's device")
         stats_ptr = stats.data_ptr()

@@ -119,6 +119,7 @@ _TAIL_WORDS = (
 # extensions of this build (NativeKernelConfig), spelled behind the reference's words
 _NATIVE_WORDS = (
     ("speculative_softmax", "spec_softmax"),
+    ("adaptive_softmax", "adaptive"),
     ("prescaled_q", "prescaled_q"),
 )
 
@@ -213,23 +214,34 @@ class NativeKernelConfig(FlashForwardKernelConfig):
 
     speculative_softmax: bool = False
     prescaled_q: bool = False
+    # with speculative_softmax: fa_speculative_mode ADAPTIVE (include/fa_hip.h) -- after a speculative launch on the device
+    # has reported items it computed twice, the library serves the next launches of this config with its non-speculative
+    # sibling for a while, then probes again.  Same tolerance either way; which of the two roundings a launch gets depends on
+    # the device's recent record, so bit-reproducible callers leave it off.
+    adaptive_softmax: bool = False
+
+    def __post_init__(self):
+        if self.adaptive_softmax and not self.speculative_softmax:
+            raise ValueError("adaptive_softmax qualifies speculative_softmax: set both")
 
     def base(self) -> FlashForwardKernelConfig:
         """The plain 13-field config (what a reference user would pass)."""
         return FlashForwardKernelConfig(*(getattr(self, f.name) for f in fields(FlashForwardKernelConfig)))
 
 
-def as_native(cfg, speculative_softmax=None, prescaled_q=None) -> NativeKernelConfig:
+def as_native(cfg, speculative_softmax=None, prescaled_q=None, adaptive_softmax=None) -> NativeKernelConfig:
     """`cfg` (plain or native) as a NativeKernelConfig with the given extensions (None = keep / off)."""
     base = [getattr(cfg, f.name) for f in fields(FlashForwardKernelConfig)]
     spec = getattr(cfg, "speculative_softmax", False) if speculative_softmax is None else speculative_softmax
     psq = getattr(cfg, "prescaled_q", False) if prescaled_q is None else prescaled_q
-    return NativeKernelConfig(*base, speculative_softmax=bool(spec), prescaled_q=bool(psq))
+    ada = getattr(cfg, "adaptive_softmax", False) if adaptive_softmax is None else adaptive_softmax
+    return NativeKernelConfig(*base, speculative_softmax=bool(spec), prescaled_q=bool(psq), adaptive_softmax=bool(ada) and bool(spec))
 
 
 def config_sort_key(cfg):
     """Total order over plain and native configs (dataclass ordering refuses mixed classes)."""
-    return cfg.to_c_abi_tuple() + (bool(getattr(cfg, "speculative_softmax", False)), bool(getattr(cfg, "prescaled_q", False)))
+    return cfg.to_c_abi_tuple() + (bool(getattr(cfg, "speculative_softmax", False)), bool(getattr(cfg, "prescaled_q", False)),
+                                   bool(getattr(cfg, "adaptive_softmax", False)))
 
 
 # ---------------------------------------------------------------------------
@@ -594,20 +606,22 @@ def best_config(dtype=DType.BF16, seq_len=4096, masked=False) -> FlashForwardKer
     rounds of four 64-key tiles; measured ahead of the 32-rows-per-wave kernels from seq_len ~1000 up,
     profiles/r01/ragged_persistent.txt), otherwise 4 waves x 32 rows.
 
-    Softmax: bf16 takes the speculative softmax (the persistent kernel re-centres rising rows every four
-    visits, so only a JUMP of ~83 nats inside 256 keys sends an item to the second pass; the 32-row
-    fallback for other seq_len has no guard: ~44 nats above the max of the row's last 64 keys); fp16 does
-    NOT by default -- its 16-bit P leaves ~15
-    binades (~10 nats) of headroom, which attention-sink-like logits at the first keys (visited last)
-    exceed, and every such item then costs 2x (profiles/r03/sink_data.txt).  Ask for it explicitly
-    (``replace(cfg, speculative_softmax=True)``) when the logits are known to be flat."""
+    Softmax: the speculative softmax, ADAPTIVELY (``adaptive_softmax``; fa_speculative_mode in include/fa_hip.h), for
+    both dtypes.  The persistent kernel re-centres rising rows every four visits, so in bf16 only a JUMP of ~83 nats
+    inside 256 keys sends an item to the second pass; fp16's 16-bit P leaves ~10 nats, which attention-sink-like logits
+    at the first keys (visited last) exceed.  A failed item costs its workgroup a second item time, and a launch ends
+    with its slowest workgroup (profiles/r03/sink_data.txt: heavy-tailed K, bf16, 5 of 1024 items: -9 %; sink data, fp16,
+    every item: -49 %) -- so the library watches the failure reports of its speculative launches and, once one arrives,
+    serves the following launches with the running-max (lazy) variant, probing the speculative one again every so often
+    (round 3 shipped fp16 without the speculative softmax for this reason, and bf16 with the cliff).  Both variants are
+    inside the same tolerance; ask for ``adaptive_softmax=False`` (always speculative) or ``speculative_softmax=False``
+    (never) where the last bits have to be reproducible from run to run."""
     dtype = DType(dtype)
-    spec = dtype == DType.BF16
     pad = (-seq_len) % 256
     if pad == 0 or (masked and seq_len >= 64 and pad * 8 <= seq_len):
         return NativeKernelConfig(
-            dtype, 128, 256, 64, 4, True, True, True, 0, 0, 0, True, False, speculative_softmax=spec
+            dtype, 128, 256, 64, 4, True, True, True, 0, 0, 0, True, False, speculative_softmax=True, adaptive_softmax=True
         )
     return NativeKernelConfig(
-        dtype, 128, 128, 64, 4, True, True, True, 0, 0, 0, True, False, speculative_softmax=spec and not masked
+        dtype, 128, 128, 64, 4, True, True, True, 0, 0, 0, True, False, speculative_softmax=not masked, adaptive_softmax=not masked
     )

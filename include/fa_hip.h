@@ -137,6 +137,32 @@ typedef struct fa_fwd_stats {
     uint32_t items_redone;
 } fa_fwd_stats;
 
+/* fa_fwd_opts.speculative.  ADAPTIVE: the speculative variant, except that after a speculative launch on this device
+ * has reported items it had to compute twice (a failed item costs its workgroup a second item time, and a launch ends
+ * with its slowest workgroup) the library enqueues the NON-speculative variant of cfg for the next `hold` adaptive
+ * launches there (32, doubled up to 4096 while probes keep failing, reset after a long quiet stretch), then probes the
+ * speculative one again.  The report is one word of pinned host memory a failing workgroup stores into; the library
+ * reads it when the next adaptive launch is enqueued and never waits for the device.  Both variants compute the same
+ * real result within the same tolerance (they round P at different points), so WHICH of the two served a launch --
+ * which depends on when a report arrived -- is visible only in the last bits: ask for 0 or 1 where bit-reproducible
+ * output matters.  A launch captured into a hipGraph freezes the decision made at capture time.  State per device:
+ * fa_adaptive_state / fa_adaptive_reset. */
+typedef enum fa_speculative_mode {
+    FA_SPECULATIVE_OFF = 0,
+    FA_SPECULATIVE_ALWAYS = 1,
+    FA_SPECULATIVE_ADAPTIVE = 2
+} fa_speculative_mode;
+
+typedef struct fa_adaptive_info {
+    uint32_t available;      /* 1: the pinned report word exists on this device (else ADAPTIVE behaves like ALWAYS) */
+    uint32_t launches;       /* adaptive launches enqueued on the device so far */
+    uint32_t demoted;        /* ... of which took the non-speculative variant */
+    uint32_t reports;        /* distinct failure reports acted on */
+    uint32_t hold;           /* current length of a demotion, in adaptive launches */
+    uint32_t demote_until;   /* launches up to this sequence number are demoted (0: none pending) */
+    uint32_t last_report;    /* sequence number of the most recent launch that reported (0: none yet) */
+} fa_adaptive_info;
+
 /* Options of fa_fwd_launch_ex: this library's extensions beyond the reference's launch.  Zero-initialise,
  * set struct_size = sizeof(fa_fwd_opts), then set what you need. */
 typedef struct fa_fwd_opts {
@@ -144,7 +170,8 @@ typedef struct fa_fwd_opts {
     int32_t causal;          /* key j contributes to query i iff j <= i (masked variant of cfg); seq_len still has to be a
                                 multiple of B_r and B_c unless allow_ragged is set too */
     int32_t allow_ragged;    /* accept seq_len that is not a multiple of B_r / B_c (masked variant of cfg) */
-    int32_t speculative;     /* 1: the speculative-softmax variant of cfg (FA_SOFTMAX_SPECULATIVE).  A row may rise, above the max of
+    int32_t speculative;     /* fa_speculative_mode.  1: the speculative-softmax variant of cfg (FA_SOFTMAX_SPECULATIVE); 2: the same,
+                                adaptively -- see fa_speculative_mode below.  A row may rise, above the max of
                                 its LAST 64 keys (visited first), by ~44 nats (bf16) / ~10 nats (fp16) before its item is
                                 computed a second time; the persistent kernel also re-centres rising rows every four visits,
                                 so there only a JUMP of ~83 nats (bf16) / ~3-10 nats (fp16) inside 256 keys fails.  The result is
@@ -201,14 +228,29 @@ int fa_fwd_ex_supported(const fa_fwd_config *cfg, const fa_fwd_opts *opts);
 int fa_fwd_query(const fa_fwd_config *cfg, const fa_fwd_opts *opts, fa_kernel_info *out);
 int fa_fwd_launch_ex(const fa_fwd_args *args, const fa_fwd_opts *opts, void *stream);
 
-/* Registry enumeration: distinct device variants built into this library. */
+/* The adaptive speculative mode's record on `device` (fa_speculative_mode), and a reset of its demotion state (tests,
+ * or a caller that knows its data has changed character). */
+int fa_adaptive_state(int device, fa_adaptive_info *out);
+int fa_adaptive_reset(int device);
+
+/* Registry enumeration: distinct device variants built into this library.  fa_get_kernel / fa_fwd_query write
+ * sizeof(fa_kernel_info) bytes of THIS library's header; fa_kernel_info has grown (0.2 -> 0.3: softmax_mode,
+ * prescaled_q), so a client that may run against a newer library than the header it was compiled with calls the _sized
+ * forms, which write at most out_size bytes (whole leading fields; the struct only ever grows at its end), or checks
+ * fa_abi_version() first.  ABI history: INTEGRATION.md 6. */
 int fa_num_kernels(void);
 int fa_get_kernel(int index, fa_kernel_info *out);
+int fa_get_kernel_sized(int index, fa_kernel_info *out, uint32_t out_size);
+int fa_fwd_query_sized(const fa_fwd_config *cfg, const fa_fwd_opts *opts, fa_kernel_info *out, uint32_t out_size);
+
+/* Increases whenever a struct of this header grows or an entry point changes meaning (4 = this header). */
+#define FA_ABI_VERSION 4
+int fa_abi_version(void);
 
 /* Message for the last non-zero status on this thread ("" if none). */
 const char *fa_last_error(void);
 
-/* Library version string, e.g. "fa_hip 0.3 gfx950". */
+/* Library version string, e.g. "fa_hip 0.4 gfx950". */
 const char *fa_version(void);
 
 #ifdef __cplusplus

@@ -1039,7 +1039,18 @@ def test_masked_variant_equals_plain_kernel_when_nothing_is_masked():
         gen = torch.Generator(device=DEV).manual_seed(3)
         q, k, v = (torch.randn((2, 1024, 4, 128), dtype=dtype, device=DEV, generator=gen) for _ in range(3))
         assert kc.uses_speculative_softmax(cfg, masked=True) == kc.uses_speculative_softmax(cfg)  # (by construction of MASKED)
-        assert torch.equal(flash_attention.forward_ex(cfg, q, k, v), flash_attention.forward(cfg, q, k, v)), str(cfg)
+        masked_out, plain_out = flash_attention.forward_ex(cfg, q, k, v), flash_attention.forward(cfg, q, k, v)
+        if kc.uses_lazy_rescale(cfg) and kc.uses_speculative_softmax(cfg):
+            # round 4: the plain speculative form of the persistent kernel carries the next tile's first four softmax units
+            # in a visit's last gaps (rotated plan) and adds their share of a row sum as one side sum; the
+            # masked forms keep the unrotated plan.  Same P, same O accumulation -- only the fp32 row sum is associated
+            # differently, so l may differ in its last bit and an output element by one ulp of the 16-bit type
+            diff = (masked_out.float() - plain_out.float()).abs()
+            ulp = torch.clamp(plain_out.float().abs(), min=2.0 ** -14) * (2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -10)
+            assert (diff <= ulp).all(), (str(cfg), diff.max().item())
+            assert (diff > 0).float().mean().item() < 0.05, str(cfg)   # ... and rarely
+        else:
+            assert torch.equal(masked_out, plain_out), str(cfg)
 
 
 @pytest.mark.parametrize("shape", [(8, 16, 1024), (40, 16, 256), (5, 7, 512), (3, 16, 2048), (2, 16, 4096),

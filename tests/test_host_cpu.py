@@ -128,9 +128,15 @@ def test_one_flag_one_meaning_softmax_mode_of_every_config():
     finally:
         del os.environ["FA_ALLOW_SPECULATIVE"]
     assert kc.softmax_mode(cfg) == "eager"
-    # best_config: bf16 speculative, fp16 not (its 16-bit P leaves ~10 nats of headroom)
-    assert kc.softmax_mode(kc.best_config(kc.DType.BF16)) == "speculative"
-    assert kc.softmax_mode(kc.best_config(kc.DType.FP16)) == "lazy"
+    # best_config: the speculative softmax, adaptively, for both dtypes (round 4: the library demotes a device whose
+    # speculative launches report items computed twice -- fp16's 16-bit P leaves only ~10 nats of headroom)
+    for dt in (kc.DType.BF16, kc.DType.FP16):
+        best = kc.best_config(dt)
+        assert kc.softmax_mode(best) == "speculative" and best.adaptive_softmax and best.speculative_softmax
+        assert kc.parse_kernel_name_into_config(best.short_form()) == best
+        assert replace(best, adaptive_softmax=False).short_form() == best.short_form().replace("+adaptive", "")
+    with pytest.raises(ValueError):  # adaptive qualifies speculative
+        replace(best, speculative_softmax=False)
     assert kc.softmax_mode(kc.best_config(kc.DType.BF16, 1000, masked=True), masked=True) == "speculative"
     assert kc.softmax_mode(kc.best_config(kc.DType.BF16, 100, masked=True), masked=True) == "eager"
 
