@@ -457,7 +457,7 @@ int fa_fwd_launch_ex(const fa_fwd_args *args, const fa_fwd_opts *opts, void *str
                 ad.seen = rep;
                 ++ad.reports;
                 if (ad.demote_until != 0 && rep > ad.demote_until && ad.hold < 4096) ad.hold *= 2;  // a probe behind a hold failed too
-                ad.demote_until = seq + ad.hold;
+                ad.demote_until = seq + ad.hold - 1;  // this launch and the hold - 1 behind it
             } else if (ad.demote_until != 0 && seq > ad.demote_until + 8u * ad.hold) {
                 ad.hold = 32;  // long quiet: forget the back-off
                 ad.demote_until = 0;

@@ -164,7 +164,9 @@ template <> struct Elem<15> {  // bf16
         asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=v"(acc) : "v"(a), "a"(q));
     }
     static FA_DEV void mfma_acc_v_qc(f32x16 &acc, vec8 a, vec8 q, const f32x16 &cin) {  // acc(VGPR) = a * q(AGPR) + cin(VGPR)
-        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=v"(acc) : "v"(a), "a"(q), "v"(cin));
+        // "=&v": a 32x32 MFMA needs D and C identical or fully disjoint; without the early clobber the allocator may overlap
+        // them partially once cin is dead behind the statement
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(acc) : "v"(a), "a"(q), "v"(cin));
     }
     static FA_DEV void mfma_acc_a_p(f32x16 &acc, vec8 a, u32x4 p) {  // acc(AGPR) += a * p(VGPR, packed >= 1 step ago)
         asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(p));
@@ -212,7 +214,9 @@ template <> struct Elem<5> {  // fp16
         asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=v"(acc) : "v"(a), "a"(q));
     }
     static FA_DEV void mfma_acc_v_qc(f32x16 &acc, vec8 a, vec8 q, const f32x16 &cin) {  // acc(VGPR) = a * q(AGPR) + cin(VGPR)
-        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %3" : "=v"(acc) : "v"(a), "a"(q), "v"(cin));
+        // "=&v": a 32x32 MFMA needs D and C identical or fully disjoint; without the early clobber the allocator may overlap
+        // them partially once cin is dead behind the statement
+        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %3" : "=&v"(acc) : "v"(a), "a"(q), "v"(cin));
     }
     static FA_DEV void mfma_acc_a_p(f32x16 &acc, vec8 a, u32x4 p) {  // acc(AGPR) += a * p(VGPR, packed >= 1 step ago)
         asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(p));

@@ -25,6 +25,11 @@ struct Plan64 {
 #ifndef FA_RING_SLOTS
 #define FA_RING_SLOTS 4
 #endif
+#ifdef FA_JITTER
+#define FA_JIT(rare) jitter(BoolTag<rare>{})
+#else
+#define FA_JIT(rare) ((void)0)
+#endif
 #ifndef FA_ROT_DEFAULT
 #define FA_ROT_DEFAULT 4   // softmax units of the next tile carried in a visit's last gaps (speculative plain forms)
 #endif
@@ -199,6 +204,43 @@ fa_fwd_kernel64(const KernelArgs args) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r31 = lane & 31;
     const int hi = lane >> 5;
+#ifdef FA_JITTER
+    // Timing-perturbed build (csrc/Makefile target `jitter` -> lib/libfa_hip_jitter.so; the counterpart of the reference's
+    // compute-sanitizer racecheck + FA_DEBUG build, tools/debug/check_race.sh:3-4, setup.py:15,37-38 -- SURVEY.md 5).
+    // The ring protocol of this kernel rests on counted waits, a barrier two MFMAs into a visit and DMA pieces issued a
+    // fixed number of visits ahead; on an idle box the four waves run in near lockstep and a missing wait can hide.  Here
+    // every wave draws from its own LCG and sleeps 0 .. 7 x 64 cycles in front of every DMA piece, every sync point and
+    // (one time in eight) every operand wait, so the waves of a workgroup drift apart by up to a visit's length and meet
+    // each protocol step in a different order from launch to launch.  The plan, the waits and the arithmetic are the
+    // product's: outputs must be bit-identical to the product library's (tests/test_gpu_parity.py, tools/soak.py).
+    unsigned jit_state;
+    {
+        unsigned long long t_;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_));
+        jit_state = __builtin_amdgcn_readfirstlane((unsigned)t_ * 2654435761u + (unsigned)wave * 40503u + blockIdx.x * 9176u);
+    }
+    auto jitter = [&](auto rare_tag) {
+        constexpr bool RARE = decltype(rare_tag)::value;   // true: sleep one time in eight only (the 16 operand waits of a visit)
+        unsigned n_, r_;
+        unsigned &js_ = jit_state;  // (named here: an asm operand alone does not make the generic lambda capture it)
+        asm volatile("s_mul_i32 %0, %0, 0x19660d\n\t"
+                     "s_add_u32 %0, %0, 0x3c6ef35f\n\t"
+                     "s_lshr_b32 %1, %0, 29\n\t"        // 0 .. 7 sleeps of 64 cycles
+                     "s_bfe_u32 %2, %0, 0x30014\n\t"    // bits 20 .. 22: the one-in-eight draw
+                     "s_cmp_lg_u32 %2, 0\n\t"
+                     "s_cselect_b32 %2, %3, 0\n\t"      // RARE and the draw is not 0: no sleep
+                     "s_cmp_lg_u32 %2, 0\n\t"
+                     "s_cselect_b32 %1, 0, %1\n"
+                     ".Ljit%=:\n\t"
+                     "s_cmp_eq_u32 %1, 0\n\t"
+                     "s_cbranch_scc1 .Ljit_done%=\n\t"
+                     "s_sleep 1\n\t"
+                     "s_sub_u32 %1, %1, 1\n\t"
+                     "s_branch .Ljit%=\n"
+                     ".Ljit_done%=:"
+                     : "+s"(js_), "=&s"(n_), "=&s"(r_) : "s"(RARE ? 1u : 0u) : "scc");
+    };
+#endif
 #if defined(FA_TRACE) && FA_TRACE == 3
     // timeline build (tools/trace64.hip): every wave stamps (low 32 bits of s_memtime) kernel entry, the
     // end of the prologue, every visit top and the exit into trace32[(wave * 256 + blockIdx.x) * 96 + n];
@@ -315,7 +357,7 @@ fa_fwd_kernel64(const KernelArgs args) {
         }
     };
     auto dma_wait = [&]() { if (DMA && !(ABL & 8)) dma_wait_all(); };
-    auto barrier = [&]() { if (!(ABL & 8)) wg_barrier(); };
+    auto barrier = [&]() { if (!(ABL & 8)) { FA_JIT(false); wg_barrier(); } };
     // forward_kernel.cuh:150-151 (fp32 product of rsqrt(d) and log2 e)
     const float c = (float)((double)(1.0f / __builtin_sqrtf((float)D)) * 1.4426950408889634074);
     const float cs = PSQ ? 1.0f : c;  // what turns an S element into a base-2 exponent (PSQ: the scale already sits in Q)
@@ -569,13 +611,17 @@ fa_fwd_kernel64(const KernelArgs args) {
             };
             auto dma_k = [&](const uint16_t *src, int stage) {
 #pragma unroll
-                for (int j = 0; j < DMA_PER_WAVE; ++j)
+                for (int j = 0; j < DMA_PER_WAVE; ++j) {
+                    FA_JIT(false);
                     glds16_sv_m0(src, k_off[j], smem_base + stage * TILE + (wave + NWAVES * j) * 1024);
+                }
             };
             auto dma_v = [&](const uint16_t *src, int stage) {
 #pragma unroll
-                for (int j = 0; j < DMA_PER_WAVE; ++j)
+                for (int j = 0; j < DMA_PER_WAVE; ++j) {
+                    FA_JIT(false);
                     glds16_sv_m0(src, v_off[j], smem_base + V_BASE + stage * TILE + (wave + NWAVES * j) * 1024);
+                }
             };
             const uint16_t *kq = nullptr, *vq = nullptr;  // next K / V tile to request (set per item below)
             // operand ring: slot u % RS holds operand u; the loads of operands step + LA, step + LA + 1 are issued
@@ -644,7 +690,10 @@ fa_fwd_kernel64(const KernelArgs args) {
                 }
                 const uint16_t *rows0 = Qh + ((int64_t)qblk * TR::kBr + wave * TR::kRowsPerWave + 32 * qt) * ss;
 #pragma unroll
-                for (int i = 0; i < 8; ++i) glds16_sv_m0(rows0, (off ^ (64u * (i & 3))) + (unsigned)(4 * i) * (unsigned)ss * 2u, stage + i * 1024);
+                for (int i = 0; i < 8; ++i) {
+                    FA_JIT(false);
+                    glds16_sv_m0(rows0, (off ^ (64u * (i & 3))) + (unsigned)(4 * i) * (unsigned)ss * 2u, stage + i * 1024);
+                }
             };
             auto read_q = [&](vec8 (&dst)[KS], unsigned stage) {  // this lane's chunks: row l % 32, chunk (2 ks + l/32) ^ (row & 15)
                 const int l_ = lane_now();
@@ -760,6 +809,7 @@ fa_fwd_kernel64(const KernelArgs args) {
                 // gap-0 lgkmcnt(0) that retires this wave's last LDS reads of visit it-1.
                 auto sync_point = [&]() {
                     if (ABL & 8) return;
+                    FA_JIT(false);
                     // One compare and one branch on the common path.  The first three visits of an item take
                     // the slow path: more may be in flight behind the pieces the barrier publishes -- in issue
                     // order: [pieces(last visit of the previous item) | 16 epilogue stores] [Q tile 0: 8]
@@ -928,6 +978,7 @@ fa_fwd_kernel64(const KernelArgs args) {
                         // operands step, step + 1 landed; the LDS reads of operands step + 2 ... step + LA - 1 (one per
                         // K fragment, two per V fragment; LDS returns in order) may still fly
                         constexpr int fly = [] { int n = 0; for (int u = step + 2; u < step + LA; ++u) n += (u >= 16 && u < 32) ? 2 : 1; return n; }();
+                        FA_JIT(true);
 #if defined(FA_TRACE) && FA_TRACE < 4
                         __builtin_amdgcn_s_waitcnt(0xC07F);      // (s_memtime returns out of order: no counting)
 #else
@@ -974,6 +1025,7 @@ fa_fwd_kernel64(const KernelArgs args) {
                         // per-piece lane offsets: 6 more VGPRs than one offset + a scalar piece stride (piece j
                         // of a wave starts 16 rows below piece j-1), but 16 fewer SALU instructions per
                         // visit (+0.5 %)
+                        FA_JIT(false);
                         if constexpr ((plan.dma[g] & 1) == 0) glds16_issue(kq, k_off[j]);
                         else glds16_issue(vq, v_off[j]);
                     }
@@ -1210,6 +1262,7 @@ fa_fwd_kernel64(const KernelArgs args) {
             // as the last tile's rows are back in registers): the request no longer queues behind all 16 stores.
             constexpr bool QEARLY = (ABL & 65536) != 0 && !RAG;
             auto store_item = [&](uint16_t *Oc, const int qb_c, const int ord, auto &&before_last_stores) {
+                FA_JIT(false);
                 asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // last P.V -> VALU reads of O
                 char *stage_o = smem + 2 * TR::kStages * TILE + wave * (32 * ROWB);
                 // lane-derived indices recomputed here from a volatile v_mbcnt: values derived from

@@ -131,7 +131,11 @@ typedef struct fa_kernel_info {
 /* Device-side statistics (optional, fa_fwd_opts.stats): a DEVICE pointer to two 32-bit counters the
  * kernel ADDS to (zero them yourself).  items = work items (batch*head, Q block) computed;
  * items_redone = items the speculative softmax had to compute a second time because a row sum
- * exceeded its limit -- the cost of such an item is 2x.  0 for every other softmax mode. */
+ * exceeded its limit -- the cost of such an item is 2x.  0 for every other softmax mode.  The persistent kernel keeps a
+ * workgroup's failures in a 64-bit mask of its walk ordinals, and ordinals >= 63 share the last bit: on a problem with
+ * more than 63 items per workgroup (> ~16 000 items on a 256-CU device) a failure at ordinal >= 63 makes the workgroup
+ * compute, and count, ALL its items from ordinal 63 on again -- items_redone is what ran twice, which there can exceed
+ * what had to. */
 typedef struct fa_fwd_stats {
     uint32_t items;
     uint32_t items_redone;

@@ -5,6 +5,7 @@ import os
 import time
 
 import bench
+from tests.conftest import ROOT
 from flash_helpers import kernel_configs as kc
 
 
@@ -59,3 +60,42 @@ def test_flop_model_and_workload_table():
     assert [s for s, _ in bench.C2_SWEEP] == [512, 1024, 2048, 4096, 8192, 16384]
     from flash_helpers.test.utils import BATCH_SIZE_FOR_SEQ_LEN
     assert all(BATCH_SIZE_FOR_SEQ_LEN[s] == b for s, b in bench.C2_SWEEP)
+
+
+def test_wave_cycles_per_mfma_does_not_creep_up_between_rounds():
+    """round 3's guard cost 0.8 wave cycles per MFMA and nothing took it back.  profiles/rNN/bench_c1.json is
+    the driver command's line of a round's evidence lease; its pipe counters (SQ_WAVE_CYCLES x 4 / SQ_INSTS_MFMA over the
+    whole launch) are the box-independent tracker of the kernel's instruction stream.  From round 4 on a round may not
+    commit a figure more than 0.5 % above the round before it (round 3 vs round 2 is the regression this test is for)."""
+    import glob
+    import json
+    import re
+
+    recs = []
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]", "bench_c1.json"))):
+        rnd = int(re.search(r"r(\d\d)", path).group(1))
+        try:
+            line = json.load(open(path))
+        except ValueError:
+            continue
+        pc = (line.get("roofline") or {}).get("pipe_counters") or {}
+        w = line.get("wave_cycles_per_mfma", pc.get("wave_cycles_per_mfma") if isinstance(pc, dict) else None)
+        if w:
+            recs.append((rnd, float(w)))
+    assert len(recs) >= 2 and recs[0][0] <= 2, recs
+    for (r0, w0), (r1, w1) in zip(recs, recs[1:]):
+        if r1 >= 4:
+            assert w1 <= w0 * 1.005, f"round {r1}: {w1:.2f} wave cycles per MFMA, round {r0} had {w0:.2f}"
+
+
+def test_short_timed_regions_also_report_a_sustained_one():
+    """bench.py: a K-step region under 100 ms (the driver's --steps 20 at C1 is ~9 ms) also times >= 250 ms of the same
+    steps with the same brackets and reports it as `sustained`; a region of 100 ms or more does not."""
+    calls = []
+
+    def step():
+        calls.append(1)
+
+    got = bench.sustained_region(step, lambda: None, lambda: None, seconds=0.010, steps=20, world=1, device=None)
+    assert got["steps"] == int(0.25 / (0.010 / 20)) + 1 == len(calls) and got["seconds"] > 0 and "ms_per_step" in got
+    assert bench.sustained_region(step, lambda: None, lambda: None, seconds=0.2, steps=20, world=1, device=None) is None

@@ -685,6 +685,102 @@ def test_soak_of_the_persistent_kernel_short():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+def test_jitter_build_matches_the_product_bit_for_bit():
+    """SURVEY.md 5's racecheck substitute (reference: tools/debug/check_race.sh:3-4, the FA_DEBUG build of setup.py:15,37-38):
+    lib/libfa_hip_jitter.so is the product's source with -DFA_JITTER -- every wave of the persistent kernel sleeps a
+    pseudo-random 0 .. 7 x 64 cycles in front of every DMA piece, sync point and (one time in eight) operand wait, so the
+    four waves of a workgroup drift apart by up to a visit and meet every step of the ring protocol (counted vmcnt waits,
+    the barrier two MFMAs into a visit, tiles requested three visits ahead) in another order at every launch.  A missing
+    wait or a stage overwritten too early shows as different bits.  tools/jitter_check.py: ten seeded cases (item seams, the
+    speculative second pass, lazy rescales, causal, ragged, both dtypes), three launches each; the jitter build's hashes
+    must equal the product library's and repeat.  Then the soak (random shapes against fp32 attention) under it."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    jit = os.path.join(root, "flash_attention_from_scratch_amd", "lib", "libfa_hip_jitter.so")
+    assert os.path.exists(jit), "lib/libfa_hip_jitter.so is not built (make -C flash_attention_from_scratch_amd/csrc jitter)"
+    env = {k: v for k, v in os.environ.items() if k != "FA_HIP_LIB"}
+
+    def lines(extra):
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "jitter_check.py")], cwd=root, capture_output=True,
+                           text=True, timeout=900, env={**env, **extra})
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        got = [ln for ln in r.stdout.splitlines() if ln.startswith("case ")]
+        assert len(got) == 10 and all(" finite=1 repeat=1 " in ln for ln in got), r.stdout[-3000:]
+        return got, r.stdout.splitlines()[0]
+    product, which_p = lines({})
+    jittered, which_j = lines({"FA_HIP_LIB": jit})
+    assert "libfa_hip_jitter.so" in which_j and "libfa_hip_jitter.so" not in which_p
+    assert product == jittered, "\n".join(f"{a}\n{b}" for a, b in zip(product, jittered) if a != b)
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "soak.py"), "15", "11"], cwd=root, capture_output=True,
+                       text=True, timeout=900, env={**env, "FA_HIP_LIB": jit})
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_adaptive_speculative_mode_demotes_after_a_reported_redo():
+    """fa_speculative_mode ADAPTIVE (include/fa_hip.h; what best_config() asks for): a speculative launch that had to
+    compute items twice stores its sequence number into the device's pinned report word; the adaptive launches enqueued
+    after the library has seen that report take the non-speculative variant for `hold` launches, then the speculative one
+    is probed again.  Outputs are inside the tolerance whichever variant served."""
+    from flash_attention_from_scratch_amd import _capi
+    dev = torch.cuda.current_device()
+    for dtype, name in ((torch.bfloat16, kc.DType.BF16), (torch.float16, kc.DType.FP16)):
+        cfg = kc.best_config(name, 1024)
+        assert cfg.adaptive_softmax and cfg.speculative_softmax
+        lazy = replace(cfg, speculative_softmax=False, adaptive_softmax=False)
+        spec = replace(cfg, adaptive_softmax=False)
+        gen = torch.Generator(device=DEV).manual_seed(77)
+        q, k, v = (torch.randn((2, 1024, 8, 128), dtype=dtype, device=DEV, generator=gen) for _ in range(3))
+        # 1. benign data: never demoted, bit-identical to the always-speculative variant
+        flash_attention.forward(cfg, q, k, v)
+        torch.cuda.synchronize()
+        _capi.adaptive_reset(dev)
+        st0 = _capi.adaptive_state(dev)
+        assert st0["available"] == 1
+        outs = [flash_attention.forward(cfg, q, k, v) for _ in range(6)]
+        torch.cuda.synchronize()
+        st1 = _capi.adaptive_state(dev)
+        assert st1["launches"] == st0["launches"] + 6 and st1["demoted"] == 0 and st1["reports"] == 0
+        want = flash_attention.forward(spec, q, k, v)
+        assert all(torch.equal(o, want) for o in outs)
+        # 2. a spike (one 30-sigma key against a few queries): the speculative pass fails -> report -> demotion
+        ks, qs = k.clone(), q.clone()
+        u = _sign_vector(5).to(dtype)
+        ks[1, 3, 2] = 30.0 * u
+        qs[1, 600:604, 2] = 30.0 * u
+        stats = torch.zeros(2, dtype=torch.int32, device=DEV)
+        vs = v
+        flash_attention_kernels.forward(spec, qs, ks, vs, None, stats=stats)
+        assert stats[1].item() > 0          # (the always-speculative variant does redo items on this input)
+        first = flash_attention.forward(cfg, qs, ks, vs)      # adaptive, still speculative: fails, reports
+        torch.cuda.synchronize()
+        st2 = _capi.adaptive_state(dev)
+        assert st2["last_report"] == st2["launches"] and st2["demoted"] == 0
+        demoted = [flash_attention.forward(cfg, qs, ks, vs) for _ in range(5)]
+        torch.cuda.synchronize()
+        st3 = _capi.adaptive_state(dev)
+        assert st3["reports"] == 1 and st3["demoted"] == 5 and st3["demote_until"] == st2["launches"] + st3["hold"]
+        want_lazy = flash_attention.forward(lazy, qs, ks, vs)
+        assert all(torch.equal(o, want_lazy) for o in demoted)      # the demoted launches ARE the lazy variant
+        # (a failed item's second pass is the lazy schedule: the speculative launch agrees with it on those items, and on
+        # the others within the tolerance)
+        eager = ut.py_flash_attention(qs, ks, vs, upcast=True).float()
+        for o in [first] + demoted:
+            assert ((o.float() - eager).abs() <= TOL[dtype] * (1 + eager.abs())).all()
+        # 3. the hold runs out: the next launch probes the speculative variant again (fails again here: hold doubles)
+        hold = st3["hold"]
+        for _ in range(hold - 5):
+            flash_attention.forward(cfg, qs, ks, vs)
+        torch.cuda.synchronize()
+        assert _capi.adaptive_state(dev)["demoted"] == hold
+        flash_attention.forward(cfg, qs, ks, vs)      # the probe
+        torch.cuda.synchronize()
+        flash_attention.forward(cfg, qs, ks, vs)      # sees the probe's report
+        st4 = _capi.adaptive_state(dev)
+        assert st4["reports"] == 2 and st4["hold"] == 2 * hold and st4["demoted"] == hold + 1
+        _capi.adaptive_reset(dev)
+
+
 @pytest.mark.parametrize("S", [1000, 2500])
 def test_speculative_softmax_ragged_second_pass(S):
     """The ragged form under speculative_softmax: the rounded-up tiles beyond the sequence are masked whole,

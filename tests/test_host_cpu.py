@@ -526,3 +526,39 @@ def test_reference_side_binding_builds(tmp_path):
     x = torch.zeros(1, 128, 1, 128, dtype=cfg.dtype.to_torch_dtype())
     with pytest.raises(RuntimeError, match="must be a CUDA tensor"):
         ext.forward(cfg, x, x, x, None)
+
+
+def test_jitter_library_is_built_and_exports_the_same_abi():
+    """lib/libfa_hip_jitter.so (csrc/Makefile `jitter`, built by __graft_entry__.build()): the timing-perturbed twin the GPU
+    tier runs through FA_HIP_LIB.  Same entry points, same registry; its 64-rows-per-wave slices carry the sleeps."""
+    path = os.path.join(ROOT, "flash_attention_from_scratch_amd", "lib", "libfa_hip_jitter.so")
+    assert os.path.exists(path), "run `make -C flash_attention_from_scratch_amd/csrc jitter`"
+    lib = ctypes.CDLL(path)
+    for sym in _capi.EXPORTED_SYMBOLS:
+        assert hasattr(lib, sym), sym
+    lib.fa_num_kernels.restype = ctypes.c_int
+    assert lib.fa_num_kernels() == _capi.load().fa_num_kernels()
+    src = open(os.path.join(ROOT, "flash_attention_from_scratch_amd", "csrc", "fa_fwd_kernel64.hpp")).read()
+    assert src.count("FA_JIT(") >= 8 and "#ifdef FA_JITTER" in src
+    # the product path never names it: FA_HIP_LIB is the only way in
+    for rel in ("flash_attention_from_scratch_amd/_capi.py", "flash_attention_from_scratch_amd/flash_attention_kernels.py", "bench.py"):
+        code = [ln for ln in open(os.path.join(ROOT, rel)).read().splitlines() if not ln.lstrip().startswith("#")]
+        assert not any("libfa_hip_jitter" in ln for ln in code), rel
+
+
+def test_adaptive_mode_abi():
+    """fa_speculative_mode / fa_adaptive_info (include/fa_hip.h): struct layout of the ctypes mirror, the version numbers."""
+    assert ctypes.sizeof(_capi.FaAdaptiveInfo) == 7 * 4
+    lib = _capi.load()
+    assert lib.fa_abi_version() == _capi.FA_ABI_VERSION == 4
+    header = open(os.path.join(ROOT, "include", "fa_hip.h")).read()
+    assert "#define FA_ABI_VERSION 4" in header and "FA_SPECULATIVE_ADAPTIVE = 2" in header
+    assert _capi.make_opts(speculative="adaptive").speculative == 2 and _capi.make_opts(speculative=True).speculative == 1
+    assert _capi.make_opts(speculative=False).speculative == 0
+    info = _capi.FaKernelInfo()
+    small = ctypes.sizeof(_capi.FaKernelInfo) - 8     # a client built against the 0.2 header (no softmax_mode / prescaled_q)
+    buf = (ctypes.c_char * ctypes.sizeof(_capi.FaKernelInfo))()
+    ctypes.memset(buf, 0x5A, ctypes.sizeof(buf))
+    assert lib.fa_get_kernel_sized(0, ctypes.cast(buf, ctypes.POINTER(_capi.FaKernelInfo)), small) == 0
+    assert bytes(buf)[small:] == b"\x5a" * 8          # nothing written beyond the caller's size
+    assert lib.fa_get_kernel(0, ctypes.byref(info)) == 0 and bytes(buf)[:small] == bytes(info)[:small]
