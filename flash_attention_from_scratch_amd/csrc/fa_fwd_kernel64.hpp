@@ -1337,7 +1337,18 @@ fa_fwd_kernel64(const KernelArgs args) {
                         // s_nop 1: a store of more than 64 bits reads its data registers for two more cycles, and hipcc --
                         // which does not see the instruction inside the asm -- may reuse v[i] for the very next vector
                         // instruction (it did, for the next store's address: tools/isa_lint64.py, finding STDATA)
-                        asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" ::"v"(lane_off + (unsigned)(RPP * i) * (unsigned)ss * 2u), "v"(v[i]), "s"(rows0));
+                        // cache policy of the O stores (ABL bits 29..30, tools/tune64.hip: 0 = nt as shipped, 1 = sc1, 2 = sc0 sc1
+                        // write-through, 3 = default): what is still dirty in the L2s when the launch ends is written back at the
+                        // kernel boundary (MI355X_MICROARCH.md, price list row `boundary`)
+                        constexpr int STP = (ABL >> 29) & 3;
+                        if constexpr (STP == 0)
+                            asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" ::"v"(lane_off + (unsigned)(RPP * i) * (unsigned)ss * 2u), "v"(v[i]), "s"(rows0));
+                        else if constexpr (STP == 1)
+                            asm volatile("global_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 1" ::"v"(lane_off + (unsigned)(RPP * i) * (unsigned)ss * 2u), "v"(v[i]), "s"(rows0));
+                        else if constexpr (STP == 2)
+                            asm volatile("global_store_dwordx4 %0, %1, %2 sc0 sc1\n\ts_nop 1" ::"v"(lane_off + (unsigned)(RPP * i) * (unsigned)ss * 2u), "v"(v[i]), "s"(rows0));
+                        else
+                            asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(lane_off + (unsigned)(RPP * i) * (unsigned)ss * 2u), "v"(v[i]), "s"(rows0));
                     }
                 }
             };

@@ -2,8 +2,8 @@
 enumeration, the test entry and the test/benchmark utilities under their reference import names.
 The modules are aliases of flash_attention_from_scratch_amd.flash_helpers (installed by the root
 setup.py), so this distribution depends on `flash_attention`.  The alias package lives INSIDE this
-project (py/flash_helpers, byte-identical to the repository root's flash_helpers/ -- a CPU test keeps
-them so), so sdists and isolated builds contain it."""
+project (py/flash_helpers), so sdists and isolated builds contain it; the repository root's
+flash_helpers/__init__.py only points in-tree imports at it."""
 from setuptools import setup
 
 __version__ = "0.3.0"

@@ -468,13 +468,18 @@ def test_the_two_distributions_build_and_import_outside_the_repo(tmp_path):
 
 def test_py_distribution_ships_its_own_alias_package():
     """py/ (the `flash_helpers` distribution, reference py/setup.py:6-9) carries the alias package inside its own project
-    root -- an sdist or an isolated build sees nothing above it -- and it is the same alias package the repository root
-    exposes for in-tree imports."""
-    for rel in ("__init__.py", "kernel_configs.py", os.path.join("test", "__init__.py"), os.path.join("test", "utils.py"),
-                os.path.join("test", "test.py")):
-        a = open(os.path.join(ROOT, "flash_helpers", rel)).read()
-        b = open(os.path.join(ROOT, "py", "flash_helpers", rel)).read()
-        assert a == b, rel
+    root -- an sdist or an isolated build sees nothing above it.  The repository root's flash_helpers/ is only a pointer
+    to it (one `__init__.py` that sets `__path__`): ONE copy of the package in the tree (round 3 kept two in step by a test)."""
+    import flash_helpers
+    import flash_helpers.kernel_configs as kc_alias
+    import flash_helpers.test.utils as ut_alias
+
+    inner = os.path.join(ROOT, "py", "flash_helpers")
+    assert [os.path.realpath(p) for p in flash_helpers.__path__] == [os.path.realpath(inner)]
+    assert os.path.realpath(kc_alias.__file__) == os.path.realpath(os.path.join(inner, "kernel_configs.py"))
+    assert os.path.realpath(ut_alias.__file__) == os.path.realpath(os.path.join(inner, "test", "utils.py"))
+    assert [n for n in sorted(os.listdir(os.path.join(ROOT, "flash_helpers"))) if n != "__pycache__"] == ["__init__.py"]
+    assert kc_alias.best_config is kc.best_config
     setup_py = open(os.path.join(ROOT, "py", "setup.py")).read()
     assert "os.pardir" not in setup_py and "package_dir" not in setup_py
 
