@@ -79,7 +79,7 @@ class FaAdaptiveInfo(ctypes.Structure):
     """fa_adaptive_info: the adaptive speculative mode's record on one device."""
 
     _fields_ = [(name, ctypes.c_uint32) for name in
-                ("available", "launches", "demoted", "reports", "hold", "demote_until", "last_report")]
+                ("available", "launches", "demoted", "reports", "hold", "mode", "remaining", "last_report")]
 
 
 def make_opts(causal=False, allow_ragged=False, speculative=False, prescaled_q=False, ms=None, stats_ptr=None):

@@ -114,24 +114,32 @@ const fa::KernelEntry *find_kernel(const fa_fwd_config *c, const char **why, con
 // does not stick to the others.
 // Adaptive speculative softmax (fa_fwd_opts.speculative == FA_SPECULATIVE_ADAPTIVE).  A speculative launch whose
 // first pass fails some item computes that item twice, and a launch ends with its slowest workgroup: ONE failing item
-// costs a whole item time.  The kernels report such a launch by storing its sequence number into one
-// word of pinned host memory (KernelArgs::redo_flag; nothing is written by a launch without failures).  The library
-// looks at that word -- a plain host read, no synchronisation: it sees what has completed so far -- when the next
-// adaptive launch is enqueued, and after a reported failure enqueues the NON-speculative variant of the configuration
-// for the next `hold` adaptive launches on that device, then probes again; a probe that fails as well doubles `hold`
-// (32 ... 4096), a long quiet stretch resets it.  Both variants give a valid result (they differ in the rounding point
-// of P); which one served a given launch depends on when the report arrived, so bit-reproducible callers ask for
-// speculative = 0 or 1 instead.
+// costs a whole item time, everything failing 2x.  The kernels report such a launch by storing its
+// sequence number into one word of pinned host memory (KernelArgs::redo_flag; a launch without failures writes
+// nothing).  The library reads that word -- a plain host read, it never waits for the device -- whenever an adaptive
+// launch is enqueued:
+//   NORMAL    every launch speculative.  A new report -> DEMOTED for `hold` launches (this one included).
+//   DEMOTED   the non-speculative sibling of the configuration serves the launch; when the hold has run out the next
+//             launch is a PROBE: speculative again, with an event recorded behind it.
+//   PROBING   launches are demoted until the probe's event has completed (hipEventQuery: no wait); then either the probe
+//             reported too -> DEMOTED with `hold` doubled (32 ... 4096), or it did not -> NORMAL, `hold` back to 32.
+// So steady bad data costs one speculative launch per hold; the host running ahead of the device costs at most the
+// launches enqueued before the first report lands.  Both variants give a valid result (they differ in the rounding point
+// of P); which one served a given launch depends on when a report arrived, so bit-reproducible callers ask for
+// speculative = 0 or 1 instead.  During a stream capture the mode behaves like ALWAYS (no event is recorded into a graph).
 struct AdaptiveState {
     std::mutex mu;
     uint32_t *flag_host = nullptr;  // hipHostMalloc'ed (mapped, coherent) word; null: no pinned memory -> always speculative
     uint32_t *flag_dev = nullptr;   // the same word as the device addresses it
+    hipEvent_t probe_done = nullptr;
     uint32_t seq = 0;               // adaptive launches enqueued on this device so far
     uint32_t seen = 0;              // the last report acted on
-    uint32_t demote_until = 0;      // launches with seq <= this take the non-speculative variant
+    uint32_t mode = 0;              // 0 NORMAL, 1 DEMOTED, 2 PROBING
+    uint32_t remaining = 0;         // DEMOTED: launches of the hold still to come
+    uint32_t probe_seq = 0;
     uint32_t hold = 32;
     uint32_t demoted = 0;           // adaptive launches that took the non-speculative variant
-    uint32_t reports = 0;           // distinct failure reports seen
+    uint32_t reports = 0;           // distinct failure reports acted on
 };
 struct DeviceState {
     std::once_flag once;
@@ -185,8 +193,15 @@ void do_init(int dev, DeviceState *st) {
         if (hipHostMalloc(&h, 64, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess && h &&
             hipHostGetDevicePointer(&d, h, 0) == hipSuccess && d) {
             memset(h, 0, 64);
-            st->adaptive.flag_host = (uint32_t *)h;
-            st->adaptive.flag_dev = (uint32_t *)d;
+            hipEvent_t ev = nullptr;
+            if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess) {
+                st->adaptive.flag_host = (uint32_t *)h;
+                st->adaptive.flag_dev = (uint32_t *)d;
+                st->adaptive.probe_done = ev;
+            } else {
+                (void)hipGetLastError();
+                (void)hipHostFree(h);
+            }
         } else {
             (void)hipGetLastError();
             if (h) (void)hipHostFree(h);
@@ -445,24 +460,53 @@ int fa_fwd_launch_ex(const fa_fwd_args *args, const fa_fwd_opts *opts, void *str
     if (!dev) return rc;
     uint32_t *redo_flag = nullptr;
     uint32_t redo_seq = 0;
-    if (o.speculative == FA_SPECULATIVE_ADAPTIVE) {
+    bool record_probe = false;
+    if (o.speculative == FA_SPECULATIVE_ADAPTIVE && dev->adaptive.flag_host) {
         // (the speculative variant exists: validated above.  Its non-speculative sibling serves a demoted launch)
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing((hipStream_t)stream, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
         AdaptiveState &ad = dev->adaptive;
         bool demote = false;
-        {
+        if (cap == hipStreamCaptureStatusNone) {
             std::lock_guard<std::mutex> lock(ad.mu);
             const uint32_t seq = ++ad.seq;
-            const uint32_t rep = ad.flag_host ? __atomic_load_n(ad.flag_host, __ATOMIC_RELAXED) : 0u;
-            if (rep != ad.seen) {  // a speculative launch that has completed since computed items twice
-                ad.seen = rep;
-                ++ad.reports;
-                if (ad.demote_until != 0 && rep > ad.demote_until && ad.hold < 4096) ad.hold *= 2;  // a probe behind a hold failed too
-                ad.demote_until = seq + ad.hold - 1;  // this launch and the hold - 1 behind it
-            } else if (ad.demote_until != 0 && seq > ad.demote_until + 8u * ad.hold) {
-                ad.hold = 32;  // long quiet: forget the back-off
-                ad.demote_until = 0;
+            const uint32_t rep = __atomic_load_n(ad.flag_host, __ATOMIC_RELAXED);
+            const bool fresh = rep != ad.seen;   // a speculative launch that has completed since computed items twice
+            if (fresh) { ad.seen = rep; ++ad.reports; }
+            if (ad.mode == 2) {                  // PROBING: has the probe finished?
+                const hipError_t q = hipEventQuery(ad.probe_done);
+                if (q == hipSuccess || fresh) {
+                    // (re-read: the report of a probe that has completed is visible by now)
+                    const uint32_t rep2 = __atomic_load_n(ad.flag_host, __ATOMIC_RELAXED);
+                    if (rep2 != ad.seen) { ad.seen = rep2; ++ad.reports; }
+                    if (fresh || rep2 == ad.probe_seq || ad.seen == ad.probe_seq) {
+                        if (ad.hold < 4096) ad.hold *= 2;
+                        ad.mode = 1;
+                        ad.remaining = ad.hold;
+                    } else {
+                        ad.mode = 0;
+                        ad.hold = 32;
+                    }
+                } else if (q != hipErrorNotReady) {
+                    (void)hipGetLastError();
+                    ad.mode = 0;
+                }
+            } else if (fresh) {                  // NORMAL or DEMOTED: (another) failure reported
+                ad.mode = 1;
+                ad.remaining = ad.hold;
             }
-            demote = ad.demote_until != 0 && seq <= ad.demote_until;
+            if (ad.mode == 1) {
+                if (ad.remaining > 0) {
+                    --ad.remaining;
+                    demote = true;
+                } else {                         // the hold has run out: this launch is the probe
+                    ad.mode = 2;
+                    ad.probe_seq = seq;
+                    record_probe = true;
+                }
+            } else if (ad.mode == 2 && !record_probe) {
+                demote = true;
+            }
             if (demote) ++ad.demoted;
             redo_flag = ad.flag_dev;
             redo_seq = seq;
@@ -477,7 +521,15 @@ int fa_fwd_launch_ex(const fa_fwd_args *args, const fa_fwd_opts *opts, void *str
             }  // (no such sibling: the speculative variant stays)
         }
     }
-    return launch_maybe_timed(args, e, dev, (hipStream_t)stream, o.causal != 0, o.ms, o.stats, redo_flag, redo_seq);
+    rc = launch_maybe_timed(args, e, dev, (hipStream_t)stream, o.causal != 0, o.ms, o.stats, redo_flag, redo_seq);
+    if (record_probe) {
+        if (hipEventRecord(dev->adaptive.probe_done, (hipStream_t)stream) != hipSuccess) {
+            (void)hipGetLastError();
+            std::lock_guard<std::mutex> lock(dev->adaptive.mu);
+            dev->adaptive.mode = 0;  // (no event to wait for: back to NORMAL; a failing probe reports like any launch)
+        }
+    }
+    return rc;
 }
 
 int fa_adaptive_state(int device, fa_adaptive_info *out) {
@@ -492,7 +544,8 @@ int fa_adaptive_state(int device, fa_adaptive_info *out) {
     out->demoted = ad.demoted;
     out->reports = ad.reports;
     out->hold = ad.hold;
-    out->demote_until = ad.demote_until;
+    out->mode = ad.mode;
+    out->remaining = ad.remaining;
     out->last_report = ad.flag_host ? __atomic_load_n(ad.flag_host, __ATOMIC_RELAXED) : 0u;
     out->available = ad.flag_host != nullptr;
     return FA_OK;
@@ -505,7 +558,8 @@ int fa_adaptive_reset(int device) {
     AdaptiveState &ad = st.adaptive;
     std::lock_guard<std::mutex> lock(ad.mu);
     ad.seen = ad.flag_host ? __atomic_load_n(ad.flag_host, __ATOMIC_RELAXED) : 0u;
-    ad.demote_until = 0;
+    ad.mode = 0;
+    ad.remaining = 0;
     ad.hold = 32;
     ad.demoted = 0;
     ad.reports = 0;

@@ -141,15 +141,18 @@ typedef struct fa_fwd_stats {
     uint32_t items_redone;
 } fa_fwd_stats;
 
-/* fa_fwd_opts.speculative.  ADAPTIVE: the speculative variant, except that after a speculative launch on this device
- * has reported items it had to compute twice (a failed item costs its workgroup a second item time, and a launch ends
- * with its slowest workgroup) the library enqueues the NON-speculative variant of cfg for the next `hold` adaptive
- * launches there (32, doubled up to 4096 while probes keep failing, reset after a long quiet stretch), then probes the
- * speculative one again.  The report is one word of pinned host memory a failing workgroup stores into; the library
- * reads it when the next adaptive launch is enqueued and never waits for the device.  Both variants compute the same
- * real result within the same tolerance (they round P at different points), so WHICH of the two served a launch --
- * which depends on when a report arrived -- is visible only in the last bits: ask for 0 or 1 where bit-reproducible
- * output matters.  A launch captured into a hipGraph freezes the decision made at capture time.  State per device:
+/* fa_fwd_opts.speculative.  ADAPTIVE: the speculative variant, except that the library watches the failure reports of its
+ * speculative launches on the device (a failed item costs its workgroup a second item time, and a launch ends with its
+ * slowest workgroup: one failing item in a thousand costs a quarter of a 4-items-per-CU launch, everything failing 2x):
+ *   NORMAL   every launch speculative; a report -> the next `hold` adaptive launches take the NON-speculative variant of cfg
+ *   DEMOTED  ... after which ONE launch probes the speculative variant again (an event is recorded behind it)
+ *   PROBING  launches stay demoted until the probe has completed (hipEventQuery, never a wait); a probe that reported too
+ *            doubles `hold` (32 ... 4096), one that did not returns the device to NORMAL.
+ * The report is one word of pinned host memory a failing workgroup stores into; the library reads it when an adaptive
+ * launch is enqueued and never waits for the device.  Both variants compute the same real result within the same
+ * tolerance (they round P at different points), so WHICH of the two served a launch -- which depends on when a report
+ * arrived -- is visible only in the last bits: ask for 0 or 1 where bit-reproducible output matters.  A launch made
+ * during a stream capture is always speculative (nothing adaptive is recorded into a graph).  State per device:
  * fa_adaptive_state / fa_adaptive_reset. */
 typedef enum fa_speculative_mode {
     FA_SPECULATIVE_OFF = 0,
@@ -163,7 +166,8 @@ typedef struct fa_adaptive_info {
     uint32_t demoted;        /* ... of which took the non-speculative variant */
     uint32_t reports;        /* distinct failure reports acted on */
     uint32_t hold;           /* current length of a demotion, in adaptive launches */
-    uint32_t demote_until;   /* launches up to this sequence number are demoted (0: none pending) */
+    uint32_t mode;           /* 0 NORMAL, 1 DEMOTED, 2 PROBING */
+    uint32_t remaining;      /* DEMOTED: launches of the hold still to come */
     uint32_t last_report;    /* sequence number of the most recent launch that reported (0: none yet) */
 } fa_adaptive_info;
 

@@ -759,7 +759,7 @@ def test_adaptive_speculative_mode_demotes_after_a_reported_redo():
         demoted = [flash_attention.forward(cfg, qs, ks, vs) for _ in range(5)]
         torch.cuda.synchronize()
         st3 = _capi.adaptive_state(dev)
-        assert st3["reports"] == 1 and st3["demoted"] == 5 and st3["demote_until"] == st2["launches"] + st3["hold"]
+        assert st3["reports"] == 1 and st3["demoted"] == 5 and st3["mode"] == 1 and st3["remaining"] == st3["hold"] - 5
         want_lazy = flash_attention.forward(lazy, qs, ks, vs)
         assert all(torch.equal(o, want_lazy) for o in demoted)      # the demoted launches ARE the lazy variant
         # (a failed item's second pass is the lazy schedule: the speculative launch agrees with it on those items, and on
@@ -773,11 +773,21 @@ def test_adaptive_speculative_mode_demotes_after_a_reported_redo():
             flash_attention.forward(cfg, qs, ks, vs)
         torch.cuda.synchronize()
         assert _capi.adaptive_state(dev)["demoted"] == hold
-        flash_attention.forward(cfg, qs, ks, vs)      # the probe
+        probe = flash_attention.forward(cfg, qs, ks, vs)      # the probe: speculative again, an event recorded behind it
+        assert _capi.adaptive_state(dev)["mode"] == 2 and torch.equal(probe, first)
         torch.cuda.synchronize()
-        flash_attention.forward(cfg, qs, ks, vs)      # sees the probe's report
+        flash_attention.forward(cfg, qs, ks, vs)      # sees the probe's report: a longer hold
         st4 = _capi.adaptive_state(dev)
-        assert st4["reports"] == 2 and st4["hold"] == 2 * hold and st4["demoted"] == hold + 1
+        assert st4["reports"] == 2 and st4["hold"] == 2 * hold and st4["demoted"] == hold + 1 and st4["mode"] == 1
+        # 4. the data turns benign: the probe behind the (longer) hold succeeds and the device is back to NORMAL
+        for _ in range(st4["remaining"]):
+            flash_attention.forward(cfg, q, k, v)
+        ok_probe = flash_attention.forward(cfg, q, k, v)
+        assert _capi.adaptive_state(dev)["mode"] == 2 and torch.equal(ok_probe, want)
+        torch.cuda.synchronize()
+        flash_attention.forward(cfg, q, k, v)
+        st5 = _capi.adaptive_state(dev)
+        assert st5["mode"] == 0 and st5["hold"] == 32 and st5["reports"] == 2
         _capi.adaptive_reset(dev)
 
 

@@ -553,7 +553,7 @@ def test_jitter_library_is_built_and_exports_the_same_abi():
 
 def test_adaptive_mode_abi():
     """fa_speculative_mode / fa_adaptive_info (include/fa_hip.h): struct layout of the ctypes mirror, the version numbers."""
-    assert ctypes.sizeof(_capi.FaAdaptiveInfo) == 7 * 4
+    assert ctypes.sizeof(_capi.FaAdaptiveInfo) == 8 * 4
     lib = _capi.load()
     assert lib.fa_abi_version() == _capi.FA_ABI_VERSION == 4
     header = open(os.path.join(ROOT, "include", "fa_hip.h")).read()
