@@ -633,6 +633,12 @@ def robustness(cfg, shape, dtype, device, args, flop, sync):
         flash_attention_kernels.forward(c_spec, q, k, v, o, stats=stats)
         sync()
         items, redone = (int(x) for x in stats.tolist())
+    adaptive_record = None
+    if getattr(cfg, "adaptive_softmax", False):  # what the adaptive mode did over this process's launches on the device
+        from flash_attention_from_scratch_amd import _capi
+
+        st = _capi.adaptive_state(local_rank)
+        adaptive_record = {k_: st[k_] for k_ in ("launches", "demoted", "reports", "hold", "mode")}
         rec = _interleaved([("lazy", c_lazy), ("default", c_def), ("speculative_always", c_spec)], q, k, v, o, args, flop, sync, rounds=4)
         after = _capi.adaptive_state(device.index or 0)
         rec["items"] = items
@@ -910,7 +916,8 @@ def main():
             },
             "clocks": clocks,
             "speculative": {"items": items, "items_redone": redone, "second_pass_fraction": redone / items if items else None,
-                            "source": "fa_fwd_stats of one more (untimed) launch of the same step"},
+                            "source": "fa_fwd_stats of one more (untimed) launch of the same step",
+                            "adaptive": adaptive_record},
         }
         if sustained:
             sustained["tflops"] = flop_per_step_rank * world * sustained["steps"] / sustained["seconds"] / 1e12

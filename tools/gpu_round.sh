@@ -2,12 +2,13 @@
 # One gpurun call worth of evidence: probe -> smoke -> pytest -m gpu -> bench lines -> sweeps -> rocprof -> PMC.
 # Usage (from the repo root, on the GPU box):  bash tools/gpu_round.sh [tag]
 # Everything here runs on ONE lease: profiles/<round>/rocprof_kernel_stats.csv and bench_c1.json are the same box.
-TAG=${1:-r03}
+TAG=${1:-r04}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
 L=flash_attention_from_scratch_amd/lib
 SPEC="(BF16, 128, 256, 64, 4): async+eager+swizzled+load_0_0_0_tiles+buffer+spec_softmax"
+ADAPT="$SPEC+adaptive"   # what best_config() returns since round 4 (both dtypes)
 LAZY="(BF16, 128, 256, 64, 4): async+eager+swizzled+load_0_0_0_tiles+buffer"
 echo "== probe"; timeout 120 $L/layout_probe > $OUT/probe.txt 2>&1; tail -3 $OUT/probe.txt
 echo "== smoke"; timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.txt 2>&1; tail -3 $OUT/smoke.txt
@@ -19,33 +20,31 @@ echo "== bench c1, 2000 steps (sustained)"; timeout 600 python bench.py --steps 
 echo "== bench c1, no preconditioning (cold clocks)"; timeout 600 python bench.py --steps 20 --warmup 5 --precondition-ms 0 --no-cpu-baseline --no-traffic --hermetic-reps 0 --no-mfma-roof > $OUT/bench_c1_cold.json 2>/dev/null; cut -c1-200 $OUT/bench_c1_cold.json
 echo "== bench c1, lazy-rescale build"; timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-traffic --hermetic-reps 0 --no-mfma-roof --kernel "$LAZY" > $OUT/bench_c1_lazy.json 2>/dev/null; cut -c1-200 $OUT/bench_c1_lazy.json
 echo "== bench c1, pre-scaled Q (opt-in), with its pipe counters"; timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --hermetic-reps 0 --no-mfma-roof --kernel "$SPEC+prescaled_q" > $OUT/bench_c1_prescaled_q.json 2>/dev/null; cut -c1-200 $OUT/bench_c1_prescaled_q.json
-echo "== bench c1 fp16 (lazy = the fp16 default; speculative), with pipe counters: why fp16 trails bf16"
+echo "== bench c1 fp16 (default = adaptive speculative since round 4; lazy beside it), with pipe counters: why fp16 trails bf16"
 timeout 600 python bench.py --steps 20 --warmup 5 --dtype fp16 --no-cpu-baseline --hermetic-reps 0 > $OUT/bench_c1_fp16.json 2>/dev/null; cut -c1-200 $OUT/bench_c1_fp16.json
-timeout 600 python bench.py --steps 20 --warmup 5 --dtype fp16 --no-cpu-baseline --hermetic-reps 0 --no-mfma-roof --kernel "${SPEC/BF16/FP16}" > $OUT/bench_c1_fp16_spec.json 2>/dev/null; cut -c1-200 $OUT/bench_c1_fp16_spec.json
+timeout 600 python bench.py --steps 20 --warmup 5 --dtype fp16 --no-cpu-baseline --hermetic-reps 0 --no-mfma-roof --kernel "${LAZY/BF16/FP16}" > $OUT/bench_c1_fp16_lazy.json 2>/dev/null; cut -c1-200 $OUT/bench_c1_fp16_lazy.json
 echo "== non-Gaussian data: what the speculative softmax's second pass costs (sink: +12 nats at the first 4 keys; heavy: Student-t K)"
 : > $OUT/sink_data.txt
-for D in randn sink heavy; do for T in bf16 fp16; do for K in spec lazy; do
-  KK="$SPEC"; [ $K = lazy ] && KK="$LAZY"; [ $T = fp16 ] && KK="${KK/BF16/FP16}"
+for D in randn sink heavy; do for T in bf16 fp16; do for K in spec adaptive lazy; do
+  KK="$SPEC"; [ $K = lazy ] && KK="$LAZY"; [ $K = adaptive ] && KK="$ADAPT"; [ $T = fp16 ] && KK="${KK/BF16/FP16}"
   timeout 600 python bench.py --steps 20 --warmup 5 --data $D --dtype $T --kernel "$KK" --no-cpu-baseline --no-traffic --hermetic-reps 0 --no-mfma-roof > $OUT/b.json 2>/dev/null
-  python -c "import json;r=json.load(open('$OUT/b.json'));s=r['speculative'];print('%-6s %-5s %-12s %8.1f TFLOP/s   items %d redone %d (%.1f %%)' % ('$D','$T',r['config']['softmax_mode'],r['value'],s['items'],s['items_redone'],100*s['second_pass_fraction']))" | tee -a $OUT/sink_data.txt
+  python -c "import json;r=json.load(open('$OUT/b.json'));s=r['speculative'];print('%-6s %-5s %-9s %8.1f TFLOP/s   items %d redone %d (%.1f %%) in one more launch; adaptive: %s' % ('$D','$T','$K',r['value'],s['items'],s['items_redone'],100*s['second_pass_fraction'],s.get('adaptive')))" | tee -a $OUT/sink_data.txt
 done; done; done
 for W in c3 c4; do echo "== bench $W"; timeout 900 python bench.py --workload $W --steps 10 --warmup 3 --no-cpu-baseline --hermetic-reps 0 --no-mfma-roof > $OUT/bench_$W.json 2>/dev/null; cut -c1-200 $OUT/bench_$W.json; done
-echo "== bench c3 with the speculative softmax (opt-in for fp16)"; timeout 900 python bench.py --workload c3 --steps 10 --warmup 3 --no-cpu-baseline --no-traffic --hermetic-reps 0 --no-mfma-roof --kernel "${SPEC/BF16/FP16}" > $OUT/bench_c3_spec.json 2>/dev/null; cut -c1-200 $OUT/bench_c3_spec.json
-echo "== bench c2 (seq sweep, harmonic mean): default, and with the pre-scaled Q"; timeout 900 python bench.py --workload c2 --steps 20 --warmup 5 > $OUT/bench_c2.json 2>/dev/null; cut -c1-200 $OUT/bench_c2.json
-timeout 900 python bench.py --workload c2 --steps 20 --warmup 5 --no-traffic --kernel "$SPEC+prescaled_q" > $OUT/bench_c2_prescaled_q.json 2>/dev/null; cut -c1-200 $OUT/bench_c2_prescaled_q.json
+echo "== bench c3 with the lazy rescale (round 3's fp16 default)"; timeout 900 python bench.py --workload c3 --steps 10 --warmup 3 --no-cpu-baseline --no-traffic --hermetic-reps 0 --no-mfma-roof --kernel "${LAZY/BF16/FP16}" > $OUT/bench_c3_lazy.json 2>/dev/null; cut -c1-200 $OUT/bench_c3_lazy.json
+echo "== bench c2 (seq sweep, harmonic mean)"; timeout 900 python bench.py --workload c2 --steps 20 --warmup 5 > $OUT/bench_c2.json 2>/dev/null; cut -c1-200 $OUT/bench_c2.json
 echo "== bench --gpus 2, self-launched (gloo; both ranks on this box's one GPU: plumbing only)"; timeout 600 python bench.py --gpus 2 --warmup 2 > $OUT/bench_n2_selflaunch.json 2> $OUT/bench_n2.err; cut -c1-200 $OUT/bench_n2_selflaunch.json
 echo "== wideners"; timeout 600 python flash_attention_from_scratch_amd/tools/bench_wideners.py > $OUT/wideners.txt 2>/dev/null; cat $OUT/wideners.txt
-echo "== tune64 (seam experiments + the pre-scaled Q, interleaved)"; timeout 600 $L/tune64 reps=8 > $OUT/tune64.txt 2>&1; grep "S= 4096" $OUT/tune64.txt
+echo "== tune64 (closing list: shipped / r03 plan / no guard / pre-scaled Q / lazy, interleaved)"; timeout 600 $L/tune64 reps=8 > $OUT/tune64.txt 2>&1; grep "S= 4096" $OUT/tune64.txt
 echo "== trace64_items / seam"; for a in "512 16 16" "1024 16 16" "4096 4 16"; do timeout 120 $L/trace64_items $a 2>&1 | grep -E "^==|mean over" | tail -2; done > $OUT/trace64_items.txt; timeout 120 $L/trace64_seam 512 16 16 2>&1 | grep -E "first seam" | tail -1 >> $OUT/trace64_items.txt; cat $OUT/trace64_items.txt | cut -c1-300
 echo "== mfma_energy"; timeout 300 $L/mfma_energy > $OUT/mfma_energy.txt 2>&1; $L/mfma_energy quick >> $OUT/mfma_energy.txt 2>&1; cat $OUT/mfma_energy.txt
-echo "== prescaled Q error report"; timeout 600 python tools/psq_error.py 2>/dev/null > $OUT/prescaled_q_error.txt; tail -4 $OUT/prescaled_q_error.txt
 echo "== c3 traffic by request size"; timeout 600 python tools/c3_traffic.py > $OUT/c3_traffic.txt 2>&1; grep "read bytes" $OUT/c3_traffic.txt
-echo "== seqsweep"; bash tools/gpu_seqsweep.sh $TAG/seq > /dev/null 2>&1
-echo "== sweeps (native; the reference's 80 configs with the reference's meaning of opt_softmax; the same under FA_ALLOW_SPECULATIVE=1)"
+echo "== sweeps (native; the reference's 80 configs with the reference's meaning of opt_softmax)"
 KERNELS=native timeout 900 python flash_attention_from_scratch_amd/tools/pt_bench.py --seq_lens 4096 --batch 4 --num_repeats 20 --num_warmups 5 > $OUT/sweep_native_c1.csv 2> $OUT/sweep.err
 KERNELS=tune timeout 900 python flash_attention_from_scratch_amd/tools/pt_bench.py --seq_lens 4096 --batch 4 --num_repeats 20 --num_warmups 5 > $OUT/sweep_tune_c1.csv 2>> $OUT/sweep.err
-FA_ALLOW_SPECULATIVE=1 KERNELS=tune timeout 900 python flash_attention_from_scratch_amd/tools/pt_bench.py --seq_lens 4096 --batch 4 --num_repeats 20 --num_warmups 5 > $OUT/sweep_tune_c1_allow_speculative.csv 2>> $OUT/sweep.err
 head -4 $OUT/sweep_native_c1.csv | cut -c1-160; tail -2 $OUT/sweep.err
 echo "== pmc"; bash tools/gpu_pmc.sh $TAG/pmc "$SPEC" "$LAZY" "$SPEC+prescaled_q" > $OUT/pmc.log 2>&1; tail -30 $OUT/pmc/pmc_summary.txt; cat $OUT/pmc/pmc_traffic.json
 echo "== soak 60 s"; timeout 300 python tools/soak.py 60 3 > $OUT/soak.txt 2>&1; tail -2 $OUT/soak.txt
+echo "== soak 60 s under the jitter build"; FA_HIP_LIB=$PWD/$L/libfa_hip_jitter.so timeout 300 python tools/soak.py 60 17 > $OUT/soak_jitter.txt 2>&1; tail -2 $OUT/soak_jitter.txt
+echo "== jitter_check (product, then jitter build)"; timeout 300 python tools/jitter_check.py > $OUT/jitter_check.txt 2>&1; FA_HIP_LIB=$PWD/$L/libfa_hip_jitter.so timeout 300 python tools/jitter_check.py >> $OUT/jitter_check.txt 2>&1; grep -c "repeat=1" $OUT/jitter_check.txt
 echo "== done"
