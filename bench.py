@@ -633,12 +633,6 @@ def robustness(cfg, shape, dtype, device, args, flop, sync):
         flash_attention_kernels.forward(c_spec, q, k, v, o, stats=stats)
         sync()
         items, redone = (int(x) for x in stats.tolist())
-    adaptive_record = None
-    if getattr(cfg, "adaptive_softmax", False):  # what the adaptive mode did over this process's launches on the device
-        from flash_attention_from_scratch_amd import _capi
-
-        st = _capi.adaptive_state(local_rank)
-        adaptive_record = {k_: st[k_] for k_ in ("launches", "demoted", "reports", "hold", "mode")}
         rec = _interleaved([("lazy", c_lazy), ("default", c_def), ("speculative_always", c_spec)], q, k, v, o, args, flop, sync, rounds=4)
         after = _capi.adaptive_state(device.index or 0)
         rec["items"] = items
@@ -852,6 +846,12 @@ def main():
     flash_attention_kernels.forward(cfg, q, k, v, o, stats=stats)
     sync()
     items, redone = (int(x) for x in stats.tolist())
+    adaptive_record = None
+    if getattr(cfg, "adaptive_softmax", False):  # what the adaptive mode did over this process's launches on the device
+        from flash_attention_from_scratch_amd import _capi
+
+        st = _capi.adaptive_state(local_rank)
+        adaptive_record = {k_: st[k_] for k_ in ("launches", "demoted", "reports", "hold", "mode")}
 
     per_rank = per_rank_clocks = None
     if world > 1:  # per-GPU rates, clocks and power next to the aggregate (rank order)
