@@ -445,11 +445,8 @@ def run_c2_sweep(args, device):
                 flash_attention.forward(cfg, q, k, v, o)
             torch.cuda.synchronize(device)
             return
-        t_pre = time.perf_counter()  # wake the clocks (see --precondition-ms), per shape: allocation and randn idle the chip
-        while (time.perf_counter() - t_pre) * 1e3 < args.precondition_ms:
-            for _ in range(8):
-                flash_attention.forward(cfg, q, k, v, o)
-            torch.cuda.synchronize(device)
+        # wake the clocks (see --precondition-ms), per shape: allocation and randn idle the chip
+        precondition(lambda: flash_attention.forward(cfg, q, k, v, o), device, args.precondition_ms)
         sampler = ClockSampler(hw)
         sampler.start()   # (before the warm-ups: see main())
         for _ in range(args.warmup):
@@ -537,14 +534,44 @@ def dry_run(args, rank, world):
         dist.destroy_process_group()
 
 
+def precondition(step, device, ms, sync_every_batch=False, batch=16):
+    """Untimed launches of `step` for `ms` milliseconds: the clock governor needs load to leave its idle state.  The device is
+    kept CONTINUOUSLY busy -- a batch is enqueued while the one before still runs (an event behind every batch, the host
+    waits for the batch before the last) -- because a synchronize after every few launches (rounds 2-3: every 8) idles the
+    chip for ~0.1 ms each time and the governor then never settles where a long run does.  Returns (steps, seconds per step
+    of the last completed batch).  FA_BENCH_PRECONDITION_SYNC=1 restores the old loop for an A/B."""
+    sync_every_batch = sync_every_batch or os.environ.get("FA_BENCH_PRECONDITION_SYNC") == "1"
+    stream = torch.cuda.current_stream(device)
+    n, t_start, per_step = 0, time.perf_counter(), 0.0
+    if sync_every_batch:
+        while (time.perf_counter() - t_start) * 1e3 < ms or n < 8:
+            t_a = time.perf_counter()
+            for _ in range(8):
+                step()
+            torch.cuda.synchronize(device)
+            per_step = (time.perf_counter() - t_a) / 8
+            n += 8
+        return n, per_step
+    pending = []
+    while (time.perf_counter() - t_start) * 1e3 < ms or n < 8:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(batch):
+            step()
+        e1.record(stream)
+        n += batch
+        pending.append((e0, e1))
+        if len(pending) > 2:
+            a0, a1 = pending.pop(0)
+            a1.synchronize()                     # (the device still has two batches queued behind this one)
+            per_step = a0.elapsed_time(a1) * 1e-3 / batch
+    return n, per_step
+
+
 def _timed_protocol(forward, cfg_, q, k, v, o, steps, warmup, pre_ms, sync):
     """The protocol of `value` in small: `pre_ms` of untimed launches (the chip is warm behind the main region: 100 ms
     re-settles it after a variant switch), `warmup` launches, then `steps` launches between two synchronisations."""
-    t_p = time.perf_counter()
-    while (time.perf_counter() - t_p) * 1e3 < pre_ms:
-        for _ in range(8):
-            forward(cfg_, q, k, v, o)
-        sync()
+    precondition(lambda: forward(cfg_, q, k, v, o), q.device, pre_ms)
     for _ in range(warmup):
         forward(cfg_, q, k, v, o)
     sync()
@@ -787,17 +814,17 @@ def main():
 
     sampler = ClockSampler(hwmon_dir(local_rank))
     # wake the clocks: the same launches, untimed, until --precondition-ms have passed
-    pre_steps, t_pre, pre_gpu_s = 0, time.perf_counter(), 0.0
-    while (time.perf_counter() - t_pre) * 1e3 < args.precondition_ms or pre_steps < 8:
-        t_a = time.perf_counter()
-        for _ in range(8):
-            step()
-        sync()
-        pre_gpu_s = time.perf_counter() - t_a
-        pre_steps += 8
+    pre_steps, pre_step_s = precondition(step, device, args.precondition_ms)
     if args.steps is None:
         # N = 1: 50.  N > 1: a timed region of >= 200 ms per rank (from the last preconditioning batch's step time)
-        est = max(pre_gpu_s / 8, 1e-6)
+        if pre_step_s <= 0.0:   # (a preconditioning too short to complete a batch: one timed batch)
+            sync()
+            t_a = time.perf_counter()
+            for _ in range(8):
+                step()
+            sync()
+            pre_step_s = (time.perf_counter() - t_a) / 8
+        est = max(pre_step_s, 1e-6)
         args.steps = 50 if world == 1 else max(50, int(0.2 / est) + 1)
         if world > 1:  # every rank times the same number of steps
             import torch.distributed as dist
@@ -902,7 +929,8 @@ def main():
             "protocol": "hermetic: flush + idle spin before every launch, value from the per-launch events"
                         if args.hermetic else "back-to-back launches",
             "precondition": {"ms": args.precondition_ms, "untimed_steps": pre_steps,
-                             "why": "clock governor ramp from idle; before the W warm-up steps, outside the timed region"},
+                             "why": "clock governor ramp from idle; before the W warm-up steps, outside the timed region; the "
+                                    "device is kept continuously busy (no synchronize between the batches)"},
             "config": {
                 "workload": f"{args.workload}: FA2 forward {dtype_name} batch={batch}/GPU heads={heads} "
                             f"seq_len={seq} d_head={d} non-causal",

@@ -27,7 +27,7 @@ EXPORTED_SYMBOLS = (
     "fa_fwd_launch_timed", "fa_num_kernels", "fa_get_kernel", "fa_last_error", "fa_version",
     "fa_fwd_masked_supported", "fa_fwd_launch_masked", "fa_device_state",
     "fa_fwd_ex_supported", "fa_fwd_launch_ex", "fa_fwd_query",
-    "fa_adaptive_state", "fa_adaptive_reset", "fa_get_kernel_sized", "fa_fwd_query_sized", "fa_abi_version",
+    "fa_adaptive_state", "fa_adaptive_reset", "fa_adaptive_simulate", "fa_get_kernel_sized", "fa_fwd_query_sized", "fa_abi_version",
 )
 FA_SPECULATIVE_OFF, FA_SPECULATIVE_ALWAYS, FA_SPECULATIVE_ADAPTIVE = 0, 1, 2  # fa_speculative_mode
 FA_ABI_VERSION = 4
@@ -151,6 +151,9 @@ def load():
     lib.fa_adaptive_state.argtypes = [ctypes.c_int, ctypes.POINTER(FaAdaptiveInfo)]
     lib.fa_adaptive_reset.restype = ctypes.c_int
     lib.fa_adaptive_reset.argtypes = [ctypes.c_int]
+    lib.fa_adaptive_simulate.restype = ctypes.c_int
+    lib.fa_adaptive_simulate.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_int32),
+                                         ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(FaAdaptiveInfo)]
     lib.fa_get_kernel_sized.restype = ctypes.c_int
     lib.fa_get_kernel_sized.argtypes = [ctypes.c_int, ctypes.POINTER(FaKernelInfo), ctypes.c_uint32]
     lib.fa_fwd_query_sized.restype = ctypes.c_int
@@ -247,3 +250,17 @@ def adaptive_state(device: int) -> dict:
 
 def adaptive_reset(device: int) -> None:
     check(load().fa_adaptive_reset(int(device)))
+
+
+def adaptive_simulate(report_word, probe_state):
+    """fa_adaptive_simulate: the adaptive policy on a fresh state, scripted -- launch i sees report_word[i] and
+    probe_state[i] (-1 none, 0 pending, 1 complete, 2 error).  -> ([run_i], final state dict); run: 0 speculative,
+    1 demoted, 2 probe."""
+    n = len(report_word)
+    assert len(probe_state) == n
+    rep = (ctypes.c_uint32 * n)(*report_word)
+    prb = (ctypes.c_int32 * n)(*probe_state)
+    run = (ctypes.c_int32 * n)()
+    info = FaAdaptiveInfo()
+    check(load().fa_adaptive_simulate(n, rep, prb, run, ctypes.byref(info)))
+    return list(run), {name: int(getattr(info, name)) for name, _ in FaAdaptiveInfo._fields_}

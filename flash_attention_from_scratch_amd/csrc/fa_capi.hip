@@ -127,19 +127,59 @@ const fa::KernelEntry *find_kernel(const fa_fwd_config *c, const char **why, con
 // launches enqueued before the first report lands.  Both variants give a valid result (they differ in the rounding point
 // of P); which one served a given launch depends on when a report arrived, so bit-reproducible callers ask for
 // speculative = 0 or 1 instead.  During a stream capture the mode behaves like ALWAYS (no event is recorded into a graph).
+// The policy itself is plain arithmetic over (the report word as read now, what the probe's event says): kept apart from
+// HIP so that the CPU tier can script it (fa_adaptive_simulate; tests/test_host_cpu.py).
+struct AdaptivePolicy {
+    enum { NORMAL = 0, DEMOTED = 1, PROBING = 2 };
+    enum { PROBE_NA = -1, PROBE_PENDING = 0, PROBE_COMPLETE = 1, PROBE_ERROR = 2 };
+    enum { RUN_SPECULATIVE = 0, RUN_DEMOTED = 1, RUN_PROBE = 2 };
+    uint32_t seq = 0;        // adaptive launches enqueued on this device so far
+    uint32_t seen = 0;       // the last report acted on
+    uint32_t mode = NORMAL;
+    uint32_t remaining = 0;  // DEMOTED: launches of the hold still to come
+    uint32_t probe_seq = 0;
+    uint32_t hold = 32;
+    uint32_t demoted = 0;    // adaptive launches that took the non-speculative variant
+    uint32_t reports = 0;    // distinct failure reports acted on
+
+    // One adaptive launch.  `rep`: the report word, read AFTER the probe's event was queried (a probe that has completed
+    // has its report in memory by then); `probe`: PROBE_* (only looked at while PROBING).
+    int step(uint32_t rep, int probe) {
+        ++seq;
+        const bool fresh = rep != seen;   // a speculative launch that has completed since computed items twice
+        if (fresh) { seen = rep; ++reports; }
+        if (mode == PROBING) {
+            if (fresh) {                            // the probe (or a straggler from before the hold) failed: a longer hold
+                if (hold < 4096) hold *= 2;
+                mode = DEMOTED;
+                remaining = hold;
+            } else if (probe == PROBE_COMPLETE) {   // the probe ran clean
+                mode = NORMAL;
+                hold = 32;
+            } else if (probe == PROBE_ERROR) {
+                mode = NORMAL;
+            }
+        } else if (fresh) {                         // NORMAL or DEMOTED: (another) failure reported
+            mode = DEMOTED;
+            remaining = hold;
+        }
+        if (mode == DEMOTED) {
+            if (remaining > 0) { --remaining; ++demoted; return RUN_DEMOTED; }
+            mode = PROBING;                         // the hold has run out: this launch is the probe
+            probe_seq = seq;
+            return RUN_PROBE;
+        }
+        if (mode == PROBING) { ++demoted; return RUN_DEMOTED; }
+        return RUN_SPECULATIVE;
+    }
+    void reset(uint32_t rep_now) { seen = rep_now; mode = NORMAL; remaining = 0; hold = 32; demoted = 0; reports = 0; }
+};
 struct AdaptiveState {
     std::mutex mu;
     uint32_t *flag_host = nullptr;  // hipHostMalloc'ed (mapped, coherent) word; null: no pinned memory -> always speculative
     uint32_t *flag_dev = nullptr;   // the same word as the device addresses it
     hipEvent_t probe_done = nullptr;
-    uint32_t seq = 0;               // adaptive launches enqueued on this device so far
-    uint32_t seen = 0;              // the last report acted on
-    uint32_t mode = 0;              // 0 NORMAL, 1 DEMOTED, 2 PROBING
-    uint32_t remaining = 0;         // DEMOTED: launches of the hold still to come
-    uint32_t probe_seq = 0;
-    uint32_t hold = 32;
-    uint32_t demoted = 0;           // adaptive launches that took the non-speculative variant
-    uint32_t reports = 0;           // distinct failure reports acted on
+    AdaptivePolicy p;
 };
 struct DeviceState {
     std::once_flag once;
@@ -469,47 +509,19 @@ int fa_fwd_launch_ex(const fa_fwd_args *args, const fa_fwd_opts *opts, void *str
         bool demote = false;
         if (cap == hipStreamCaptureStatusNone) {
             std::lock_guard<std::mutex> lock(ad.mu);
-            const uint32_t seq = ++ad.seq;
-            const uint32_t rep = __atomic_load_n(ad.flag_host, __ATOMIC_RELAXED);
-            const bool fresh = rep != ad.seen;   // a speculative launch that has completed since computed items twice
-            if (fresh) { ad.seen = rep; ++ad.reports; }
-            if (ad.mode == 2) {                  // PROBING: has the probe finished?
+            int probe = AdaptivePolicy::PROBE_NA;
+            if (ad.p.mode == AdaptivePolicy::PROBING) {   // has the probe finished?  (never a wait)
                 const hipError_t q = hipEventQuery(ad.probe_done);
-                if (q == hipSuccess || fresh) {
-                    // (re-read: the report of a probe that has completed is visible by now)
-                    const uint32_t rep2 = __atomic_load_n(ad.flag_host, __ATOMIC_RELAXED);
-                    if (rep2 != ad.seen) { ad.seen = rep2; ++ad.reports; }
-                    if (fresh || rep2 == ad.probe_seq || ad.seen == ad.probe_seq) {
-                        if (ad.hold < 4096) ad.hold *= 2;
-                        ad.mode = 1;
-                        ad.remaining = ad.hold;
-                    } else {
-                        ad.mode = 0;
-                        ad.hold = 32;
-                    }
-                } else if (q != hipErrorNotReady) {
-                    (void)hipGetLastError();
-                    ad.mode = 0;
-                }
-            } else if (fresh) {                  // NORMAL or DEMOTED: (another) failure reported
-                ad.mode = 1;
-                ad.remaining = ad.hold;
+                probe = q == hipSuccess ? AdaptivePolicy::PROBE_COMPLETE
+                                        : (q == hipErrorNotReady ? AdaptivePolicy::PROBE_PENDING : AdaptivePolicy::PROBE_ERROR);
+                if (q != hipSuccess) (void)hipGetLastError();
             }
-            if (ad.mode == 1) {
-                if (ad.remaining > 0) {
-                    --ad.remaining;
-                    demote = true;
-                } else {                         // the hold has run out: this launch is the probe
-                    ad.mode = 2;
-                    ad.probe_seq = seq;
-                    record_probe = true;
-                }
-            } else if (ad.mode == 2 && !record_probe) {
-                demote = true;
-            }
-            if (demote) ++ad.demoted;
+            const uint32_t rep = __atomic_load_n(ad.flag_host, __ATOMIC_ACQUIRE);   // (behind the query: see step())
+            const int run = ad.p.step(rep, probe);
+            demote = run == AdaptivePolicy::RUN_DEMOTED;
+            record_probe = run == AdaptivePolicy::RUN_PROBE;
             redo_flag = ad.flag_dev;
-            redo_seq = seq;
+            redo_seq = ad.p.seq;
         }
         if (demote) {
             Want w2 = w;
@@ -526,7 +538,7 @@ int fa_fwd_launch_ex(const fa_fwd_args *args, const fa_fwd_opts *opts, void *str
         if (hipEventRecord(dev->adaptive.probe_done, (hipStream_t)stream) != hipSuccess) {
             (void)hipGetLastError();
             std::lock_guard<std::mutex> lock(dev->adaptive.mu);
-            dev->adaptive.mode = 0;  // (no event to wait for: back to NORMAL; a failing probe reports like any launch)
+            dev->adaptive.p.mode = AdaptivePolicy::NORMAL;  // (no event to wait for; a failing probe reports like any launch)
         }
     }
     return rc;
@@ -540,14 +552,32 @@ int fa_adaptive_state(int device, fa_adaptive_info *out) {
     if (!st.inited.load(std::memory_order_acquire)) return FA_OK;
     AdaptiveState &ad = st.adaptive;
     std::lock_guard<std::mutex> lock(ad.mu);
-    out->launches = ad.seq;
-    out->demoted = ad.demoted;
-    out->reports = ad.reports;
-    out->hold = ad.hold;
-    out->mode = ad.mode;
-    out->remaining = ad.remaining;
+    out->launches = ad.p.seq;
+    out->demoted = ad.p.demoted;
+    out->reports = ad.p.reports;
+    out->hold = ad.p.hold;
+    out->mode = ad.p.mode;
+    out->remaining = ad.p.remaining;
     out->last_report = ad.flag_host ? __atomic_load_n(ad.flag_host, __ATOMIC_RELAXED) : 0u;
     out->available = ad.flag_host != nullptr;
+    return FA_OK;
+}
+
+int fa_adaptive_simulate(int n, const uint32_t *report_word, const int32_t *probe_state, int32_t *run, fa_adaptive_info *final_state) {
+    if (n < 0 || (n > 0 && (!report_word || !probe_state || !run))) return fail(FA_ERR_NULL, "null pointer argument");
+    AdaptivePolicy p;
+    for (int i = 0; i < n; ++i) run[i] = p.step(report_word[i], probe_state[i]);
+    if (final_state) {
+        memset(final_state, 0, sizeof(*final_state));
+        final_state->available = 1;
+        final_state->launches = p.seq;
+        final_state->demoted = p.demoted;
+        final_state->reports = p.reports;
+        final_state->hold = p.hold;
+        final_state->mode = p.mode;
+        final_state->remaining = p.remaining;
+        final_state->last_report = n > 0 ? report_word[n - 1] : 0u;
+    }
     return FA_OK;
 }
 
@@ -557,12 +587,7 @@ int fa_adaptive_reset(int device) {
     if (!st.inited.load(std::memory_order_acquire)) return FA_OK;
     AdaptiveState &ad = st.adaptive;
     std::lock_guard<std::mutex> lock(ad.mu);
-    ad.seen = ad.flag_host ? __atomic_load_n(ad.flag_host, __ATOMIC_RELAXED) : 0u;
-    ad.mode = 0;
-    ad.remaining = 0;
-    ad.hold = 32;
-    ad.demoted = 0;
-    ad.reports = 0;
+    ad.p.reset(ad.flag_host ? __atomic_load_n(ad.flag_host, __ATOMIC_RELAXED) : 0u);
     return FA_OK;
 }
 

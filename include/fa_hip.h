@@ -240,6 +240,10 @@ int fa_fwd_launch_ex(const fa_fwd_args *args, const fa_fwd_opts *opts, void *str
  * or a caller that knows its data has changed character). */
 int fa_adaptive_state(int device, fa_adaptive_info *out);
 int fa_adaptive_reset(int device);
+/* The policy alone, on a fresh state and without a device (tests): launch i sees report_word[i] in the pinned word and
+ * probe_state[i] for its outstanding probe (-1 none, 0 pending, 1 complete, 2 error); run[i] = 0 speculative, 1 the
+ * non-speculative sibling, 2 the probe (speculative, an event recorded behind it). */
+int fa_adaptive_simulate(int n, const uint32_t *report_word, const int32_t *probe_state, int32_t *run, fa_adaptive_info *final_state);
 
 /* Registry enumeration: distinct device variants built into this library.  fa_get_kernel / fa_fwd_query write
  * sizeof(fa_kernel_info) bytes of THIS library's header; fa_kernel_info has grown (0.2 -> 0.3: softmax_mode,

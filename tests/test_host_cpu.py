@@ -567,3 +567,47 @@ def test_adaptive_mode_abi():
     assert lib.fa_get_kernel_sized(0, ctypes.cast(buf, ctypes.POINTER(_capi.FaKernelInfo)), small) == 0
     assert bytes(buf)[small:] == b"\x5a" * 8          # nothing written beyond the caller's size
     assert lib.fa_get_kernel(0, ctypes.byref(info)) == 0 and bytes(buf)[:small] == bytes(info)[:small]
+
+
+def test_adaptive_policy_scripted():
+    """The adaptive speculative mode's policy (csrc/fa_capi.hip AdaptivePolicy; include/fa_hip.h fa_speculative_mode), run
+    without a device through fa_adaptive_simulate: NORMAL -> a report -> DEMOTED for `hold` launches -> one PROBE -> demoted
+    while the probe is pending -> a failed probe doubles the hold (capped at 4096), a clean one returns to NORMAL / hold 32."""
+    SPEC, DEM, PROBE = 0, 1, 2
+    # benign: nothing ever reported
+    run, st = _capi.adaptive_simulate([0] * 50, [-1] * 50)
+    assert run == [SPEC] * 50 and st["mode"] == 0 and st["demoted"] == 0 and st["launches"] == 50
+    # launch 3 (sequence number 3) fails; its report lands while launches 4 .. 6 are enqueued; seen by launch 7
+    rep = [0, 0, 0, 0, 0, 0] + [3] * 32 + [3]
+    prb = [-1] * 38 + [-1]
+    run, st = _capi.adaptive_simulate(rep, prb)
+    assert run[:6] == [SPEC] * 6 and run[6:38] == [DEM] * 32 and run[38] == PROBE
+    assert st["mode"] == 2 and st["reports"] == 1 and st["hold"] == 32 and st["demoted"] == 32
+    # the probe (sequence number 39) is pending for three launches, then complete WITH a report: hold doubles
+    rep2 = rep + [3, 3, 3, 39]
+    prb2 = prb + [0, 0, 0, 1]
+    run, st = _capi.adaptive_simulate(rep2, prb2)
+    assert run[39:] == [DEM] * 4 and st["mode"] == 1 and st["hold"] == 64 and st["remaining"] == 63 and st["reports"] == 2
+    # ... 63 more demoted, the next probe (sequence 107) runs clean: NORMAL, hold back to 32
+    rep3 = rep2 + [39] * 63 + [39, 39, 39]
+    prb3 = prb2 + [-1] * 63 + [-1, 0, 1]
+    run, st = _capi.adaptive_simulate(rep3, prb3)
+    assert run[43:106] == [DEM] * 63 and run[106] == PROBE and run[107] == DEM and run[108] == SPEC
+    assert st["mode"] == 0 and st["hold"] == 32 and st["reports"] == 2
+    # steady failure: every probe fails -> holds 32, 64, ... 4096, 4096: ONE speculative launch per hold
+    rep, prb, want = [0], [-1], [SPEC]          # launch 1: speculative, fails (its report word: 1)
+    word, start, hold, holds = 1, 2, 32, []
+    for _ in range(9):
+        holds.append(hold)
+        # the launch at `start` sees the report (and, behind a probe, that the probe's event has completed)
+        rep += [word] * hold
+        prb += [1 if len(holds) > 1 else -1] + [-1] * (hold - 1)
+        want += [DEM] * hold
+        rep.append(word); prb.append(-1); want.append(PROBE)    # the hold has run out: the probe, which fails too
+        word = start + hold
+        start = word + 1
+        hold = min(2 * hold, 4096)
+    run, st = _capi.adaptive_simulate(rep, prb)
+    assert holds == [32, 64, 128, 256, 512, 1024, 2048, 4096, 4096]
+    assert run == want and run.count(PROBE) == 9 and run.count(SPEC) == 1
+    assert st["mode"] == 2 and st["hold"] == 4096 and st["reports"] == 9 and st["demoted"] == sum(holds)
