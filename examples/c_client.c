@@ -64,7 +64,7 @@ int main(void) {
     fa_fwd_opts o;
     memset(&o, 0, sizeof(o));
     o.struct_size = (uint32_t)sizeof(o);
-    o.speculative = 1;
+    o.speculative = FA_SPECULATIVE_ADAPTIVE;   /* speculative softmax, demoted per device while its launches report redone items */
     o.stats = (fa_fwd_stats *)dstats;
     float ms = 0.0f;
     o.ms = &ms;
@@ -103,7 +103,13 @@ int main(void) {
                 }
                 ++rows;
             }
-    printf("%s | softmax_mode %d, %d threads, %d B LDS | %.3f ms | items %u, computed twice %u | %d rows checked, max |err| %.3e, %d outside 2^-7 (1 + |ref|)\n",
-           fa_version(), info.softmax_mode, info.threads, info.lds_bytes, ms, st.items, st.items_redone, rows, worst, bad);
+    fa_adaptive_info ad;
+    int dev = 0;
+    CHECK_HIP(hipGetDevice(&dev));
+    if (fa_adaptive_state(dev, &ad) != FA_OK) { fprintf(stderr, "fa_adaptive_state: %s\n", fa_last_error()); return 3; }
+    printf("%s (ABI %d) | softmax_mode %d, %d threads, %d B LDS | %.3f ms | items %u, computed twice %u | adaptive: %u launches, %u demoted, mode %u | "
+           "%d rows checked, max |err| %.3e, %d outside 2^-7 (1 + |ref|)\n",
+           fa_version(), fa_abi_version(), info.softmax_mode, info.threads, info.lds_bytes, ms, st.items, st.items_redone,
+           ad.launches, ad.demoted, ad.mode, rows, worst, bad);
     return bad == 0 && st.items == (uint32_t)(B * H * (S / 256)) ? 0 : 1;
 }
