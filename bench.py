@@ -617,7 +617,7 @@ def _interleaved(named_cfgs, q, k, v, o, args, flop, sync, rounds=5):
     return out
 
 
-def side_by_side(cfg, q, k, v, o, args, flop, sync, device):
+def side_by_side(cfg, q, k, v, o, args, flop, sync):
     """`variants` of the driver line: the default kernel beside (a) the same with the speculative softmax always on (when the
     default is adaptive), (b) the running-max (lazy rescale) kernel -- north_star's "fp32 running max/sum" literally --
     and (c) the opt-in pre-scaled Q (NOT the reference's arithmetic: DESIGN.md 3.7; never `value`)."""
@@ -986,7 +986,7 @@ def main():
                                      "(tools/benchmark/pt_bench.py:145-174), 3 warm-ups"},
             }
         if world == 1 and not args.kernel and not args.no_variants and hasattr(cfg, "prescaled_q") and not cfg.prescaled_q:
-            line["variants"] = side_by_side(cfg, q, k, v, o, args, flop_per_step_rank, sync, device)
+            line["variants"] = side_by_side(cfg, q, k, v, o, args, flop_per_step_rank, sync)
             line["robustness"] = robustness(cfg, (hi - lo, seq, heads, d), dtype, device, args, flop_per_step_rank, sync)
         if world == 1 and not args.no_mfma_roof:
             del flush_buf

@@ -87,8 +87,8 @@ def make_opts(causal=False, allow_ragged=False, speculative=False, prescaled_q=F
     o = FaFwdOpts()
     o.struct_size = ctypes.sizeof(FaFwdOpts)
     o.causal, o.allow_ragged = int(bool(causal)), int(bool(allow_ragged))
-    o.speculative = FA_SPECULATIVE_ADAPTIVE if speculative in ("adaptive", FA_SPECULATIVE_ADAPTIVE) and speculative is not True \
-        else int(bool(speculative))
+    adaptive = speculative == "adaptive" or (not isinstance(speculative, bool) and speculative == FA_SPECULATIVE_ADAPTIVE)
+    o.speculative = FA_SPECULATIVE_ADAPTIVE if adaptive else int(bool(speculative))
     o.prescaled_q = int(bool(prescaled_q))
     if ms is not None:
         o.ms = ctypes.pointer(ms)

@@ -132,7 +132,8 @@ constexpr bool plan64_ok(const Plan64 &p, int rot_k = 0) {
 // (results wrong: timing only), 8 drops the waits and barriers (timing only), 256 512 1024 8192 16384 pick another filler
 // plan, 64 the prologue's last 16 requests at visit 0's sync point instead, 32768 the guard's check behind the visit instead of inside it, 65536 the next Q tile requested in front of the
 // epilogue's last stores, 131072 two d tiles per epilogue step, 262144 no guard, 524288 a prologue that requests only
-// what visit 0 needs (timing only).
+// what visit 0 needs (timing only).  Round 4: 32 no row sums (timing only), bits 24..27 the rotated plan's rot_k (0 = the
+// shipped FA_ROT_DEFAULT, 15 = off), bit 28 the next request pointers in gap 58, bits 29..30 the cache policy of the O stores.
 // RAG (a second MASK variant): any seq_len >= 64.  The host rounds the Q blocks up and passes
 // n_kv_blocks = 4 n_q_blocks (the ring arithmetic wants a multiple of four tiles); a tile that would reach
 // beyond the sequence is fetched as the window of its last 64 keys instead (always inside the tensor, no
