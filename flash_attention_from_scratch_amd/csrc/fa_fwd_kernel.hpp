@@ -130,15 +130,21 @@ template <int DT> struct Elem;
 // !(l < limit) is also true for NaN and +inf.
 template <int DT> __device__ constexpr float spec_limit() { return DT == 5 ? 32768.0f : 18446744073709551616.0f; }
 // The persistent kernel's guard (fa_fwd_kernel64.hpp): every four visits a wave looks at its running row sums; a row
-// whose sum has passed this threshold (bf16 2^32; fp16 2^11: N(0, 1) rows reach 2^9 .. 2^12 on their own between S = 4096 and
-// 16384, and a rescue costs ~700 instructions) is brought back to l in [1, 2) -- O and l multiplied by an exact
+// whose sum has passed this threshold (bf16 2^32; fp16 2^13) is brought back to l in [1, 2) -- O and l multiplied by an exact
 // power of two, the row's reference moved by as many binades -- so that slowly or moderately rising logits never reach the
-// limit at all; only a jump beyond the limit within four visits (256 keys) still fails the item.
+// limit at all; only a jump beyond the limit within four visits (256 keys) still fails the item.  fp16: N(0, 1) rows
+// reach l ~ 0.15 n on their own (2^11.3 at n = 16384 keys, unlucky rows 2.5x that), and a rescue costs the wave ~700
+// instructions: with round 3's 2^11 every wave took it near the end of a 16384-key item and the speculative softmax gained
+// nothing there (C3: 1228 vs 1226 lazy); 2^13 leaves the rescues to rows that need them and still two binades below the
+// limit 2^15 (a jump of more than 4x inside 256 keys fails either way: profiles/r04/fp16_guard_threshold.txt).
 // With the guard the persistent kernel checks O for inf / NaN itself whenever a row sum has passed the threshold, so
 // its limit only has to keep P = 2^x finite in fp32 and in the 16-bit type: bf16 2^120 (a single jump of ~83 nats inside
 // four visits), fp16 2^15 as above.
 template <int DT> __device__ constexpr float spec_limit64() { return DT == 5 ? 32768.0f : 1.329227995784916e36f; }
-template <int DT> __device__ constexpr float spec_guard() { return DT == 5 ? 2048.0f : 4294967296.0f; }
+#ifndef FA_FP16_GUARD
+#define FA_FP16_GUARD 8192.0f
+#endif
+template <int DT> __device__ constexpr float spec_guard() { return DT == 5 ? FA_FP16_GUARD : 4294967296.0f; }
 
 template <> struct Elem<15> {  // bf16
     typedef bf16x8 vec8;

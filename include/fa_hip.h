@@ -182,7 +182,7 @@ typedef struct fa_fwd_opts {
                                 adaptively -- see fa_speculative_mode below.  A row may rise, above the max of
                                 its LAST 64 keys (visited first), by ~44 nats (bf16) / ~10 nats (fp16) before its item is
                                 computed a second time; the persistent kernel also re-centres rising rows every four visits,
-                                so there only a JUMP of ~83 nats (bf16) / ~3-10 nats (fp16) inside 256 keys fails.  The result is
+                                so there only a JUMP of ~83 nats (bf16) / ~1.4-10 nats (fp16) inside 256 keys fails.  The result is
                                 right either way; fa_fwd_stats counts the items that ran twice.  See INTEGRATION.md 5 */
     int32_t prescaled_q;     /* 1: logits from a 16-bit Q * (log2 e / sqrt d) instead of an fp32 multiply per logit: a logit moves by
                                 ~|k| |q c| 2^-9 (bf16) / 2^-12 (fp16) -- FA-3 / Triton practice, not the reference's arithmetic;
