@@ -817,7 +817,10 @@ fa_fwd_kernel64(const KernelArgs args) {
                     // pieces(0) [Q tile 1: 8] pieces(1) pieces(2) -- and the next item's Q tiles are moved
                     // into the spare Q set here (see request_next_q).
                     if (it >= 3) {
-                        asm volatile("s_waitcnt vmcnt(" FA_VM8 ")\n\ts_barrier" ::: "memory");
+                        // (ABL bit 22, tools/tune64.hip, TIMING ONLY -- results wrong: the workgroup barrier on every second
+                        // visit only, the counted wait on all: what a ring protocol with one barrier per two visits could save)
+                        if constexpr ((ABL & (1 << 22)) != 0 && (R & 1) != 0) asm volatile("s_waitcnt vmcnt(" FA_VM8 ")" ::: "memory");
+                        else asm volatile("s_waitcnt vmcnt(" FA_VM8 ")\n\ts_barrier" ::: "memory");
                         return;
                     }
                     if constexpr (DEFER && R == 0) {

@@ -21,7 +21,7 @@ static hipEvent_t e0, e1;
 
 // ABL bit 1 << 20: the speculative-softmax build (SPEC) of the same knobs
 template <int ABL> void launch(const fa::KernelArgs &a) {
-    auto kern = fa::fa_fwd_kernel64<15, false, (ABL & 0x7f0fffff), false, ((ABL >> 20) & 1) != 0, ((ABL >> 21) & 1) != 0>;  // bit 21: the pre-scaled Q; bits 24..28: the rotated plan
+    auto kern = fa::fa_fwd_kernel64<15, false, (ABL & 0x7f4fffff), false, ((ABL >> 20) & 1) != 0, ((ABL >> 21) & 1) != 0>;  // bit 21: the pre-scaled Q; bits 24..28: the rotated plan
     static bool init = false;
     if (!init) { CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 163840)); init = true; }
     fa::KernelArgs b = a;
