@@ -501,6 +501,7 @@ int fa_fwd_launch_ex(const fa_fwd_args *args, const fa_fwd_opts *opts, void *str
     uint32_t *redo_flag = nullptr;
     uint32_t redo_seq = 0;
     bool record_probe = false;
+    std::unique_lock<std::mutex> probe_lock;
     if (o.speculative == FA_SPECULATIVE_ADAPTIVE && dev->adaptive.flag_host) {
         // (the speculative variant exists: validated above.  Its non-speculative sibling serves a demoted launch)
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
@@ -508,7 +509,7 @@ int fa_fwd_launch_ex(const fa_fwd_args *args, const fa_fwd_opts *opts, void *str
         AdaptiveState &ad = dev->adaptive;
         bool demote = false;
         if (cap == hipStreamCaptureStatusNone) {
-            std::lock_guard<std::mutex> lock(ad.mu);
+            probe_lock = std::unique_lock<std::mutex>(ad.mu);
             int probe = AdaptivePolicy::PROBE_NA;
             if (ad.p.mode == AdaptivePolicy::PROBING) {   // has the probe finished?  (never a wait)
                 const hipError_t q = hipEventQuery(ad.probe_done);
@@ -522,6 +523,9 @@ int fa_fwd_launch_ex(const fa_fwd_args *args, const fa_fwd_opts *opts, void *str
             record_probe = run == AdaptivePolicy::RUN_PROBE;
             redo_flag = ad.flag_dev;
             redo_seq = ad.p.seq;
+            // (a probe keeps the lock until its event is recorded: another thread's launch must not query an event that
+            // has not been recorded yet -- it would read as complete)
+            if (!record_probe) probe_lock.unlock();
         }
         if (demote) {
             Want w2 = w;
@@ -534,10 +538,9 @@ int fa_fwd_launch_ex(const fa_fwd_args *args, const fa_fwd_opts *opts, void *str
         }
     }
     rc = launch_maybe_timed(args, e, dev, (hipStream_t)stream, o.causal != 0, o.ms, o.stats, redo_flag, redo_seq);
-    if (record_probe) {
-        if (hipEventRecord(dev->adaptive.probe_done, (hipStream_t)stream) != hipSuccess) {
+    if (record_probe) {   // (probe_lock is still held)
+        if (rc != FA_OK || hipEventRecord(dev->adaptive.probe_done, (hipStream_t)stream) != hipSuccess) {
             (void)hipGetLastError();
-            std::lock_guard<std::mutex> lock(dev->adaptive.mu);
             dev->adaptive.p.mode = AdaptivePolicy::NORMAL;  // (no event to wait for; a failing probe reports like any launch)
         }
     }
