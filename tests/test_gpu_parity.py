@@ -792,6 +792,57 @@ def test_adaptive_speculative_mode_demotes_after_a_reported_redo():
         _capi.adaptive_reset(dev)
 
 
+def test_adaptive_mode_from_two_threads_on_two_streams():
+    """The adaptive mode's per-device state is shared by every caller on the device: two host threads, each on its own
+    stream -- one feeding benign data, one data that makes the speculative pass fail -- launch concurrently.  Every output is
+    inside the tolerance (whichever variant served it), the counters add up, nothing deadlocks (a probe holds the policy
+    lock across its launch and event record)."""
+    import threading
+    from flash_attention_from_scratch_amd import _capi
+    dev = torch.cuda.current_device()
+    dtype = torch.bfloat16
+    cfg = kc.best_config(kc.DType.BF16, 1024)
+    gen = torch.Generator(device=DEV).manual_seed(123)
+    q, k, v = (torch.randn((2, 1024, 8, 128), dtype=dtype, device=DEV, generator=gen) for _ in range(3))
+    ks, qs = k.clone(), q.clone()
+    u = _sign_vector(5).to(dtype)
+    ks[1, 3, 2] = 30.0 * u
+    qs[1, 600:604, 2] = 30.0 * u
+    refs = {"benign": ut.py_flash_attention(q, k, v, upcast=True).float(), "spiky": ut.py_flash_attention(qs, ks, v, upcast=True).float()}
+    torch.cuda.synchronize()
+    _capi.adaptive_reset(dev)
+    before = _capi.adaptive_state(dev)["launches"]
+    outs, errors = {"benign": [], "spiky": []}, []
+    n_each = 60
+
+    def worker(name, args):
+        try:
+            st = torch.cuda.Stream(device=DEV)
+            with torch.cuda.stream(st):
+                for i in range(n_each):
+                    outs[name].append(flash_attention.forward(cfg, *args))
+                    if i % 16 == 15:
+                        st.synchronize()      # (lets reports land between batches, as a real caller's host work would)
+            st.synchronize()
+        except Exception as exc:  # noqa: BLE001
+            errors.append((name, repr(exc)))
+    threads = [threading.Thread(target=worker, args=("benign", (q, k, v))), threading.Thread(target=worker, args=("spiky", (qs, ks, v)))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not any(t.is_alive() for t in threads) and not errors, errors
+    torch.cuda.synchronize()
+    after = _capi.adaptive_state(dev)
+    assert after["launches"] == before + 2 * n_each and after["reports"] >= 1 and 0 < after["demoted"] <= 2 * n_each
+    for name, ref in refs.items():
+        tol = TOL[dtype] * (1 + ref.abs())
+        assert len(outs[name]) == n_each
+        for o in outs[name]:
+            assert ((o.float() - ref).abs() <= tol).all(), name
+    _capi.adaptive_reset(dev)
+
+
 @pytest.mark.parametrize("S", [1000, 2500])
 def test_speculative_softmax_ragged_second_pass(S):
     """The ragged form under speculative_softmax: the rounded-up tiles beyond the sequence are masked whole,
