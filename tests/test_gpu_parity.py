@@ -792,6 +792,23 @@ def test_adaptive_speculative_mode_demotes_after_a_reported_redo():
         _capi.adaptive_reset(dev)
 
 
+def test_speculative_request_is_dropped_where_the_masked_form_has_no_speculative_build():
+    """best_config(bf16, seq_len not a multiple of 256) is the pipelined (128, 64, 4) kernel with the speculative
+    softmax; its MASKED forms keep the running max (no speculative build), and kc.softmax_mode(cfg, masked=True) says
+    'eager'.  forward_ex(cfg, ..., causal=True) used to raise; it now runs the masked variant the mirror names."""
+    for name, dtype in ((kc.DType.BF16, torch.bfloat16), (kc.DType.FP16, torch.float16)):
+        cfg = kc.best_config(name, 1000)
+        assert (cfg.B_r, cfg.n_warps) == (128, 4) and cfg.speculative_softmax and kc.softmax_mode(cfg, masked=True) != "speculative"
+        gen = torch.Generator(device=DEV).manual_seed(9)
+        q, k, v = (torch.randn((2, 1024, 4, 128), dtype=dtype, device=DEV, generator=gen) for _ in range(3))
+        out = flash_attention.forward_ex(cfg, q, k, v, causal=True)
+        plain = replace(cfg, speculative_softmax=False, adaptive_softmax=False)
+        assert torch.equal(out, flash_attention.forward_ex(plain, q, k, v, causal=True))
+        stats = torch.zeros(2, dtype=torch.int32, device=DEV)
+        flash_attention_kernels.forward(cfg, q, k, v, None, causal=True, stats=stats)
+        assert stats[1].item() == 0 and stats[0].item() > 0
+
+
 def test_adaptive_mode_from_two_threads_on_two_streams():
     """The adaptive mode's per-device state is shared by every caller on the device: two host threads, each on its own
     stream -- one feeding benign data, one data that makes the speculative pass fail -- launch concurrently.  Every output is
