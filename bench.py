@@ -161,6 +161,7 @@ def timed_steps(step, steps, warmup, sync, barrier):
     return time.perf_counter() - t0
 
 
+HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: HBM3E peak (6.3 TB/s achievable)
 SUSTAINED_BELOW_S = 0.1     # a timed region shorter than this also gets the sub-measurement below
 SUSTAINED_TARGET_S = 0.25
 
@@ -1010,6 +1011,11 @@ def main():
             else:
                 line["roofline"]["traffic"] = traffic
                 line["roofline"]["traffic_source"] = how
+                # achieved HBM rate against the chip's peak (north star: "achieved HBM GB/s against the chip's peaks"): the
+                # measured bytes of a launch over the kernel's average duration in the timed region
+                line["roofline"]["hbm_gb_per_s"] = traffic / (kernel_ms * 1e-3) / 1e9
+                line["roofline"]["hbm_peak_gb_per_s"] = HBM_PEAK_GBPS
+                line["roofline"]["hbm_frac_of_peak"] = traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS
                 pc = measure_pipe_counters(tail)
                 line["roofline"]["pipe_counters"] = pc
                 if isinstance(pc, dict) and "wave_cycles_per_mfma" in pc:
