@@ -100,7 +100,10 @@ int main(int argc, char **argv) {
     }
     CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
 #define X(abl, name) add<abl>(name);
-#include "tune64_list.inc"
+#ifndef TUNE64_LIST
+#define TUNE64_LIST "tune64_list.inc"
+#endif
+#include TUNE64_LIST
 #undef X
     const int seqs[4] = {512, 1024, 4096, 16384};
     for (int pass = 0; pass < 4; ++pass) {
