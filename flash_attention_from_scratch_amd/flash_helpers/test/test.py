@@ -1,4 +1,4 @@
-"""unittest entry of the flash_helpers test suite -- `python flash_helpers/test/test.py` or
+"""unittest entry of the flash_helpers test suite -- `python py/flash_helpers/test/test.py` or
 `python -m flash_helpers.test.test` -- the counterpart of the reference's
 py/flash_helpers/test/test.py:17-99: one test per config of get_kernels_to_build(), on the
 reference's fixture (seq_len 2048, batch BATCH_SIZE_FOR_SEQ_LEN[2048], BENCHMARK_N_HEADS heads,

@@ -1,4 +1,4 @@
-"""Drop-in alias of the reference's test entry: `python flash_helpers/test/test.py`."""
+"""Drop-in alias of the reference's test entry: `python py/flash_helpers/test/test.py` (or `python -m flash_helpers.test.test`)."""
 import os
 import sys
 
