@@ -130,8 +130,8 @@ constexpr bool plan64_ok(const Plan64 &p, int rot_k = 0) {
 // ABL: 0 in the product.  tools/tune64.hip instantiates the kernel with experiment / timing-only bits so that a
 // measured claim in profiles/ can be re-run against the shipped code: 1 2 4 16 2048 4096 delete one part of the stream
 // (results wrong: timing only), 8 drops the waits and barriers (timing only), 256 512 1024 8192 16384 pick another filler
-// plan, 64 the prologue's last 16 requests at visit 0's sync point instead, 32768 the guard's check behind the visit instead of inside it, 65536 the next Q tile requested in front of the
-// epilogue's last stores, 131072 two d tiles per epilogue step, 262144 no guard, 524288 a prologue that requests only
+// plan, 64 the prologue's last 16 requests at visit 0's sync point instead, 32768 the guard's check behind the visit instead of inside it, 128 the round-4 item loop (no hot region: every
+// visit carries the seam handling), 131072 two d tiles per epilogue step, 262144 no guard, 524288 a prologue that requests only
 // what visit 0 needs (timing only).  Round 4: 32 no row sums (timing only), bits 24..27 the rotated plan's rot_k (0 = the
 // shipped FA_ROT_DEFAULT, 15 = off), bit 28 the next request pointers in gap 58, bits 29..30 the cache policy of the O stores.
 // RAG (a second MASK variant): any seq_len >= 64.  The host rounds the Q blocks up and passes
@@ -218,12 +218,16 @@ fa_fwd_kernel64(const KernelArgs args) {
     {
         unsigned long long t_;
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_));
-        jit_state = __builtin_amdgcn_readfirstlane((unsigned)t_ * 2654435761u + (unsigned)wave * 40503u + blockIdx.x * 9176u);
+        const unsigned seed_ = __builtin_amdgcn_readfirstlane((unsigned)t_ * 2654435761u + (unsigned)wave * 40503u + blockIdx.x * 9176u);
+        asm volatile("v_mov_b32 %0, %1" : "=v"(jit_state) : "s"(seed_));
     }
     auto jitter = [&](auto rare_tag) {
         constexpr bool RARE = decltype(rare_tag)::value;   // true: sleep one time in eight only (the 16 operand waits of a visit)
         unsigned n_, r_;
-        unsigned &js_ = jit_state;  // (named here: an asm operand alone does not make the generic lambda capture it)
+        // the generator's state lives in a VECTOR register between draws (every lane the same value): as one more scalar
+        // carried through twelve visit bodies hipcc ran out of ways to keep it (it copied it into a vector register and
+        // back, which is not an instruction: "illegal VGPR to SGPR copy")
+        unsigned js_ = __builtin_amdgcn_readfirstlane(jit_state);
         asm volatile("s_mul_i32 %0, %0, 0x19660d\n\t"
                      "s_add_u32 %0, %0, 0x3c6ef35f\n\t"
                      "s_lshr_b32 %1, %0, 29\n\t"        // 0 .. 7 sleeps of 64 cycles
@@ -240,6 +244,7 @@ fa_fwd_kernel64(const KernelArgs args) {
                      "s_branch .Ljit%=\n"
                      ".Ljit_done%=:"
                      : "+s"(js_), "=&s"(n_), "=&s"(r_) : "s"(RARE ? 1u : 0u) : "scc");
+        asm volatile("v_mov_b32 %0, %1" : "=v"(jit_state) : "s"(js_));
     };
 #endif
 #if defined(FA_TRACE) && FA_TRACE == 3
@@ -417,15 +422,6 @@ fa_fwd_kernel64(const KernelArgs args) {
         for (int qt = 0; qt < QT; ++qt) m[qt] = -__builtin_inff();
         // O = 0 by eight MFMAs on a zero operand (16 registers apiece; 128 v_accvgpr_write otherwise)
         auto zero_o = [&]() {
-            if constexpr (MASK) {  // (the causal variant has no four registers to spare at the seam)
-#pragma unroll
-                for (int qt = 0; qt < QT; ++qt)
-#pragma unroll
-                    for (int t = 0; t < DTILES; ++t)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) O[qt][t][r] = 0.0f;
-                return;
-            }
             typename E::vec8 zz = __builtin_bit_cast(typename E::vec8, u32x4{0u, 0u, 0u, 0u});
             asm volatile("s_nop 3" : "+v"(zz));  // VALU write -> MFMA operand read
 #pragma unroll
@@ -566,10 +562,22 @@ fa_fwd_kernel64(const KernelArgs args) {
             auto tile_g = [&](const uint16_t *cur, const uint16_t *nxt, int j) {
                 return j < nkc ? tile_at(cur, nkc - 1 - j) : tile_at(nxt, nkn - 1 - (j - nkc));
             };
+            auto lane_now = [&]() {  // volatile: anything derived from threadIdx would be kept live across the walk
+                int l_;
+                asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l_));
+                return l_;
+            };
             // MASK: logits above the causal diagonal become -inf.  `tile` counts from the start of the
             // sequence, `qb_rows` is the Q block whose rows the S tile belongs to.  A wave's 64 rows meet
             // the diagonal in exactly one 64-key tile; tiles beyond it are masked whole.
-            auto mask_tile = [&](auto &S, int tile, int qb_rows) {
+            // only_nt: -1, or the one 32-key half of the tile to mask (a visit masks the halves in two consecutive gaps: each
+            // half's sixteen-register tuples are rebuilt while the old ones are still live, and all four at once cost the
+            // masked speculative build its last registers)
+            auto mask_tile = [&](auto &S, int tile, int qb_rows, int only_nt = -1) {
+                // (lane indices from a volatile v_mbcnt, as in the seam code: derived from threadIdx at kernel entry, the
+                // per-register compare constants of all four S tiles were kept in registers across the whole walk)
+                const int l_ = lane_now();
+                const int r31 = l_ & 31, hi = l_ >> 5;
                 if constexpr (RAG) {
                     const int r0 = 64 * tile < args.seq_len - 64 ? 64 * tile : args.seq_len - 64;  // first key of the window
                     const int delta = 64 * tile - r0;  // keys of the window in front of the tile's own first key
@@ -578,7 +586,7 @@ fa_fwd_kernel64(const KernelArgs args) {
 #pragma unroll
                         for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
-                            for (int nt = 0; nt < NT; ++nt)
+                            for (int nt = (only_nt < 0 ? 0 : only_nt); nt < (only_nt < 0 ? NT : only_nt + 1); ++nt)
 #pragma unroll
                                 for (int r = 0; r < 16; ++r)
                                     S[qt][nt][r] = (32 * nt + (r & 3) + 8 * (r >> 2) < lim) ? -__builtin_inff() : S[qt][nt][r];
@@ -589,7 +597,7 @@ fa_fwd_kernel64(const KernelArgs args) {
                         for (int qt = 0; qt < 2; ++qt) {
                             const int lim = row_min + 32 * qt + r31 - r0 - 4 * hi;  // key-in-window > lim: above the diagonal
 #pragma unroll
-                            for (int nt = 0; nt < NT; ++nt)
+                            for (int nt = (only_nt < 0 ? 0 : only_nt); nt < (only_nt < 0 ? NT : only_nt + 1); ++nt)
 #pragma unroll
                                 for (int r = 0; r < 16; ++r)
                                     S[qt][nt][r] = (32 * nt + (r & 3) + 8 * (r >> 2) > lim) ? -__builtin_inff() : S[qt][nt][r];
@@ -601,7 +609,7 @@ fa_fwd_kernel64(const KernelArgs args) {
 #pragma unroll
                         for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
-                            for (int nt = 0; nt < NT; ++nt)
+                            for (int nt = (only_nt < 0 ? 0 : only_nt); nt < (only_nt < 0 ? NT : only_nt + 1); ++nt)
 #pragma unroll
                                 for (int r = 0; r < 16; ++r) {
                                     const int key = 32 * nt + (r & 3) + 8 * (r >> 2) + 4 * hi, row = 32 * qt + r31;
@@ -646,7 +654,6 @@ fa_fwd_kernel64(const KernelArgs args) {
             // they are issued, and 16 pieces cost more at a sync point than under S(0).  Not adopted.
             constexpr bool DEFER = (ABL & 64) != 0 && !MASK;
             int deferred = 0;  // 1: those pieces are still to be requested (first visit of the walk's first item only)
-            int q_st_behind = 0;  // QEARLY: row stores issued BEHIND the next Q tile 0's request (8 after a seam, else 0)
             // the guard's common path (see guard() below) rides in the last gaps of every fourth visit, where the vector
             // stream has room (all 32 softmax units have issued by gap 53): two adds, a max, a compare.  ABL & 32768
             // (tools/tune64.hip): behind the visit instead, as first built.
@@ -664,11 +671,6 @@ fa_fwd_kernel64(const KernelArgs args) {
             // which is read behind the barrier of visit 2 -- all on the slow path that the sync point of
             // an item's first three visits takes anyway, so the steady state carries none of it.
             const unsigned q_stage = smem_base + 2 * TR::kStages * TILE + wave * 8192;
-            auto lane_now = [&]() {  // volatile: anything derived from threadIdx would be kept live across the walk
-                int l_;
-                asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l_));
-                return l_;
-            };
             auto request_q = [&](const uint16_t *Qh, int qblk, int qt, unsigned stage) {  // rows 32 qt .. 32 qt + 31 of this wave's rows
                 const int l_ = lane_now();
                 // piece i: rows 4i .. 4i+3; this lane: row 4i + l/16, chunk (l % 16) ^ (row & 15)
@@ -789,8 +791,18 @@ fa_fwd_kernel64(const KernelArgs args) {
                                 if constexpr (ROT_K > 0)
                     static_for<0, ROT_K>([&](auto i) { exp_unit_on(S0, decltype(i)::value, IntTag<(decltype(i)::value < 2 ? SET_EARLY : SUM_EARLY)>{}); });
             };
-            auto visit = [&](int it, auto &S_cur, auto &S_nxt, auto r_tag) {
+            // hot_tag (round 5): what a visit does for an item's two ENDS is decided at compile time.  Past the item's first
+            // four visits (>= 1): no slow path at the sync point (the first three visits: Q tiles, stores in flight) and no mask
+            // (a causal item's diagonal tiles and a ragged sequence's last tiles are the FIRST three it forms); before its last
+            // eight as well (2): no Q swap (the last visit) and no change of direction in the request pointers (K of the next
+            // item from the fifth visit before the end, V from the fourth).  The item loop below runs [first group: 0 | middle
+            // groups: 2 | last two groups: 1].  With `it` a run-time value in every visit the steady state carried a
+            // compare-and-branch in its sync point and six scalar selects in its pointer chain, and hipcc cut every visit into
+            // blocks at them.
+            auto visit = [&](int it, auto &S_cur, auto &S_nxt, auto r_tag, auto hot_tag) {
                 constexpr int R = decltype(r_tag)::value;  // it & 3
+                // 0: general; 1: not one of the item's first four (no slow sync path, no mask); 2: nor one of its last eight
+                constexpr bool HOTB = decltype(hot_tag)::value >= 1, HOT = decltype(hot_tag)::value >= 2;
 #if defined(FA_TRACE) && FA_TRACE < 4
                 unsigned long long ts[20];
                 asm volatile("s_memtime %0" : "=s"(ts[0]));
@@ -816,7 +828,7 @@ fa_fwd_kernel64(const KernelArgs args) {
                     // order: [pieces(last visit of the previous item) | 16 epilogue stores] [Q tile 0: 8]
                     // pieces(0) [Q tile 1: 8] pieces(1) pieces(2) -- and the next item's Q tiles are moved
                     // into the spare Q set here (see request_next_q).
-                    if (it >= 3) {
+                    if (HOTB || it >= 3) {
                         // (ABL bit 22, tools/tune64.hip, TIMING ONLY -- results wrong: the workgroup barrier on every second
                         // visit only, the counted wait on all: what a ring protocol with one barrier per two visits could save)
                         if constexpr ((ABL & (1 << 22)) != 0 && (R & 1) != 0) asm volatile("s_waitcnt vmcnt(" FA_VM8 ")" ::: "memory");
@@ -841,10 +853,8 @@ fa_fwd_kernel64(const KernelArgs args) {
                     else asm volatile("s_waitcnt vmcnt(" FA_VM32 ")\n\ts_barrier" ::: "memory");
                     if constexpr (R == 1 || R == 2) {
                         if (it == R && has_next) {
-                            // Q tile R-1 landed (only pieces(R-1) are younger -- and, QEARLY, the 8 row stores issued behind tile 0's request)
-                            if (R == 1 && q_st_behind) asm volatile("s_waitcnt vmcnt(" FA_VM16 ")" ::: "memory");
-                            else asm volatile("s_waitcnt vmcnt(" FA_VM8 ")" ::: "memory");
-                            if (R == 1) q_st_behind = 0;
+                            // Q tile R-1 landed (only pieces(R-1) are younger)
+                            asm volatile("s_waitcnt vmcnt(" FA_VM8 ")" ::: "memory");
                             read_next_q(Qr2[R - 1]);
                             if constexpr (R == 1) {
                                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // ... and read: its image may be overwritten
@@ -853,7 +863,7 @@ fa_fwd_kernel64(const KernelArgs args) {
                         }
                     }
                 };
-                if constexpr (R == 3) {
+                if constexpr (R == 3 && !HOT) {
                     // last visit of an item forms the next item's S(0): swap the next item's Q in
                     if (it + 1 == nkc && has_next) {
                         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the LDS reads into the spare set (visits 1, 2)
@@ -945,11 +955,14 @@ fa_fwd_kernel64(const KernelArgs args) {
                         if constexpr (RAG) {  // (a window per tile: no pointer chain)
                             kq = tile_g(Kc, Kn, it + 5);
                             vq = tile_g(Vc, Vn, it + 4);
+                        } else if constexpr (HOT) {  // (it + 5 < n_kv: the next requests are this item's next tiles down)
+                            kq -= tile_stride;
+                            vq -= tile_stride;
                         } else {
                             kq = (it + 5 == nkc) ? Kn + (int64_t)(nkn - 1) * tile_stride : kq - tile_stride;
                             vq = (it + 4 == nkc) ? Vn + (int64_t)(nkn - 1) * tile_stride : vq - tile_stride;
                         }
-                        if constexpr (R == 1) seam_st = 0;
+                        if constexpr (R == 1 && !HOTB) seam_st = 0;
                     }
                 };
                 auto tail_step = [&](int k) {  // plan step: 1..8 one unit each; 10..14 the masked plan's merged steps
@@ -1010,11 +1023,17 @@ fa_fwd_kernel64(const KernelArgs args) {
                     }
                     if constexpr (g == 0) asm volatile("" ::"v"(Pw[1][3]));  // ... of the previous visit's last one
                     if constexpr (plan.barrier[g] != 0) sync_point();
-                    if constexpr (MASK && g == 34) {
-                        // S(it+1) is complete (last written at gap 31): causal mask, before its row max.
-                        // The last visit's S tile is the NEXT item's S(0).
-                        if (it + 1 < nkc) mask_tile(S_nxt, nkc - 2 - it, qb_c);
-                        else mask_tile(S_nxt, nkn - 1, qb_n);
+                    if constexpr (MASK && (g == 34 || g == 35) && (!HOTB || (R == 3 && !HOT))) {
+                        // S(it+1) is complete (last written at gap 31): causal mask, before its row max (whose units start at
+                        // gap 36 in the masked plan), one 32-key half per gap.  The tiles a wave's rows meet the diagonal in,
+                        // and a ragged sequence's last tiles, are S(0) .. S(3) of an item: S(1) .. S(3) are formed by its
+                        // first three visits, S(0) by the LAST visit of the item before it (or the prologue) -- no other
+                        // visit carries mask code.
+                        if (it + 1 < nkc) {
+                            if constexpr (!HOTB) mask_tile(S_nxt, nkc - 2 - it, qb_c, g - 34);
+                        } else {
+                            mask_tile(S_nxt, nkn - 1, qb_n, g - 34);
+                        }
                     }
                     if constexpr (g < 63 && plan.dma[g + 1] >= 0 && !(ABL & 16)) {
                         // M0 (LDS destination) of the DMA piece of the NEXT gap: the write needs one instruction
@@ -1058,7 +1077,7 @@ fa_fwd_kernel64(const KernelArgs args) {
                     __builtin_amdgcn_sched_barrier(0);
                 };
                 static_for<0, 64>([&](auto gap_tag) { gap_body(gap_tag); });
-                if constexpr (FAST && MASK) {
+                if constexpr (FAST && MASK && !HOTB) {
                     // masked forms, speculative: a wave's reference is the row max of the FIRST tile it visits that is
                     // not masked whole -- causal: its diagonal tile 4 qb + wave; ragged: the last tile that holds keys
                     // of the sequence (the rounded-up tiles beyond it are masked whole); both: the earlier of the two.
@@ -1261,11 +1280,7 @@ fa_fwd_kernel64(const KernelArgs args) {
             // area one 32-row Q tile at a time so that the global stores are whole 256-B rows (16 B per
             // lane, 4 rows per wave-instruction).  Wave-private: no barrier.  The 16-B chunk index is
             // XORed with (row & 15) so the 8-B writes and the 16-B reads are bank-conflict free.
-            // ABL & 65536 (experiment, tools/tune64.hip): the seam rotates to the next item FIRST and requests the item-after-
-            // next's Q tile 0 from inside the epilogue, in front of the last 8 row stores (the staging area is free as soon
-            // as the last tile's rows are back in registers): the request no longer queues behind all 16 stores.
-            constexpr bool QEARLY = (ABL & 65536) != 0 && !RAG;
-            auto store_item = [&](uint16_t *Oc, const int qb_c, const int ord, auto &&before_last_stores) {
+            auto store_item = [&](uint16_t *Oc, const int qb_c, const int ord) {
                 FA_JIT(false);
                 asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // last P.V -> VALU reads of O
                 char *stage_o = smem + 2 * TR::kStages * TILE + wave * (32 * ROWB);
@@ -1320,14 +1335,6 @@ fa_fwd_kernel64(const KernelArgs args) {
 #pragma unroll
                     for (int i = 0; i < 32 / RPP; ++i)
                         v[i] = *(const s16x8 *)(stage_o + RPP * i * ROWB + (rd0 ^ (((RPP * i) & 15u) << 4)));
-                    if constexpr (QEARLY) {
-                        if (qt == 1) {
-#pragma unroll
-                            for (int i = 0; i < 32 / RPP; ++i) asm volatile("" : "+v"(v[i]));  // the reads are issued ...
-                            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 // ... and back: the staging area is free
-                            before_last_stores();
-                        }
-                    }
 #pragma unroll
                     for (int i = 0; i < 32 / RPP; ++i) {
                         // non-temporal: O is written once and not read again by this kernel (+1.3...2.8 % at
@@ -1356,14 +1363,42 @@ fa_fwd_kernel64(const KernelArgs args) {
                     }
                 }
             };
-            // seq_len is a multiple of B_r = 256, so n_kv = seq_len / 64 is a multiple of 4 = ring depth
+            // seq_len is a multiple of B_r = 256, so n_kv = seq_len / 64 is a multiple of 4 = ring depth.
+            // The item loop, in groups of four visits (one per ring stage): an item's first group and its last two run the
+            // GENERAL visits (whatever an item's ends need, decided at run time), the groups in between the HOT ones (see
+            // visit()).  Straight-line by construction -- [first group] [hot loop] [loop over the last two groups] [epilogue
+            // + seam] -- because alternative visit bodies that join behind a branch (or a loop both reach) made hipcc
+            // shuffle the accumulator tiles between them and spill.  ABL & 128 (tools/tune64.hip): no hot region, as round 4 ran.
+            constexpr bool HOT_LOOP = !(ABL & 128);
             for (;;) {
-                for (int it = 0; it < nkc; it += 4) {
-                    if (it) guard(Sa, false);
-                    visit(it, Sa, Sb, IntTag<0>{});
-                    visit(it + 1, Sb, Sa, IntTag<1>{});
-                    visit(it + 2, Sa, Sb, IntTag<2>{});
-                    visit(it + 3, Sb, Sa, IntTag<3>{});
+                int it = 0;
+                if constexpr (HOT_LOOP) {
+                    visit(0, Sa, Sb, IntTag<0>{}, IntTag<0>{});
+                    visit(1, Sb, Sa, IntTag<1>{}, IntTag<0>{});
+                    visit(2, Sa, Sb, IntTag<2>{}, IntTag<0>{});
+                    visit(3, Sb, Sa, IntTag<3>{}, IntTag<0>{});
+                    for (it = 4; it + 12 <= nkc; it += 4) {
+                        guard(Sa, false);
+                        visit(it, Sa, Sb, IntTag<0>{}, IntTag<2>{});
+                        visit(it + 1, Sb, Sa, IntTag<1>{}, IntTag<2>{});
+                        visit(it + 2, Sa, Sb, IntTag<2>{}, IntTag<2>{});
+                        visit(it + 3, Sb, Sa, IntTag<3>{}, IntTag<2>{});
+                    }
+                    for (; it < nkc; it += 4) {  // the last two groups (or the last one: n_kv = 8)
+                        guard(Sa, false);
+                        visit(it, Sa, Sb, IntTag<0>{}, IntTag<1>{});
+                        visit(it + 1, Sb, Sa, IntTag<1>{}, IntTag<1>{});
+                        visit(it + 2, Sa, Sb, IntTag<2>{}, IntTag<1>{});
+                        visit(it + 3, Sb, Sa, IntTag<3>{}, IntTag<1>{});
+                    }
+                } else {
+                    for (; it < nkc; it += 4) {
+                        if (it) guard(Sa, false);
+                        visit(it, Sa, Sb, IntTag<0>{}, IntTag<0>{});
+                        visit(it + 1, Sb, Sa, IntTag<1>{}, IntTag<0>{});
+                        visit(it + 2, Sa, Sb, IntTag<2>{}, IntTag<0>{});
+                        visit(it + 3, Sb, Sa, IntTag<3>{}, IntTag<0>{});
+                    }
                 }
 #if defined(FA_TRACE) && FA_TRACE < 4
                 unsigned long long te0, te1, te2;
@@ -1374,35 +1409,15 @@ fa_fwd_kernel64(const KernelArgs args) {
                 if (tl_seam) tl_at(50);  // last visit done
 #endif
                 guard(Sa, true);
-                bool q_requested = false;
                 const int qb_st = qb_c;  // the item being stored
                 (void)qb_st;
-                if constexpr (QEARLY) {
-                    // rotate to the next item first; the epilogue below still stores the item that just ended
-                    uint16_t *O_st = Oc;
-                    const int qb_done = qb_c, ord_done = ord;
-                    const bool had_next = has_next;
-                    if (had_next) {
-                        ord = ord_n;
-                        item = (int)blockIdx.x + ord * (int)gridDim.x;
-                        Kc = Kn; Vc = Vn; Oc = On; qb_c = qb_n;
-                        nkc = nkn;
-                        set_next();
-                    }
-                    store_item(O_st, qb_done, ord_done, [&]() {
-                        if (had_next && has_next) { request_next_q(0); q_requested = true; q_st_behind = 8; }
-                    });
-                    if (!had_next) break;
-                } else {
-                    store_item(Oc, qb_c, ord, []() {});
-                }
+                store_item(Oc, qb_c, ord);
 #if defined(FA_TRACE) && FA_TRACE >= 4
                 if (tl_seam) tl_at(51);  // epilogue issued
 #endif
 #if defined(FA_TRACE) && FA_TRACE < 4
                 asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(te1)::"memory");
 #endif
-                if constexpr (!QEARLY) {
                 if (!has_next) break;
                 // ---- seam: the last visit left the next item's S(0) in Sa and its row max in mraw; its
                 // first tiles are landed or in flight, its first operands sit in the ring
@@ -1411,13 +1426,12 @@ fa_fwd_kernel64(const KernelArgs args) {
                 Kc = Kn; Vc = Vn; Oc = On; qb_c = qb_n;
                 nkc = nkn;
                 set_next();
-                }
 #if defined(FA_TRACE) && FA_TRACE >= 4
                 if (tl_seam) tl_at(53);  // coordinates of the item after
 #endif
                 kq = tile_g(Kc, Kn, 4);  // visit 0 requests K(4), V(3) (for n_kv == 4 that is already the item after)
                 vq = tile_g(Vc, Vn, 3);
-                if (has_next && !q_requested) request_next_q(0);  // (the staging area is free again: store_item's reads have retired)
+                if (has_next) request_next_q(0);  // (the staging area is free again: store_item's reads have retired)
                 seam_st = 16;
                 if constexpr (RAG) {  // stores the epilogue above issued: one per four rows inside the sequence (16 per 64 rows)
                     const int rows_in = args.seq_len - (qb_st * TR::kBr + wave * TR::kRowsPerWave);

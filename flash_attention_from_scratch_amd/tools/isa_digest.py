@@ -4,13 +4,14 @@
 
 The visit's schedule lives at the edge of hipcc's register allocator: the MFMAs, DMA pieces and stores
 are inline asm the compiler neither pads nor looks into, and a compiler upgrade re-rolls everything around them.  The
-committed digest (profiles/r04/toolchain.json) is what the measured numbers of the round belong to; the CPU test
+committed digest (profiles/r05/toolchain.json) is what the measured numbers of the round belong to; the CPU test
 tests/test_tools_cpu.py::test_visit_histogram_matches_the_committed_digest fails when a rebuild no longer produces it.
 
-    isa_digest.py [--write profiles/r04/toolchain.json]
+    isa_digest.py [--write profiles/r05/toolchain.json]
 
-A "visit" = a basic block of the kernel with >= 56 MFMAs (the 4x-unrolled visit loop has four of them per walk; the
-barrier two MFMAs into a visit may split off a 3-MFMA head, hence 61 or 64).  Per visit the plan of DESIGN.md 3.5/3.6
+A "visit" = a basic block of the kernel with >= 56 MFMAs (the barrier two MFMAs into a visit may split off a 3-MFMA
+head, hence 61 or 64; since round 5 a walk is [first group | hot loop | last two groups] = twelve visit bodies, and hipcc
+merges the branch-free hot ones into blocks of several visits: 256 MFMAs for the four of the hot loop).  Per visit the plan of DESIGN.md 3.5/3.6
 deals 64 MFMAs, 64 v_exp_f32, 48 LDS operand reads (16 ds_read_b128 + 32 ds_read_b64_tr_b16) and 8 LDS-DMA pieces."""
 import argparse
 import collections

@@ -19,18 +19,33 @@ struct Variant { const char *name; int abl; void (*launch)(const fa::KernelArgs 
 static std::vector<Variant> variants;
 static hipEvent_t e0, e1;
 
-// ABL bit 1 << 20: the speculative-softmax build (SPEC) of the same knobs
+// ABL bit 1 << 20: the speculative-softmax build (SPEC) of the same knobs; bit 23: the masked (causal-capable) build, run with
+// nothing masked (causal = 0): what the masked form costs a caller that masks nothing
 template <int ABL> void launch(const fa::KernelArgs &a) {
-    auto kern = fa::fa_fwd_kernel64<15, false, (ABL & 0x7f4fffff), false, ((ABL >> 20) & 1) != 0, ((ABL >> 21) & 1) != 0>;  // bit 21: the pre-scaled Q; bits 24..28: the rotated plan
+    auto kern = fa::fa_fwd_kernel64<15, ((ABL >> 23) & 1) != 0, (ABL & 0x7f4fffff), false, ((ABL >> 20) & 1) != 0, ((ABL >> 21) & 1) != 0>;  // bit 21: the pre-scaled Q; bits 24..28: the rotated plan
     static bool init = false;
     if (!init) { CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 163840)); init = true; }
     fa::KernelArgs b = a;
     if (ABL & 2048) b.q = q_scaled;
     hipLaunchKernelGGL(kern, dim3(b.n_bh * b.n_q_blocks < 256 ? b.n_bh * b.n_q_blocks : 256), dim3(256), 163840, 0, b);
 }
+// the previous round's kernel (tools/tune64_prev.hip), when the build links it: list entries -1 (speculative), -2 (lazy)
+#ifdef TUNE64_PREV
+namespace prev { void launch(bool spec, const void *q, const void *k, const void *v, void *o, long long bs, long long ss, long long hs,
+                             int seq_len, int n_heads, int n_bh, int n_q_blocks, int n_kv_blocks); }
+template <bool SPEC> void launch_prev(const fa::KernelArgs &a) {
+    prev::launch(SPEC, a.q, a.k, a.v, a.o, a.batch_stride, a.seq_stride, a.head_stride, a.seq_len, a.n_heads, a.n_bh, a.n_q_blocks, a.n_kv_blocks);
+}
+#endif
 template <int ABL> void add(const char *name) {
     if (!only_list.empty() && std::find(only_list.begin(), only_list.end(), ABL) == only_list.end()) return;
-    variants.push_back({name, ABL, launch<ABL>, 0.0, 0, 1e9f});
+    if constexpr (ABL < 0) {
+#ifdef TUNE64_PREV
+        variants.push_back({name, ABL, launch_prev<ABL == -1>, 0.0, 0, 1e9f});
+#endif
+    } else {
+        variants.push_back({name, ABL, launch<ABL>, 0.0, 0, 1e9f});
+    }
 }
 // interleaved timing: the chip's clock drifts with temperature / power state by a few percent
 // over seconds, so every round runs every variant and the means are compared
