@@ -407,6 +407,90 @@ def cpu_baseline(dtype, batch, heads, seq, d, budget_s=12.0):
     }
 
 
+# ---- host side of an N-rank run: where each rank's launcher thread runs ---------------------------
+def _parse_cpulist(text):
+    """'0-3,8,10-11' -> [0, 1, 2, 3, 8, 10, 11] (the kernel's cpulist format)."""
+    out = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        a, _, b = part.partition("-")
+        out.extend(range(int(a), int(b or a) + 1))
+    return out
+
+
+def _numa_nodes():
+    """{node: [cpus]} from /sys/devices/system/node (intersected with what this process may run on); one node 0 with every
+    allowed CPU where the box exposes none."""
+    allowed = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
+    nodes = {}
+    base = "/sys/devices/system/node"
+    try:
+        for name in sorted(os.listdir(base)):
+            if name.startswith("node") and name[4:].isdigit():
+                cpus = [c for c in _parse_cpulist(open(os.path.join(base, name, "cpulist")).read()) if c in set(allowed)]
+                if cpus:
+                    nodes[int(name[4:])] = cpus
+    except OSError:
+        pass
+    return nodes or {0: allowed}
+
+
+def _gpu_numa_node(device_index):
+    """NUMA node of GPU `device_index` (its PCI function's numa_node), or None."""
+    try:
+        bdf = torch.cuda.get_device_properties(device_index).pci_bus_id if hasattr(torch.cuda.get_device_properties(device_index), "pci_bus_id") else None
+    except Exception:  # noqa: BLE001
+        bdf = None
+    cands = []
+    if bdf:
+        cands.append(f"/sys/bus/pci/devices/{str(bdf).lower()}/numa_node")
+    hw = hwmon_dir(device_index)
+    if hw:
+        cands.append(os.path.join(os.path.dirname(os.path.dirname(hw)), "numa_node"))
+    for path in cands:
+        try:
+            node = int(open(path).read().strip())
+            if node >= 0:
+                return node
+        except (OSError, ValueError):
+            continue
+    return None
+
+
+def pin_rank(rank, world, local_rank, gpu_node=None):
+    """Pin this rank's process to its own slice of the CPUs of its GPU's NUMA node (the only resource N ranks
+    share is the host -- 13-14 us of launch work per forward and rank, which should neither migrate between sockets nor
+    queue behind another rank's thread).  The ranks whose GPUs sit on one node split that node's CPUs evenly, in rank
+    order; a box without NUMA information (or a dry run) splits every allowed CPU the same way.  -> what was done, for the
+    JSON line."""
+    nodes = _numa_nodes()
+    order = sorted(nodes)
+    node = gpu_node if gpu_node in nodes else order[local_rank * len(order) // max(world, 1) % len(order)]
+    # how many ranks share the node, and which of them this one is (ranks are dealt to nodes in blocks, as GPUs are)
+    per_node = max(1, -(-world // len(order)))
+    slot = local_rank % per_node
+    cpus = nodes[node]
+    n = max(1, len(cpus) // per_node)
+    mine = cpus[slot * n:(slot + 1) * n] or cpus
+    info = {"rank": rank, "numa_node": node, "cpus": f"{mine[0]}-{mine[-1]}" if mine == list(range(mine[0], mine[-1] + 1)) else ",".join(map(str, mine)),
+            "n_cpus": len(mine), "source": "gpu numa_node" if gpu_node in nodes else "no NUMA information for the device: CPUs split by rank"}
+    try:
+        os.sched_setaffinity(0, mine)
+        info["pinned"] = True
+    except (AttributeError, OSError) as exc:
+        info["pinned"] = False
+        info["error"] = repr(exc)
+    return info
+
+
+def rocprof_command(rank, out_dir, argv):
+    """--rocprof-rank R: the command rank R replaces itself with -- the same bench process under `rocprofv3 --kernel-trace
+    --stats` (its own run: no counters, so nothing gpurun refuses), writing <out_dir>/scale_rank<R>_*.csv."""
+    return ["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", out_dir, "-o", f"scale_rank{rank}", "--",
+            sys.executable, os.path.abspath(__file__)] + list(argv)
+
+
 # ---- N > 1 without an external launcher ---------------------------------------------------------
 def self_launch(n):
     """`python bench.py --gpus N` with no RANK in the environment: start one rank per GPU (the same
@@ -461,10 +545,25 @@ def run_c2_sweep(args, device):
         sec = (t_end - t0) / args.steps
         sampler.stop()
         clk = sampler.summary(t0, t_end)
-        per_s[seq] = {"tflops": mfma_flop(batch, 16, seq, 128) / sec / 1e12, "ms": sec * 1e3,
+        flop = mfma_flop(batch, 16, seq, 128)
+        alg_bytes = 4 * batch * seq * 16 * 128 * 2
+        # which roof bounds THIS shape: arithmetic intensity (= seq_len / 2 FLOP/B here) against the chip's balance
+        # PEAK / HBM = 2500 TFLOP/s / 8 TB/s = 312.5 FLOP/B -- S = 512 sits below it (HBM-bound: 16.8 us at 8 TB/s =
+        # 2048 TFLOP/s-equivalent), every longer shape above
+        ai = flop / alg_bytes
+        hbm_equiv = ai * HBM_PEAK_GBPS * 1e9 / 1e12
+        bound = "hbm" if hbm_equiv < PEAK_TFLOPS["bf16"] else "mfma"
+        roof = min(hbm_equiv, PEAK_TFLOPS["bf16"])
+        tf = flop / sec / 1e12
+        per_s[seq] = {"tflops": tf, "ms": sec * 1e3,
                       "batch": batch, "kernel": cfg.short_form(),
                       "sclk_mhz": clk.get("sclk_mhz", {}).get("mean"), "power_w": clk.get("power_w", {}).get("mean"),
-                      "algorithmic_bytes": 4 * batch * seq * 16 * 128 * 2}
+                      "algorithmic_bytes": alg_bytes,
+                      "roofline": {"bound": bound, "arithmetic_intensity_flop_per_byte": ai,
+                                   "achieved": (alg_bytes / sec / 1e9 if bound == "hbm" else tf),
+                                   "peak": (HBM_PEAK_GBPS if bound == "hbm" else PEAK_TFLOPS["bf16"]),
+                                   "unit": "GB/s" if bound == "hbm" else "TFLOP/s",
+                                   "frac": tf / roof, "roof_tflops_equivalent": roof}}
         if not args.no_traffic:  # HBM bytes per launch of this shape, measured (two rocprofv3 PMC passes)
             traffic, _how = measure_traffic(["--workload", "c2", "--c2-shape", str(seq)]
                                             + (["--kernel", args.kernel] if args.kernel else []))
@@ -480,6 +579,10 @@ def run_c2_sweep(args, device):
         "per_seq_len": per_s,
         "roofline": {"bound": "mfma", "achieved": value, "peak": PEAK_TFLOPS["bf16"], "unit": "TFLOP/s",
                      "frac": value / PEAK_TFLOPS["bf16"],
+                     "bound_per_seq_len": {str(s_): r["roofline"]["bound"] for s_, r in per_s.items()},
+                     "note": "the harmonic mean against the MFMA roof; each shape's own roof (S = 512 is HBM-bound: its "
+                             "intensity S/2 = 256 FLOP/B is below the chip's 312.5) and fraction are under per_seq_len",
+                     "harmonic_mean_of_roofs": statistics.harmonic_mean([r["roofline"]["roof_tflops_equivalent"] for r in per_s.values()]),
                      "traffic": (sum(r["traffic"] for r in per_s.values())
                                  if all(r.get("traffic") for r in per_s.values()) else None),
                      "algorithmic_bytes": sum(r["algorithmic_bytes"] for r in per_s.values()),
@@ -503,6 +606,7 @@ def dry_run(args, rank, world):
             return None
     if args.steps is None:
         args.steps = 5
+    affinity = pin_rank(rank, world, int(os.environ.get("LOCAL_RANK", "0"))) if (world > 1 and not args.no_pin) else None
     _, batch, heads, seq, d = WORKLOADS[args.workload if args.workload != "c2" else "c1"]
     lo, hi = shard_for_rank(batch * world, world, rank)
     seconds = timed_steps(lambda: time.sleep(0.002), args.steps, args.warmup, lambda: None, barrier)
@@ -510,6 +614,7 @@ def dry_run(args, rank, world):
     seconds = max_over_ranks(seconds, world, torch.device("cpu"))
     sustained = sustained_region(lambda: time.sleep(0.002), lambda: None, barrier, seconds, args.steps, world, torch.device("cpu"))
     per_rank = [mine]
+    affinities = [affinity]
     if world > 1:
         import torch.distributed as dist
 
@@ -517,6 +622,8 @@ def dry_run(args, rank, world):
         got = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(got, t)
         per_rank = [float(g.item()) for g in got]
+        affinities = [None] * world
+        dist.all_gather_object(affinities, affinity)
     if rank == 0:
         value = mfma_flop(hi - lo, heads, seq, d) * world * args.steps / seconds / 1e12
         print(json.dumps({"metric": "cpu-dry-run (a step is a 2 ms sleep: NOT a measurement)", "value": value,
@@ -527,6 +634,10 @@ def dry_run(args, rank, world):
                                      "seq_len": seq, "flop_per_step_per_gpu": mfma_flop(hi - lo, heads, seq, d),
                                      "shards": [list(shard_for_rank(batch * world, world, r)) for r in range(world)]},
                           "per_gpu_tflops": per_rank,
+                          "per_gpu": [{"affinity": a} for a in (affinities if world > 1 else [affinity])],
+                          "rocprof_rank": (args.rocprof_rank if args.rocprof_rank >= 0 else None),
+                          "rocprof_command": (rocprof_command(args.rocprof_rank, args.rocprof_dir, [a for a in sys.argv[1:] if a != "--cpu-dry-run"])
+                                              if args.rocprof_rank >= 0 else None),
                           "sustained": (dict(sustained, tflops=mfma_flop(hi - lo, heads, seq, d) * world * sustained["steps"]
                                              / sustained["seconds"] / 1e12) if sustained else None)}), flush=True)
     if world > 1:
@@ -716,6 +827,11 @@ def main():
     ap.add_argument("--cpu-dry-run", action="store_true",
                     help="no GPU, no kernel: a step is a 2 ms sleep.  Exercises the launcher, the shard arithmetic, "
                          "the barrier-bracketed timing and the rank-0 line on a CPU-only box (tests/); the line says so")
+    ap.add_argument("--no-pin", action="store_true", help="N > 1: do not pin the ranks to the NUMA nodes of their GPUs")
+    ap.add_argument("--rocprof-rank", type=int, default=-1,
+                    help="N > 1: rank R runs under `rocprofv3 --kernel-trace --stats` and leaves --rocprof-dir/scale_rank<R>*.csv "
+                         "(one rank only: the profiled rank clocks a few % lower, see MI355X_MICROARCH.md DVFS)")
+    ap.add_argument("--rocprof-dir", default=os.path.join("profiles", "r05"))
     ap.add_argument("--dist-backend", default="gloo", choices=["gloo", "nccl"],
                     help="barrier + max-over-ranks only (the data path has no collective): gloo (default; on "
                          "a box with fewer GPUs than ranks the ranks share devices and the timings mean "
@@ -731,6 +847,11 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
 
+    if args.rocprof_rank == rank and world > 1 and not args.cpu_dry_run and not os.environ.get("FA_UNDER_ROCPROF"):
+        os.environ["FA_UNDER_ROCPROF"] = "1"   # (the re-executed process keeps RANK / WORLD_SIZE / MASTER_*: it joins the same rendezvous)
+        os.makedirs(args.rocprof_dir, exist_ok=True)
+        os.execvp("rocprofv3", rocprof_command(rank, args.rocprof_dir, sys.argv[1:]))
+
     if args.cpu_dry_run:
         return dry_run(args, rank, world)
 
@@ -745,6 +866,9 @@ def main():
     local_rank = local_rank % n_dev
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    affinity = None
+    if world > 1 and not args.no_pin:
+        affinity = pin_rank(rank, world, local_rank, _gpu_numa_node(local_rank))
     reduce_device = device if args.dist_backend == "nccl" else torch.device("cpu")
     if world > 1:
         import torch.distributed as dist
@@ -901,7 +1025,8 @@ def main():
 
         clk = sampler.summary(t0, t_end)
         mine = {"tflops": achieved, "sclk_mhz": clk.get("sclk_mhz", {}).get("mean"), "power_w": clk.get("power_w", {}).get("mean"),
-                "device": local_rank, "kernel_ms": kernel_ms}
+                "device": local_rank, "kernel_ms": kernel_ms, "affinity": affinity,
+                "under_rocprof": bool(os.environ.get("FA_UNDER_ROCPROF"))}
         gathered = [None] * world
         dist.all_gather_object(gathered, mine)
         per_rank = [g["tflops"] for g in gathered]

@@ -27,10 +27,10 @@ EXPORTED_SYMBOLS = (
     "fa_fwd_launch_timed", "fa_num_kernels", "fa_get_kernel", "fa_last_error", "fa_version",
     "fa_fwd_masked_supported", "fa_fwd_launch_masked", "fa_device_state",
     "fa_fwd_ex_supported", "fa_fwd_launch_ex", "fa_fwd_query",
-    "fa_adaptive_state", "fa_adaptive_reset", "fa_adaptive_simulate", "fa_get_kernel_sized", "fa_fwd_query_sized", "fa_abi_version",
+    "fa_adaptive_state", "fa_adaptive_state_for", "fa_adaptive_reset", "fa_adaptive_simulate", "fa_get_kernel_sized", "fa_fwd_query_sized", "fa_abi_version",
 )
 FA_SPECULATIVE_OFF, FA_SPECULATIVE_ALWAYS, FA_SPECULATIVE_ADAPTIVE = 0, 1, 2  # fa_speculative_mode
-FA_ABI_VERSION = 4
+FA_ABI_VERSION = 5
 SOFTMAX_MODES = ("eager", "first_block_skip", "lazy", "speculative")  # fa_softmax_mode
 
 
@@ -149,6 +149,8 @@ def load():
     lib.fa_get_kernel.argtypes = [ctypes.c_int, ctypes.POINTER(FaKernelInfo)]
     lib.fa_adaptive_state.restype = ctypes.c_int
     lib.fa_adaptive_state.argtypes = [ctypes.c_int, ctypes.POINTER(FaAdaptiveInfo)]
+    lib.fa_adaptive_state_for.restype = ctypes.c_int
+    lib.fa_adaptive_state_for.argtypes = [ctypes.c_int, ctypes.POINTER(FaFwdConfig), ctypes.POINTER(FaFwdOpts), ctypes.POINTER(FaAdaptiveInfo)]
     lib.fa_adaptive_reset.restype = ctypes.c_int
     lib.fa_adaptive_reset.argtypes = [ctypes.c_int]
     lib.fa_adaptive_simulate.restype = ctypes.c_int
@@ -241,10 +243,17 @@ def device_state(device: int):
     return bool(a.value), b.value, c.value
 
 
-def adaptive_state(device: int) -> dict:
-    """fa_adaptive_state: the adaptive speculative mode's record on `device` as a dict."""
+def adaptive_state(device: int, kernel_cfg=None, **opts) -> dict:
+    """fa_adaptive_state: the adaptive speculative mode's records on `device` taken together, as a dict; with
+    `kernel_cfg` (and causal= / allow_ragged= / prescaled_q=) fa_adaptive_state_for: the record of the one device variant
+    that serves that configuration (records are per variant since ABI 5)."""
     info = FaAdaptiveInfo()
-    check(load().fa_adaptive_state(int(device), ctypes.byref(info)))
+    if kernel_cfg is None:
+        check(load().fa_adaptive_state(int(device), ctypes.byref(info)))
+    else:
+        cfg = make_config(kernel_cfg)
+        o = make_opts(**opts)
+        check(load().fa_adaptive_state_for(int(device), ctypes.byref(cfg), ctypes.byref(o), ctypes.byref(info)))
     return {name: int(getattr(info, name)) for name, _ in FaAdaptiveInfo._fields_}
 
 

@@ -174,12 +174,20 @@ struct AdaptivePolicy {
     }
     void reset(uint32_t rep_now) { seen = rep_now; mode = NORMAL; remaining = 0; hold = 32; demoted = 0; reports = 0; }
 };
+// Round 5: ONE RECORD PER DEVICE VARIANT (the registry index of the speculative entry that a launch asked for), each with
+// its own report word and probe event: a failing workload demotes its own configuration only -- an fp16 attention-sink layer
+// no longer drags a benign bf16 one down with it, and a clean probe of one configuration no longer resets another's hold
+// (ADVICE r04).  What stays shared is the mutex (launches are enqueued one at a time per device anyway).
+constexpr int kAdaptiveSlots = 512;   // >= registry().size(), checked at init
+struct AdaptiveSlot {
+    AdaptivePolicy p;
+    hipEvent_t probe_done = nullptr;  // created at the slot's first probe
+};
 struct AdaptiveState {
     std::mutex mu;
-    uint32_t *flag_host = nullptr;  // hipHostMalloc'ed (mapped, coherent) word; null: no pinned memory -> always speculative
-    uint32_t *flag_dev = nullptr;   // the same word as the device addresses it
-    hipEvent_t probe_done = nullptr;
-    AdaptivePolicy p;
+    uint32_t *flag_host = nullptr;  // hipHostMalloc'ed (mapped, coherent) words, one per slot; null: no pinned memory -> always speculative
+    uint32_t *flag_dev = nullptr;   // the same words as the device addresses them
+    AdaptiveSlot slot[kAdaptiveSlots];
 };
 struct DeviceState {
     std::once_flag once;
@@ -230,18 +238,13 @@ void do_init(int dev, DeviceState *st) {
     do_init_body(dev, st);
     if (st->status == FA_OK) {  // the adaptive mode's report word (see AdaptiveState); without it the mode stays speculative
         void *h = nullptr, *d = nullptr;
-        if (hipHostMalloc(&h, 64, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess && h &&
+        const size_t bytes = sizeof(uint32_t) * kAdaptiveSlots;
+        if ((int)registry().size() <= kAdaptiveSlots &&
+            hipHostMalloc(&h, bytes, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess && h &&
             hipHostGetDevicePointer(&d, h, 0) == hipSuccess && d) {
-            memset(h, 0, 64);
-            hipEvent_t ev = nullptr;
-            if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess) {
-                st->adaptive.flag_host = (uint32_t *)h;
-                st->adaptive.flag_dev = (uint32_t *)d;
-                st->adaptive.probe_done = ev;
-            } else {
-                (void)hipGetLastError();
-                (void)hipHostFree(h);
-            }
+            memset(h, 0, bytes);
+            st->adaptive.flag_host = (uint32_t *)h;
+            st->adaptive.flag_dev = (uint32_t *)d;
         } else {
             (void)hipGetLastError();
             if (h) (void)hipHostFree(h);
@@ -395,10 +398,31 @@ int fa_fwd_lds_bytes(const fa_fwd_config *cfg) {
 
 // Enqueue (ms == nullptr) or enqueue between two events on the stream and wait for the second one
 // (flash_attention.cu:119-132).  Whatever was created is destroyed on every path.
+// `probe` (an adaptive probe launch): its event is recorded right behind the kernel, its policy told if that failed, and
+// the device's adaptive lock -- held by the caller until then, so that no other thread queries an event that has not
+// been recorded -- is released BEFORE the timed path waits for the stop event (a timed probe used to keep
+// every other thread's adaptive launch on the device out for the kernel's whole duration).
+struct ProbeHook {
+    AdaptiveSlot *slot = nullptr;
+    std::unique_lock<std::mutex> *lock = nullptr;
+    void after_launch(int launch_rc, hipStream_t s) {
+        if (!slot) return;
+        if (launch_rc != FA_OK || hipEventRecord(slot->probe_done, s) != hipSuccess) {
+            (void)hipGetLastError();
+            slot->p.mode = AdaptivePolicy::NORMAL;  // (no event to wait for; a failing probe reports like any launch)
+        }
+        if (lock && lock->owns_lock()) lock->unlock();
+        slot = nullptr;
+    }
+};
 static int launch_maybe_timed(const fa_fwd_args *args, const fa::KernelEntry *e, const DeviceState *dev,
                               hipStream_t s, int causal, float *ms, fa_fwd_stats *stats = nullptr,
-                              uint32_t *redo_flag = nullptr, uint32_t redo_seq = 0) {
-    if (!ms) return launch(args, e, dev, s, causal, stats, redo_flag, redo_seq);
+                              uint32_t *redo_flag = nullptr, uint32_t redo_seq = 0, ProbeHook probe = ProbeHook()) {
+    if (!ms) {
+        const int rc0 = launch(args, e, dev, s, causal, stats, redo_flag, redo_seq);
+        probe.after_launch(rc0, s);
+        return rc0;
+    }
     hipEvent_t start = nullptr, stop = nullptr;
     hipError_t hrc = hipEventCreate(&start);
     if (hrc == hipSuccess) hrc = hipEventCreate(&stop);
@@ -406,11 +430,13 @@ static int launch_maybe_timed(const fa_fwd_args *args, const fa::KernelEntry *e,
     int rc = FA_OK;
     if (hrc == hipSuccess) {
         rc = launch(args, e, dev, s, causal, stats, redo_flag, redo_seq);
+        probe.after_launch(rc, s);
         hrc = hipEventRecord(stop, s);  // (recorded even if the launch failed: nothing is left pending)
         if (hrc == hipSuccess) hrc = hipEventSynchronize(stop);
     }
     float elapsed = 0.0f;
     if (hrc == hipSuccess && rc == FA_OK) hrc = hipEventElapsedTime(&elapsed, start, stop);
+    probe.after_launch(FA_ERR_LAUNCH, s);  // (only if the events could not even be created: nothing was launched)
     if (start) (void)hipEventDestroy(start);
     if (stop) (void)hipEventDestroy(stop);
     if (rc != FA_OK) return rc;
@@ -465,7 +491,23 @@ static int read_opts(const fa_fwd_opts *in, fa_fwd_opts *o) {
         return fail(FA_ERR_SHAPE, "fa_fwd_opts.struct_size (%u) is not set: zero the struct and set it to sizeof(fa_fwd_opts)",
                     in->struct_size);
     memcpy(o, in, in->struct_size < sizeof(*o) ? in->struct_size : sizeof(*o));
+    // (checked HERE so that fa_fwd_ex_supported, fa_fwd_query and fa_fwd_launch_ex agree: ADVICE r04)
+    if (o->speculative < 0 || o->speculative > FA_SPECULATIVE_ADAPTIVE)
+        return fail(FA_ERR_SHAPE, "fa_fwd_opts.speculative must be 0, 1 (always) or 2 (adaptive), not %d", o->speculative);
     return FA_OK;
+}
+
+// hipEventQuery is not a capture-safe call: with another thread's stream in a global-mode capture it would invalidate
+// that capture.  Queried in relaxed mode (this thread's view only); if the mode cannot be switched the probe counts as
+// still pending -- the policy stays demoted, which is always valid.
+static int query_probe(hipEvent_t ev) {
+    hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
+    if (hipThreadExchangeStreamCaptureMode(&mode) != hipSuccess) { (void)hipGetLastError(); return AdaptivePolicy::PROBE_PENDING; }
+    const hipError_t q = hipEventQuery(ev);
+    if (q != hipSuccess) (void)hipGetLastError();
+    if (hipThreadExchangeStreamCaptureMode(&mode) != hipSuccess) (void)hipGetLastError();
+    return q == hipSuccess ? AdaptivePolicy::PROBE_COMPLETE
+                           : (q == hipErrorNotReady ? AdaptivePolicy::PROBE_PENDING : AdaptivePolicy::PROBE_ERROR);
 }
 
 int fa_fwd_ex_supported(const fa_fwd_config *cfg, const fa_fwd_opts *opts) {
@@ -490,8 +532,6 @@ int fa_fwd_launch_ex(const fa_fwd_args *args, const fa_fwd_opts *opts, void *str
     w.ragged = o.allow_ragged != 0;
     w.speculative = o.speculative != 0;
     w.prescaled_q = o.prescaled_q != 0;
-    if (o.speculative < 0 || o.speculative > FA_SPECULATIVE_ADAPTIVE)
-        return fail(FA_ERR_SHAPE, "fa_fwd_opts.speculative must be 0, 1 (always) or 2 (adaptive), not %d", o.speculative);
     const fa::KernelEntry *e = nullptr;
     rc = validate(args, &e, w);
     if (rc != FA_OK) return rc;
@@ -500,32 +540,36 @@ int fa_fwd_launch_ex(const fa_fwd_args *args, const fa_fwd_opts *opts, void *str
     if (!dev) return rc;
     uint32_t *redo_flag = nullptr;
     uint32_t redo_seq = 0;
-    bool record_probe = false;
+    ProbeHook hook;
     std::unique_lock<std::mutex> probe_lock;
     if (o.speculative == FA_SPECULATIVE_ADAPTIVE && dev->adaptive.flag_host) {
         // (the speculative variant exists: validated above.  Its non-speculative sibling serves a demoted launch)
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
         if (hipStreamIsCapturing((hipStream_t)stream, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
         AdaptiveState &ad = dev->adaptive;
+        const int idx = (int)(e - registry().data());   // the record of THIS device variant
         bool demote = false;
-        if (cap == hipStreamCaptureStatusNone) {
+        if (cap == hipStreamCaptureStatusNone && idx >= 0 && idx < kAdaptiveSlots) {
+            AdaptiveSlot &sl = ad.slot[idx];
             probe_lock = std::unique_lock<std::mutex>(ad.mu);
             int probe = AdaptivePolicy::PROBE_NA;
-            if (ad.p.mode == AdaptivePolicy::PROBING) {   // has the probe finished?  (never a wait)
-                const hipError_t q = hipEventQuery(ad.probe_done);
-                probe = q == hipSuccess ? AdaptivePolicy::PROBE_COMPLETE
-                                        : (q == hipErrorNotReady ? AdaptivePolicy::PROBE_PENDING : AdaptivePolicy::PROBE_ERROR);
-                if (q != hipSuccess) (void)hipGetLastError();
+            if (sl.p.mode == AdaptivePolicy::PROBING) probe = query_probe(sl.probe_done);   // has the probe finished?  (never a wait)
+            const uint32_t rep = __atomic_load_n(ad.flag_host + idx, __ATOMIC_ACQUIRE);   // (behind the query: see step())
+            int run = sl.p.step(rep, probe);
+            if (run == AdaptivePolicy::RUN_PROBE && !sl.probe_done &&
+                hipEventCreateWithFlags(&sl.probe_done, hipEventDisableTiming) != hipSuccess) {
+                (void)hipGetLastError();
+                sl.probe_done = nullptr;
+                sl.p.mode = AdaptivePolicy::NORMAL;   // no event to probe with: speculative, reports still demote
+                run = AdaptivePolicy::RUN_SPECULATIVE;
             }
-            const uint32_t rep = __atomic_load_n(ad.flag_host, __ATOMIC_ACQUIRE);   // (behind the query: see step())
-            const int run = ad.p.step(rep, probe);
             demote = run == AdaptivePolicy::RUN_DEMOTED;
-            record_probe = run == AdaptivePolicy::RUN_PROBE;
-            redo_flag = ad.flag_dev;
-            redo_seq = ad.p.seq;
-            // (a probe keeps the lock until its event is recorded: another thread's launch must not query an event that
-            // has not been recorded yet -- it would read as complete)
-            if (!record_probe) probe_lock.unlock();
+            redo_flag = ad.flag_dev + idx;
+            redo_seq = sl.p.seq;
+            // (a probe keeps the lock until its event is recorded -- ProbeHook: another thread's launch must not query an
+            // event that has not been recorded yet, it would read as complete)
+            if (run == AdaptivePolicy::RUN_PROBE) { hook.slot = &sl; hook.lock = &probe_lock; }
+            else probe_lock.unlock();
         }
         if (demote) {
             Want w2 = w;
@@ -537,31 +581,65 @@ int fa_fwd_launch_ex(const fa_fwd_args *args, const fa_fwd_opts *opts, void *str
             }  // (no such sibling: the speculative variant stays)
         }
     }
-    rc = launch_maybe_timed(args, e, dev, (hipStream_t)stream, o.causal != 0, o.ms, o.stats, redo_flag, redo_seq);
-    if (record_probe) {   // (probe_lock is still held)
-        if (rc != FA_OK || hipEventRecord(dev->adaptive.probe_done, (hipStream_t)stream) != hipSuccess) {
-            (void)hipGetLastError();
-            dev->adaptive.p.mode = AdaptivePolicy::NORMAL;  // (no event to wait for; a failing probe reports like any launch)
-        }
+    return launch_maybe_timed(args, e, dev, (hipStream_t)stream, o.causal != 0, o.ms, o.stats, redo_flag, redo_seq, hook);
+}
+
+static void add_slot(const AdaptiveState &ad, int idx, fa_adaptive_info *out) {
+    const AdaptivePolicy &p = ad.slot[idx].p;
+    out->launches += p.seq;
+    out->demoted += p.demoted;
+    out->reports += p.reports;
+    if (p.mode != AdaptivePolicy::NORMAL || out->hold < p.hold) {   // the record that is (or was longest) demoted
+        if (p.hold >= out->hold) { out->hold = p.hold; out->remaining = p.remaining; }
+        if (p.mode > out->mode) out->mode = p.mode;
     }
-    return rc;
+    if (ad.flag_host) { const uint32_t r = __atomic_load_n(ad.flag_host + idx, __ATOMIC_RELAXED); if (r > out->last_report) out->last_report = r; }
 }
 
 int fa_adaptive_state(int device, fa_adaptive_info *out) {
     if (!out) return fail(FA_ERR_NULL, "null output");
     if (device < 0 || device >= kMaxDevices) return fail(FA_ERR_DEVICE, "device ordinal %d out of range", device);
     memset(out, 0, sizeof(*out));
+    out->hold = 32;
     DeviceState &st = g_dev[device];
     if (!st.inited.load(std::memory_order_acquire)) return FA_OK;
     AdaptiveState &ad = st.adaptive;
     std::lock_guard<std::mutex> lock(ad.mu);
-    out->launches = ad.p.seq;
-    out->demoted = ad.p.demoted;
-    out->reports = ad.p.reports;
-    out->hold = ad.p.hold;
-    out->mode = ad.p.mode;
-    out->remaining = ad.p.remaining;
-    out->last_report = ad.flag_host ? __atomic_load_n(ad.flag_host, __ATOMIC_RELAXED) : 0u;
+    // the device's records taken together: counters summed; mode / hold / remaining of the record that is demoted (or was
+    // demoted longest)
+    const int n = (int)registry().size() < kAdaptiveSlots ? (int)registry().size() : kAdaptiveSlots;
+    for (int i = 0; i < n; ++i) add_slot(ad, i, out);
+    out->available = ad.flag_host != nullptr;
+    return FA_OK;
+}
+
+int fa_adaptive_state_for(int device, const fa_fwd_config *cfg, const fa_fwd_opts *opts, fa_adaptive_info *out) {
+    if (!out || !cfg) return fail(FA_ERR_NULL, "null pointer argument");
+    if (device < 0 || device >= kMaxDevices) return fail(FA_ERR_DEVICE, "device ordinal %d out of range", device);
+    fa_fwd_opts o;
+    int rc = read_opts(opts, &o);
+    if (rc != FA_OK) return rc;
+    Want w;
+    w.masked = o.causal || o.allow_ragged;
+    w.ragged = o.allow_ragged != 0;
+    w.speculative = true;
+    w.prescaled_q = o.prescaled_q != 0;
+    const char *why = "";
+    const fa::KernelEntry *e = find_kernel(cfg, &why, w);
+    if (!e) return fail(FA_ERR_NO_KERNEL, "%s", why);
+    memset(out, 0, sizeof(*out));
+    out->hold = 32;
+    DeviceState &st = g_dev[device];
+    if (!st.inited.load(std::memory_order_acquire)) return FA_OK;
+    AdaptiveState &ad = st.adaptive;
+    std::lock_guard<std::mutex> lock(ad.mu);
+    const int idx = (int)(e - registry().data());
+    if (idx >= 0 && idx < kAdaptiveSlots) {
+        const AdaptivePolicy &p = ad.slot[idx].p;
+        out->launches = p.seq; out->demoted = p.demoted; out->reports = p.reports;
+        out->hold = p.hold; out->mode = p.mode; out->remaining = p.remaining;
+        out->last_report = ad.flag_host ? __atomic_load_n(ad.flag_host + idx, __ATOMIC_RELAXED) : 0u;
+    }
     out->available = ad.flag_host != nullptr;
     return FA_OK;
 }
@@ -590,7 +668,8 @@ int fa_adaptive_reset(int device) {
     if (!st.inited.load(std::memory_order_acquire)) return FA_OK;
     AdaptiveState &ad = st.adaptive;
     std::lock_guard<std::mutex> lock(ad.mu);
-    ad.p.reset(ad.flag_host ? __atomic_load_n(ad.flag_host, __ATOMIC_RELAXED) : 0u);
+    for (int i = 0; i < kAdaptiveSlots; ++i)
+        ad.slot[i].p.reset(ad.flag_host ? __atomic_load_n(ad.flag_host + i, __ATOMIC_RELAXED) : 0u);
     return FA_OK;
 }
 
@@ -673,6 +752,6 @@ int fa_abi_version(void) { return FA_ABI_VERSION; }
 
 const char *fa_last_error(void) { return g_err; }
 
-const char *fa_version(void) { return "fa_hip 0.4 gfx950"; }
+const char *fa_version(void) { return "fa_hip 0.5 gfx950"; }
 
 }  // extern "C"

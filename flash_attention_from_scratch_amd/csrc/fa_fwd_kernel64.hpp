@@ -130,7 +130,7 @@ constexpr bool plan64_ok(const Plan64 &p, int rot_k = 0) {
 // ABL: 0 in the product.  tools/tune64.hip instantiates the kernel with experiment / timing-only bits so that a
 // measured claim in profiles/ can be re-run against the shipped code: 1 2 4 16 2048 4096 delete one part of the stream
 // (results wrong: timing only), 8 drops the waits and barriers (timing only), 256 512 1024 8192 16384 pick another filler
-// plan, 64 the prologue's last 16 requests at visit 0's sync point instead, 32768 the guard's check behind the visit instead of inside it, 128 the round-4 item loop (no hot region: every
+// plan, 64 an eight-slot operand ring with one counted wait per four steps, 32768 the guard's check behind the visit instead of inside it, 128 the round-4 item loop (no hot region: every
 // visit carries the seam handling), 131072 two d tiles per epilogue step, 262144 no guard, 524288 a prologue that requests only
 // what visit 0 needs (timing only).  Round 4: 32 no row sums (timing only), bits 24..27 the rotated plan's rot_k (0 = the
 // shipped FA_ROT_DEFAULT, 15 = off), bit 28 the next request pointers in gap 58, bits 29..30 the cache policy of the O stores.
@@ -638,7 +638,13 @@ fa_fwd_kernel64(const KernelArgs args) {
             // two steps (4 MFMAs, ~170 cycles) between a load and its use -- less than the LDS latency with four
             // waves reading operands and the DMA writing: tools/trace64.hip (-DFA_TRACE=2) shows the wait in front
             // of every fourth MFMA stall 25-50 cycles.  RS = 8: six steps.
-            constexpr int RS = FA_RING_SLOTS, LA = RS - 2;
+            // ABL & 64 (round 5, tools/tune64.hip): RS = 8 and ONE counted wait per FOUR steps -- the wait in front of step s
+            // (s % 4 == 0) retires operands s .. s+3 (requested six and four steps ago) and lets the two youngest fly, the one
+            // in front of step s+2 is gone: eight s_waitcnt fewer per visit.  Measured +0.2 % at S = 4096, 0 at 16384
+            // (profiles/r05/tune64_ring8_wait4.txt; the eight-slot ring alone: +0.1 %, profiles/r04/ring_slots_4_vs_8.txt):
+            // a satisfied s_waitcnt is not what the issue-bound stream pays for.  Not adopted (16 registers).
+            constexpr int RS = ((ABL & 64) && !PSQ) ? 8 : FA_RING_SLOTS, LA = RS - 2;
+            constexpr bool WAIT4 = RS >= 8;
             vec8 ring[RS];
             vec8 Qr2[2][KS];  // the next item's Q (AGPRs), requested during the item's first visit
             float mraw[2];   // row max of the S tile formed by the last visit (the next item's S(0))
@@ -646,14 +652,6 @@ fa_fwd_kernel64(const KernelArgs args) {
             // the counted waits allow -- 16 of them, or fewer (RAG: a wave whose rows reach beyond the sequence
             // skips stores; counted down to a multiple of 8, which only waits for more)
             int seam_st = 0;
-            // ABL & 64 (experiment, tools/tune64.hip; plain form only): the walk's prologue leaves K(3), V(2) and the next
-            // item's Q tile 0 -- 16 pieces per wave that visit 0 does not need -- to the sync point of visit 0.  Their place
-            // in the issue order is the same (behind K(2), V(1), in front of visit 0's own pieces), so every later counted
-            // wait holds and the output is bit-identical.  Measured (profiles/r03/tune64_seam_and_guard.txt, last table):
-            // -1.1 % at S = 512, -0.6 % at S = 1024, -0.2 % at C1 -- the start-up requests return at the fabric's rate whenever
-            // they are issued, and 16 pieces cost more at a sync point than under S(0).  Not adopted.
-            constexpr bool DEFER = (ABL & 64) != 0 && !MASK;
-            int deferred = 0;  // 1: those pieces are still to be requested (first visit of the walk's first item only)
             // the guard's common path (see guard() below) rides in the last gaps of every fourth visit, where the vector
             // stream has room (all 32 softmax units have issued by gap 53): two adds, a max, a compare.  ABL & 32768
             // (tools/tune64.hip): behind the visit instead, as first built.
@@ -775,9 +773,15 @@ fa_fwd_kernel64(const KernelArgs args) {
                     asm volatile("" : "+v"(rs_e[qt][0]), "+v"(rs_e[qt][1]));
                 }
                 if constexpr (SUM == SET_EARLY) {
+                    // the pack FIRST: p0 / p1 then die into the side sums, which take over their registers (set behind the
+                    // pack they cost a v_mov apiece, four per visit)
+                    unsigned pk0 = E::pack2(p0, p1);
+                    asm volatile("" : "+v"(pk0));
+                    Pw[qt][s16][j] = pk0;
                     rs_e[qt][0] = p0;
                     rs_e[qt][1] = p1;
                     asm volatile("" : "+v"(rs_e[qt][0]), "+v"(rs_e[qt][1]));
+                    return;
                 }
                 unsigned pk = E::pack2(p0, p1);
                 // ... and the pack: sunk below a branch of the stream it would sit right in front of the
@@ -834,16 +838,6 @@ fa_fwd_kernel64(const KernelArgs args) {
                         if constexpr ((ABL & (1 << 22)) != 0 && (R & 1) != 0) asm volatile("s_waitcnt vmcnt(" FA_VM8 ")" ::: "memory");
                         else asm volatile("s_waitcnt vmcnt(" FA_VM8 ")\n\ts_barrier" ::: "memory");
                         return;
-                    }
-                    if constexpr (DEFER && R == 0) {
-                        if (deferred) {  // (it == 0) nothing is younger than K(2), V(1) yet
-                            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-                            dma_k(tile_g(Kc, Kn, 3), 3);
-                            dma_v(tile_g(Vc, Vn, 2), 2);
-                            if (has_next) request_next_q(0);
-                            deferred = 0;
-                            return;
-                        }
                     }
                     const int q8 = has_next ? 8 : 0;
                     const int allow = (it < 2) ? 8 + seam_st + q8 : 8 + q8;
@@ -991,16 +985,20 @@ fa_fwd_kernel64(const KernelArgs args) {
                     // removed).  So every operand is kept alive until the NEXT MFMA has issued: an empty asm
                     // that names it, placed behind that MFMA (volatile asm statements keep their order).
                     vec8 prev_a = ring[(step + RS - 1) % RS];  // A operand of the previous step (its slot is reloaded below)
-                    if constexpr (qt == 0 && (step & 1) == 0) {  // operands in pairs: one counted wait per two steps
-                        // operands step, step + 1 landed; the LDS reads of operands step + 2 ... step + LA - 1 (one per
-                        // K fragment, two per V fragment; LDS returns in order) may still fly
-                        constexpr int fly = [] { int n = 0; for (int u = step + 2; u < step + LA; ++u) n += (u >= 16 && u < 32) ? 2 : 1; return n; }();
+                    if constexpr (qt == 0 && (step & 1) == 0) {  // operands in pairs
+                        // the counted wait: operands step, step + 1 (WAIT4: step .. step + 3, every second pair only) landed;
+                        // the LDS reads of the operands behind them up to step + LA - 1 (one per K fragment, two per V
+                        // fragment; LDS returns in order) may still fly
+                        constexpr int need = WAIT4 ? 4 : 2;
+                        constexpr int fly = [] { int n = 0; for (int u = step + need; u < step + LA; ++u) n += (u >= 16 && u < 32) ? 2 : 1; return n; }();
+                        if constexpr (!WAIT4 || (step & 3) == 0) {
                         FA_JIT(true);
 #if defined(FA_TRACE) && FA_TRACE < 4
                         __builtin_amdgcn_s_waitcnt(0xC07F);      // (s_memtime returns out of order: no counting)
 #else
                         __builtin_amdgcn_s_waitcnt(0xC07F | (fly << 8));
 #endif
+                        }
 #if defined(FA_TRACE) && FA_TRACE == 1
                         asm volatile("s_memtime %0" : "=s"(ts[2 + step / 2]));
 #endif
@@ -1235,14 +1233,13 @@ fa_fwd_kernel64(const KernelArgs args) {
                 barrier();  // every wave has read its Q tile 1 out of stages 3, which K(3) now overwrites
                 // (ABL & 524288, tools/tune64.hip, TIMING ONLY -- results are wrong: the upper bound of what deferring these
                 // 64 KB + 32 KB out of the prologue could buy: they are simply not requested)
-                if (!(ABL & 524288) && !DEFER) {
+                if (!(ABL & 524288)) {
                     dma_k(tile_g(Kc, Kn, 3), 3);
                     dma_v(tile_g(Vc, Vn, 2), 2);
                 }
                 kq = tile_g(Kc, Kn, 4);
                 vq = tile_g(Vc, Vn, 3);
-                if (has_next && !(ABL & 524288) && !DEFER) request_next_q(0);
-                if constexpr (DEFER) deferred = 1;
+                if (has_next && !(ABL & 524288)) request_next_q(0);
                 FA_TLP(4);  // S(0) MFMAs and the remaining requests issued
                 asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // MFMA D -> VALU read
 #pragma unroll
@@ -1263,8 +1260,7 @@ fa_fwd_kernel64(const KernelArgs args) {
                 set_cinit(Sa);
                 head_units(Sa);
                 if (!(ABL & 8)) {  // K(1) landed (under S(0)); younger: V(0), K(2), V(1) [, K(3), V(2) [, the next Q tile 0]]
-                    if constexpr (DEFER) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-                    else if (has_next) asm volatile("s_waitcnt vmcnt(28)" ::: "memory");
+                    if (has_next) asm volatile("s_waitcnt vmcnt(28)" ::: "memory");
                     else asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
                 }
                 FA_TLP(5);  // row max done, K(1) landed
@@ -1280,7 +1276,10 @@ fa_fwd_kernel64(const KernelArgs args) {
             // area one 32-row Q tile at a time so that the global stores are whole 256-B rows (16 B per
             // lane, 4 rows per wave-instruction).  Wave-private: no barrier.  The 16-B chunk index is
             // XORed with (row & 15) so the 8-B writes and the 16-B reads are bank-conflict free.
-            auto store_item = [&](uint16_t *Oc, const int qb_c, const int ord) {
+            // zero_behind: O is cleared for the next item as soon as its last register has been read (eight MFMAs on a zero
+            // operand, which then run under the second tile's LDS round trip and row stores instead of behind the seam's
+            // row max: -0.3 k cycles per item)
+            auto store_item = [&](uint16_t *Oc, const int qb_c, const int ord, const bool zero_behind) {
                 FA_JIT(false);
                 asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // last P.V -> VALU reads of O
                 char *stage_o = smem + 2 * TR::kStages * TILE + wave * (32 * ROWB);
@@ -1324,6 +1323,7 @@ fa_fwd_kernel64(const KernelArgs args) {
                         // one d tile at a time: S(0) of the next item is live (ABL & 131072, experiment: two at a time)
                         if (!(ABL & 131072) || (t & 1)) __builtin_amdgcn_sched_barrier(0);
                     }
+                    if (qt == 1 && zero_behind) zero_o();
                     // rows RPP i + rsub of the tile: one scalar base for the 32 rows, a 32-bit lane offset per store;
                     // all reads first (the waits then count down), and the read address is one XOR per row
                     // group: row = RPP i + rsub, so chunk ^ swz_of(row) = (chunk ^ rsub) ^ (RPP i & 15)
@@ -1411,7 +1411,7 @@ fa_fwd_kernel64(const KernelArgs args) {
                 guard(Sa, true);
                 const int qb_st = qb_c;  // the item being stored
                 (void)qb_st;
-                store_item(Oc, qb_c, ord);
+                store_item(Oc, qb_c, ord, has_next && !(ABL & 128));
 #if defined(FA_TRACE) && FA_TRACE >= 4
                 if (tl_seam) tl_at(51);  // epilogue issued
 #endif
@@ -1469,7 +1469,7 @@ fa_fwd_kernel64(const KernelArgs args) {
 #if defined(FA_TRACE) && FA_TRACE >= 4
                 if (tl_seam) tl_at(55);  // row max of S(0), softmax state reset
 #endif
-                zero_o();
+                if constexpr ((ABL & 128) != 0) zero_o();  // (otherwise cleared inside store_item)
 #if defined(FA_TRACE) && FA_TRACE >= 4
                 if (tl_seam) tl_at(52);  // O = 0 issued
 #endif

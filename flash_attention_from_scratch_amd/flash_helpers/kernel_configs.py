@@ -221,8 +221,11 @@ class NativeKernelConfig(FlashForwardKernelConfig):
     adaptive_softmax: bool = False
 
     def __post_init__(self):
+        # adaptive_softmax qualifies speculative_softmax: without it there is nothing to adapt.  Cleared rather than refused,
+        # so that dataclasses.replace(best_config(...), speculative_softmax=False) -- what the docstring of best_config
+        # tells a caller who wants "never" to do -- works on its own (round 4 raised ValueError here)
         if self.adaptive_softmax and not self.speculative_softmax:
-            raise ValueError("adaptive_softmax qualifies speculative_softmax: set both")
+            object.__setattr__(self, "adaptive_softmax", False)
 
     def base(self) -> FlashForwardKernelConfig:
         """The plain 13-field config (what a reference user would pass)."""

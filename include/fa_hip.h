@@ -29,9 +29,20 @@
  * fa_last_error() on the calling thread.  Unlike the reference (which never calls
  * cudaGetLastError), launch failures are reported.
  *
- * Threading / streams: no internal threads, no global mutable state besides the
- * const kernel registry and the one-time per-device setup (fa_init).  Launches are
- * asynchronous on the caller's stream; fa_fwd_launch_timed blocks on its stop event.
+ * Threading / streams: no internal threads.  Launches are asynchronous on the caller's
+ * stream (graph-capturable); fa_fwd_launch_timed blocks on its stop event.  State:
+ *   - fa_fwd_launch, fa_fwd_launch_timed, fa_fwd_launch_masked and fa_fwd_launch_ex with
+ *     speculative = 0 or 1 are STATELESS, as the reference's launcher is
+ *     (src/flash_attention.cu:42,118,126-131): nothing but the const kernel registry and
+ *     the one-time per-device setup (fa_init) outlives a call, the same inputs give the
+ *     same bits from any thread, process or stream.
+ *   - fa_fwd_launch_ex with speculative = 2 (FA_SPECULATIVE_ADAPTIVE; what
+ *     flash_helpers.kernel_configs.best_config() asks for) is NOT: it keeps, per device and
+ *     per device variant, a small record (fa_adaptive_info) behind one mutex, one word of
+ *     pinned host memory the kernels report into and one event; which of two valid variants
+ *     serves a launch depends on that record, so the last bits of its output may differ from
+ *     run to run on data that makes the speculative softmax fail.  The record is per process
+ *     (two processes on one device do not see each other's).  See fa_speculative_mode.
  */
 #ifndef FA_HIP_H
 #define FA_HIP_H
@@ -152,8 +163,10 @@ typedef struct fa_fwd_stats {
  * launch is enqueued and never waits for the device.  Both variants compute the same real result within the same
  * tolerance (they round P at different points), so WHICH of the two served a launch -- which depends on when a report
  * arrived -- is visible only in the last bits: ask for 0 or 1 where bit-reproducible output matters.  A launch made
- * during a stream capture is always speculative (nothing adaptive is recorded into a graph).  State per device:
- * fa_adaptive_state / fa_adaptive_reset. */
+ * during a stream capture is always speculative (nothing adaptive is recorded into a graph).  State per device AND per
+ * device variant (ABI 5: a failing fp16 layer no longer demotes a benign bf16 one on the same device, and a probe's verdict
+ * belongs to the configuration that probed): fa_adaptive_state (the device's records taken together),
+ * fa_adaptive_state_for (one configuration's), fa_adaptive_reset (all of the device's). */
 typedef enum fa_speculative_mode {
     FA_SPECULATIVE_OFF = 0,
     FA_SPECULATIVE_ALWAYS = 1,
@@ -162,7 +175,7 @@ typedef enum fa_speculative_mode {
 
 typedef struct fa_adaptive_info {
     uint32_t available;      /* 1: the pinned report word exists on this device (else ADAPTIVE behaves like ALWAYS) */
-    uint32_t launches;       /* adaptive launches enqueued on the device so far */
+    uint32_t launches;       /* adaptive launches enqueued so far (fa_adaptive_state: summed over the device's records) */
     uint32_t demoted;        /* ... of which took the non-speculative variant */
     uint32_t reports;        /* distinct failure reports acted on */
     uint32_t hold;           /* current length of a demotion, in adaptive launches */
@@ -239,6 +252,9 @@ int fa_fwd_launch_ex(const fa_fwd_args *args, const fa_fwd_opts *opts, void *str
 /* The adaptive speculative mode's record on `device` (fa_speculative_mode), and a reset of its demotion state (tests,
  * or a caller that knows its data has changed character). */
 int fa_adaptive_state(int device, fa_adaptive_info *out);
+/* ... of the ONE device variant that serves cfg with these options when it runs speculatively (opts may be NULL; its
+ * `speculative` field is ignored).  FA_ERR_NO_KERNEL if cfg has no speculative variant. */
+int fa_adaptive_state_for(int device, const fa_fwd_config *cfg, const fa_fwd_opts *opts, fa_adaptive_info *out);
 int fa_adaptive_reset(int device);
 /* The policy alone, on a fresh state and without a device (tests): launch i sees report_word[i] in the pinned word and
  * probe_state[i] for its outstanding probe (-1 none, 0 pending, 1 complete, 2 error); run[i] = 0 speculative, 1 the
@@ -255,8 +271,9 @@ int fa_get_kernel(int index, fa_kernel_info *out);
 int fa_get_kernel_sized(int index, fa_kernel_info *out, uint32_t out_size);
 int fa_fwd_query_sized(const fa_fwd_config *cfg, const fa_fwd_opts *opts, fa_kernel_info *out, uint32_t out_size);
 
-/* Increases whenever a struct of this header grows or an entry point changes meaning (4 = this header). */
-#define FA_ABI_VERSION 4
+/* Increases whenever a struct of this header grows or an entry point changes meaning (5 = this header: the adaptive
+ * record is per device variant, fa_adaptive_state_for added). */
+#define FA_ABI_VERSION 5
 int fa_abi_version(void);
 
 /* Message for the last non-zero status on this thread ("" if none). */

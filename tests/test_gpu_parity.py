@@ -720,7 +720,7 @@ def test_jitter_build_matches_the_product_bit_for_bit():
 
 def test_adaptive_speculative_mode_demotes_after_a_reported_redo():
     """fa_speculative_mode ADAPTIVE (include/fa_hip.h; what best_config() asks for): a speculative launch that had to
-    compute items twice stores its sequence number into the device's pinned report word; the adaptive launches enqueued
+    compute items twice stores its sequence number into the pinned report word of ITS device variant (ABI 5); the adaptive launches enqueued
     after the library has seen that report take the non-speculative variant for `hold` launches, then the speculative one
     is probed again.  Outputs are inside the tolerance whichever variant served."""
     from flash_attention_from_scratch_amd import _capi
@@ -736,11 +736,11 @@ def test_adaptive_speculative_mode_demotes_after_a_reported_redo():
         flash_attention.forward(cfg, q, k, v)
         torch.cuda.synchronize()
         _capi.adaptive_reset(dev)
-        st0 = _capi.adaptive_state(dev)
+        st0 = _capi.adaptive_state(dev, cfg)
         assert st0["available"] == 1
         outs = [flash_attention.forward(cfg, q, k, v) for _ in range(6)]
         torch.cuda.synchronize()
-        st1 = _capi.adaptive_state(dev)
+        st1 = _capi.adaptive_state(dev, cfg)
         assert st1["launches"] == st0["launches"] + 6 and st1["demoted"] == 0 and st1["reports"] == 0
         want = flash_attention.forward(spec, q, k, v)
         assert all(torch.equal(o, want) for o in outs)
@@ -755,11 +755,11 @@ def test_adaptive_speculative_mode_demotes_after_a_reported_redo():
         assert stats[1].item() > 0          # (the always-speculative variant does redo items on this input)
         first = flash_attention.forward(cfg, qs, ks, vs)      # adaptive, still speculative: fails, reports
         torch.cuda.synchronize()
-        st2 = _capi.adaptive_state(dev)
+        st2 = _capi.adaptive_state(dev, cfg)
         assert st2["last_report"] == st2["launches"] and st2["demoted"] == 0
         demoted = [flash_attention.forward(cfg, qs, ks, vs) for _ in range(5)]
         torch.cuda.synchronize()
-        st3 = _capi.adaptive_state(dev)
+        st3 = _capi.adaptive_state(dev, cfg)
         assert st3["reports"] == 1 and st3["demoted"] == 5 and st3["mode"] == 1 and st3["remaining"] == st3["hold"] - 5
         want_lazy = flash_attention.forward(lazy, qs, ks, vs)
         assert all(torch.equal(o, want_lazy) for o in demoted)      # the demoted launches ARE the lazy variant
@@ -773,21 +773,21 @@ def test_adaptive_speculative_mode_demotes_after_a_reported_redo():
         for _ in range(hold - 5):
             flash_attention.forward(cfg, qs, ks, vs)
         torch.cuda.synchronize()
-        assert _capi.adaptive_state(dev)["demoted"] == hold
+        assert _capi.adaptive_state(dev, cfg)["demoted"] == hold
         probe = flash_attention.forward(cfg, qs, ks, vs)      # the probe: speculative again, an event recorded behind it
-        assert _capi.adaptive_state(dev)["mode"] == 2 and torch.equal(probe, first)
+        assert _capi.adaptive_state(dev, cfg)["mode"] == 2 and torch.equal(probe, first)
         torch.cuda.synchronize()
         flash_attention.forward(cfg, qs, ks, vs)      # sees the probe's report: a longer hold
-        st4 = _capi.adaptive_state(dev)
+        st4 = _capi.adaptive_state(dev, cfg)
         assert st4["reports"] == 2 and st4["hold"] == 2 * hold and st4["demoted"] == hold + 1 and st4["mode"] == 1
         # 4. the data turns benign: the probe behind the (longer) hold succeeds and the device is back to NORMAL
         for _ in range(st4["remaining"]):
             flash_attention.forward(cfg, q, k, v)
         ok_probe = flash_attention.forward(cfg, q, k, v)
-        assert _capi.adaptive_state(dev)["mode"] == 2 and torch.equal(ok_probe, want)
+        assert _capi.adaptive_state(dev, cfg)["mode"] == 2 and torch.equal(ok_probe, want)
         torch.cuda.synchronize()
         flash_attention.forward(cfg, q, k, v)
-        st5 = _capi.adaptive_state(dev)
+        st5 = _capi.adaptive_state(dev, cfg)
         assert st5["mode"] == 0 and st5["hold"] == 32 and st5["reports"] == 2
         _capi.adaptive_reset(dev)
 
@@ -810,7 +810,7 @@ def test_speculative_request_is_dropped_where_the_masked_form_has_no_speculative
 
 
 def test_adaptive_mode_from_two_threads_on_two_streams():
-    """The adaptive mode's per-device state is shared by every caller on the device: two host threads, each on its own
+    """The adaptive mode's record of a device variant is shared by every caller of that configuration on the device: two host threads, each on its own
     stream -- one feeding benign data, one data that makes the speculative pass fail -- launch concurrently.  Every output is
     inside the tolerance (whichever variant served it), the counters add up, nothing deadlocks (a probe holds the policy
     lock across its launch and event record)."""
@@ -828,7 +828,7 @@ def test_adaptive_mode_from_two_threads_on_two_streams():
     refs = {"benign": ut.py_flash_attention(q, k, v, upcast=True).float(), "spiky": ut.py_flash_attention(qs, ks, v, upcast=True).float()}
     torch.cuda.synchronize()
     _capi.adaptive_reset(dev)
-    before = _capi.adaptive_state(dev)["launches"]
+    before = _capi.adaptive_state(dev, cfg)["launches"]
     outs, errors = {"benign": [], "spiky": []}, []
     n_each = 60
 
@@ -850,7 +850,7 @@ def test_adaptive_mode_from_two_threads_on_two_streams():
         t.join(timeout=300)
     assert not any(t.is_alive() for t in threads) and not errors, errors
     torch.cuda.synchronize()
-    after = _capi.adaptive_state(dev)
+    after = _capi.adaptive_state(dev, cfg)
     assert after["launches"] == before + 2 * n_each and after["reports"] >= 1 and 0 < after["demoted"] <= 2 * n_each
     for name, ref in refs.items():
         tol = TOL[dtype] * (1 + ref.abs())
@@ -1619,3 +1619,97 @@ def test_reference_side_binding_runs(tmp_path):
         with pytest.raises(RuntimeError, match="Kernel configuration dtype does not match input dtype"):
             other = torch.float16 if dtype == torch.bfloat16 else torch.bfloat16
             ext.forward(cfg, q.to(other), k.to(other), v.to(other), None)
+
+
+def test_default_config_keeps_state_and_says_so():
+    """SURVEY 8b, threading / streams: the reference's launcher is stateless (src/flash_attention.cu:42,118,126-131).  This
+    library's DEFAULT configuration (best_config(): the adaptive speculative softmax) is not, and include/fa_hip.h says which
+    entry points are.  This test runs WITHOUT the fixture's reset between its steps and pins what the header documents:
+    1. heavy data through the default config: every output inside the tolerance, but the launches do NOT all give the same
+       bits -- the first ones are the speculative variant's, the ones behind the failure report the lazy variant's;
+    2. the record is per device variant: while that configuration is demoted, the fp16 default on benign data (another
+       variant on the same device) stays NORMAL and bit-identical to its always-speculative form (round 4: one record
+       per device, so it was demoted too: ADVICE r04);
+    3. the stateless entry points (speculative 0 / 1) are unaffected by any record: same bits before and after."""
+    from flash_attention_from_scratch_amd import _capi
+    dev = torch.cuda.current_device()
+    cfg = kc.best_config(kc.DType.BF16, 1024)
+    spec, lazy = replace(cfg, adaptive_softmax=False), replace(cfg, speculative_softmax=False)
+    gen = torch.Generator(device=DEV).manual_seed(2024)
+    q, k, v = (torch.randn((2, 1024, 8, 128), dtype=torch.bfloat16, device=DEV, generator=gen) for _ in range(3))
+    u = _sign_vector(5).to(torch.bfloat16)
+    k[1, 3, 2] = 30.0 * u
+    q[1, 600:604, 2] = 30.0 * u
+    want_spec, want_lazy = flash_attention.forward(spec, q, k, v), flash_attention.forward(lazy, q, k, v)
+    assert not torch.equal(want_spec, want_lazy)   # (the two roundings differ on this input: otherwise nothing to document)
+    eager = ut.py_flash_attention(q, k, v, upcast=True).float()
+    outs = []
+    for i in range(24):
+        outs.append(flash_attention.forward(cfg, q, k, v))
+        if i % 4 == 3:
+            torch.cuda.synchronize()      # (a caller's host work: reports land)
+    torch.cuda.synchronize()
+    for o in outs:
+        assert ((o.float() - eager).abs() <= TOL[torch.bfloat16] * (1 + eager.abs())).all()
+    kinds = ["spec" if torch.equal(o, want_spec) else ("lazy" if torch.equal(o, want_lazy) else "?") for o in outs]
+    assert "?" not in kinds and kinds[0] == "spec" and kinds[-1] == "lazy", kinds   # not reproducible from launch to launch, by design
+    st = _capi.adaptive_state(dev, cfg)
+    assert st["reports"] >= 1 and st["demoted"] >= 1 and st["mode"] == 1
+    # 2. another variant on the same device is not touched
+    cfg16 = kc.best_config(kc.DType.FP16, 1024)
+    g2 = torch.Generator(device=DEV).manual_seed(7)
+    q16, k16, v16 = (torch.randn((2, 1024, 8, 128), dtype=torch.float16, device=DEV, generator=g2) for _ in range(3))
+    o16 = [flash_attention.forward(cfg16, q16, k16, v16) for _ in range(4)]
+    torch.cuda.synchronize()
+    st16 = _capi.adaptive_state(dev, cfg16)
+    assert st16["demoted"] == 0 and st16["mode"] == 0 and st16["reports"] == 0
+    want16 = flash_attention.forward(replace(cfg16, adaptive_softmax=False), q16, k16, v16)
+    assert all(torch.equal(o, want16) for o in o16)
+    assert _capi.adaptive_state(dev, cfg)["mode"] == 1          # ... and the bf16 one is still demoted
+    assert _capi.adaptive_state(dev)["demoted"] == _capi.adaptive_state(dev, cfg)["demoted"]   # (the device view: records summed)
+    # 3. the stateless entry points
+    assert torch.equal(flash_attention.forward(spec, q, k, v), want_spec) and torch.equal(flash_attention.forward(lazy, q, k, v), want_lazy)
+    _capi.adaptive_reset(dev)
+
+
+def test_adaptive_record_is_per_process():
+    """Two processes on one device: each has its own libfa_hip.so, its own pinned report words and its own records (the
+    header's 'per process').  A child process drives the default configuration into demotion on heavy data; this process'
+    record of the same configuration does not move and its next default launch is still the speculative variant."""
+    import json
+    import subprocess
+    import sys
+    from flash_attention_from_scratch_amd import _capi
+    dev = torch.cuda.current_device()
+    cfg = kc.best_config(kc.DType.BF16, 1024)
+    gen = torch.Generator(device=DEV).manual_seed(99)
+    q, k, v = (torch.randn((2, 1024, 8, 128), dtype=torch.bfloat16, device=DEV, generator=gen) for _ in range(3))
+    before = _capi.adaptive_state(dev, cfg)
+    child = r"""
+import json, sys, torch
+sys.path.insert(0, %r)
+import flash_attention
+from flash_helpers import kernel_configs as kc
+from flash_attention_from_scratch_amd import _capi
+cfg = kc.best_config(kc.DType.BF16, 1024)
+g = torch.Generator(device="cuda:0").manual_seed(5)
+q, k, v = (torch.randn((2, 1024, 8, 128), dtype=torch.bfloat16, device="cuda:0", generator=g) for _ in range(3))
+g2 = torch.Generator().manual_seed(1005)
+u = ((torch.randint(0, 2, (128,), generator=g2).float() * 2 - 1) * 30.0).to(torch.bfloat16).to("cuda:0")
+k[1, 3, 2] = u
+q[1, 600:604, 2] = u
+for i in range(12):
+    flash_attention.forward(cfg, q, k, v)
+    if i %% 3 == 2:
+        torch.cuda.synchronize()
+torch.cuda.synchronize()
+print(json.dumps(_capi.adaptive_state(0, cfg)))
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", child], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    theirs = json.loads(r.stdout.strip().splitlines()[-1])
+    assert theirs["reports"] >= 1 and theirs["demoted"] >= 1 and theirs["launches"] == 12
+    mine = _capi.adaptive_state(dev, cfg)
+    assert mine["launches"] == before["launches"] and mine["demoted"] == before["demoted"] and mine["mode"] == 0
+    out = flash_attention.forward(cfg, q, k, v)
+    assert torch.equal(out, flash_attention.forward(replace(cfg, adaptive_softmax=False), q, k, v))

@@ -135,8 +135,10 @@ def test_one_flag_one_meaning_softmax_mode_of_every_config():
         assert kc.softmax_mode(best) == "speculative" and best.adaptive_softmax and best.speculative_softmax
         assert kc.parse_kernel_name_into_config(best.short_form()) == best
         assert replace(best, adaptive_softmax=False).short_form() == best.short_form().replace("+adaptive", "")
-    with pytest.raises(ValueError):  # adaptive qualifies speculative
-        replace(best, speculative_softmax=False)
+    # "never speculative" from the default in ONE step (round 4 raised ValueError here): adaptive qualifies
+    # speculative and is cleared with it
+    never = replace(best, speculative_softmax=False)
+    assert not never.adaptive_softmax and kc.softmax_mode(never) == "lazy" and "+adaptive" not in never.short_form()
     assert kc.softmax_mode(kc.best_config(kc.DType.BF16, 1000, masked=True), masked=True) == "speculative"
     assert kc.softmax_mode(kc.best_config(kc.DType.BF16, 100, masked=True), masked=True) == "eager"
 
@@ -555,9 +557,24 @@ def test_adaptive_mode_abi():
     """fa_speculative_mode / fa_adaptive_info (include/fa_hip.h): struct layout of the ctypes mirror, the version numbers."""
     assert ctypes.sizeof(_capi.FaAdaptiveInfo) == 8 * 4
     lib = _capi.load()
-    assert lib.fa_abi_version() == _capi.FA_ABI_VERSION == 4
+    assert lib.fa_abi_version() == _capi.FA_ABI_VERSION == 5
     header = open(os.path.join(ROOT, "include", "fa_hip.h")).read()
-    assert "#define FA_ABI_VERSION 4" in header and "FA_SPECULATIVE_ADAPTIVE = 2" in header
+    assert "#define FA_ABI_VERSION 5" in header and "FA_SPECULATIVE_ADAPTIVE = 2" in header
+    # the boundary row (SURVEY 8b threading / streams; the reference's launcher is stateless, src/flash_attention.cu:42,118,
+    # 126-131): the header says which entry points keep state, and no longer claims that none does
+    assert "no global mutable state" not in header and "STATELESS" in header and "per device variant" in header
+    # an out-of-range `speculative` is refused by supported / query / launch alike (ADVICE r04), without a device
+    cfg_c = _capi.make_config(kc.best_config(kc.DType.BF16))
+    bad = _capi.make_opts(speculative=True)
+    bad.speculative = 3
+    assert lib.fa_fwd_ex_supported(ctypes.byref(cfg_c), ctypes.byref(bad)) == 0
+    assert lib.fa_fwd_query(ctypes.byref(cfg_c), ctypes.byref(bad), ctypes.byref(_capi.FaKernelInfo())) == -4
+    assert "must be 0, 1 (always) or 2 (adaptive)" in _capi.last_error()
+    ok = _capi.make_opts(speculative="adaptive")
+    assert lib.fa_fwd_ex_supported(ctypes.byref(cfg_c), ctypes.byref(ok)) == 1
+    # the per-variant record answers without a device too (nothing initialised: zeros, hold 32)
+    st = _capi.adaptive_state(0, kc.best_config(kc.DType.FP16))
+    assert st["launches"] == 0 and st["mode"] == 0 and st["hold"] == 32
     assert _capi.make_opts(speculative="adaptive").speculative == 2 and _capi.make_opts(speculative=True).speculative == 1
     assert _capi.make_opts(speculative=False).speculative == 0
     info = _capi.FaKernelInfo()

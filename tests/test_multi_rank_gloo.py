@@ -108,7 +108,7 @@ def test_scale_command_dry_run_eight_ranks_on_c4():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
     res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--workload", "c4", "--warmup", "1",
-                          "--cpu-dry-run"], env=env, capture_output=True, text=True, timeout=600)
+                          "--cpu-dry-run", "--rocprof-rank", "3"], env=env, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stderr[-2000:]
     lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1
@@ -119,3 +119,14 @@ def test_scale_command_dry_run_eight_ranks_on_c4():
     assert rec["config"]["flop_per_step_per_gpu"] == 8796093022208          # C4 per GPU
     assert 8 * rec["config"]["flop_per_step_per_gpu"] == 70368744177664     # ... and the whole job
     assert rec["value"] <= sum(rec["per_gpu_tflops"]) * (1 + 1e-9)
+    # round 5: every rank's launcher is pinned to its own CPUs (on the GPU box: a slice of the NUMA node of
+    # its GPU; here: of whatever this box allows), and the line says where
+    aff = [g["affinity"] for g in rec["per_gpu"]]
+    assert len(aff) == 8 and all(a and a["pinned"] and a["n_cpus"] >= 1 for a in aff), aff
+    if len(os.sched_getaffinity(0)) >= 8:
+        assert len({a["cpus"] for a in aff}) == 8, aff          # distinct, non-overlapping
+    assert [a["rank"] for a in aff] == list(range(8))
+    # --rocprof-rank 3: the command rank 3 would replace itself with on the GPU box (not executed in a dry run)
+    cmd = rec["rocprof_command"]
+    assert rec["rocprof_rank"] == 3 and cmd[:3] == ["rocprofv3", "--kernel-trace", "--stats"] and "scale_rank3" in cmd
+    assert "--pmc" not in cmd and cmd[cmd.index("--") + 3:][:4] == ["--gpus", "8", "--workload", "c4"]
