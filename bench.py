@@ -458,23 +458,39 @@ def _gpu_numa_node(device_index):
     return None
 
 
-def pin_rank(rank, world, local_rank, gpu_node=None):
+def _format_cpulist(cpus):
+    """[0, 1, 2, 3, 8, 10, 11] -> '0-3,8,10-11'."""
+    out, i = [], 0
+    while i < len(cpus):
+        j = i
+        while j + 1 < len(cpus) and cpus[j + 1] == cpus[j] + 1:
+            j += 1
+        out.append(str(cpus[i]) if i == j else f"{cpus[i]}-{cpus[j]}")
+        i = j + 1
+    return ",".join(out)
+
+
+def pin_rank(rank, world, local_rank, gpu_nodes=None):
     """Pin this rank's process to its own slice of the CPUs of its GPU's NUMA node (the only resource N ranks
     share is the host -- 13-14 us of launch work per forward and rank, which should neither migrate between sockets nor
-    queue behind another rank's thread).  The ranks whose GPUs sit on one node split that node's CPUs evenly, in rank
-    order; a box without NUMA information (or a dry run) splits every allowed CPU the same way.  -> what was done, for the
-    JSON line."""
+    queue behind another rank's thread).  `gpu_nodes`: the NUMA node of every rank's GPU, in rank order (None entries, or
+    no list at all -- a dry run --, for "unknown").  The ranks whose GPUs sit on one node split that node's CPUs evenly, in
+    rank order; ranks without NUMA information split every allowed CPU the same way.  -> what was done, for the JSON line."""
     nodes = _numa_nodes()
-    order = sorted(nodes)
-    node = gpu_node if gpu_node in nodes else order[local_rank * len(order) // max(world, 1) % len(order)]
-    # how many ranks share the node, and which of them this one is (ranks are dealt to nodes in blocks, as GPUs are)
-    per_node = max(1, -(-world // len(order)))
-    slot = local_rank % per_node
-    cpus = nodes[node]
-    n = max(1, len(cpus) // per_node)
+    gpu_nodes = list(gpu_nodes) if gpu_nodes else [None] * world
+    mine_node = gpu_nodes[rank] if rank < len(gpu_nodes) else None
+    if mine_node in nodes:
+        peers = [r for r in range(world) if r < len(gpu_nodes) and gpu_nodes[r] == mine_node]
+        cpus, source = nodes[mine_node], "gpu numa_node"
+    else:
+        peers = [r for r in range(world) if not (r < len(gpu_nodes) and gpu_nodes[r] in nodes)]
+        cpus, source = sorted(c for cs in nodes.values() for c in cs), "no NUMA information for the device: CPUs split by rank"
+        mine_node = None
+    slot, per = peers.index(rank), len(peers)
+    n = max(1, len(cpus) // per)
     mine = cpus[slot * n:(slot + 1) * n] or cpus
-    info = {"rank": rank, "numa_node": node, "cpus": f"{mine[0]}-{mine[-1]}" if mine == list(range(mine[0], mine[-1] + 1)) else ",".join(map(str, mine)),
-            "n_cpus": len(mine), "source": "gpu numa_node" if gpu_node in nodes else "no NUMA information for the device: CPUs split by rank"}
+    info = {"rank": rank, "numa_node": mine_node, "cpus": _format_cpulist(mine), "n_cpus": len(mine),
+            "ranks_on_this_node": per, "source": source}
     try:
         os.sched_setaffinity(0, mine)
         info["pinned"] = True
@@ -868,7 +884,7 @@ def main():
     device = torch.device("cuda", local_rank)
     affinity = None
     if world > 1 and not args.no_pin:
-        affinity = pin_rank(rank, world, local_rank, _gpu_numa_node(local_rank))
+        affinity = pin_rank(rank, world, local_rank, [_gpu_numa_node(r % n_dev) for r in range(world)])
     reduce_device = device if args.dist_backend == "nccl" else torch.device("cpu")
     if world > 1:
         import torch.distributed as dist

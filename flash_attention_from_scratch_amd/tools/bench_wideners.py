@@ -14,17 +14,29 @@ from flash_helpers import kernel_configs as kc
 from flash_helpers.test import utils as ut
 
 
-def timed(fn, reps=20):
-    for _ in range(5):
-        fn()
-    torch.cuda.synchronize()
+def timed(fn, reps=20, warm_s=0.3, min_s=0.15):
+    """Mean ms per call: `warm_s` of untimed calls first (the clock governor needs load to leave idle -- bench.py's
+    precondition; with five warm-ups the 0.25-ms causal C1 launches read 5 % low: profiles/r05/wideners.txt vs
+    masked_probe.txt before this), then at least `reps` calls and `min_s` seconds between two events."""
+    import time
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < warm_s:
+        for _ in range(8):
+            fn()
+        torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    n = 0
+    t0 = time.perf_counter()
     e0.record()
-    for _ in range(reps):
-        fn()
+    while n < reps or time.perf_counter() - t0 < min_s:
+        for _ in range(reps):
+            fn()
+        n += reps
+        if n >= 16 * reps:
+            break
     e1.record()
     torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / reps
+    return e0.elapsed_time(e1) / n
 
 
 def main():
