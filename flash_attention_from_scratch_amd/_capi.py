@@ -56,6 +56,9 @@ class FaKernelInfo(ctypes.Structure):
         ("num_regs", ctypes.c_int32), ("scratch_bytes", ctypes.c_int32),
         ("rows_per_wave", ctypes.c_int32), ("masked", ctypes.c_int32),
         ("softmax_mode", ctypes.c_int32), ("prescaled_q", ctypes.c_int32),
+        # ABI 5: the ring form of a 32-rows-per-wave configuration (include/fa_hip.h)
+        ("ring_form", ctypes.c_int32), ("ring_softmax_mode", ctypes.c_int32),
+        ("ring_num_regs", ctypes.c_int32), ("ring_scratch_bytes", ctypes.c_int32),
     ]
 
 

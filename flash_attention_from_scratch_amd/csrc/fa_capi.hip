@@ -224,6 +224,9 @@ void do_init_body(int dev, DeviceState *st) {
             if (rc == hipSuccess && e.fn_ragged)
                 rc = hipFuncSetAttribute((const void *)e.fn_ragged, hipFuncAttributeMaxDynamicSharedMemorySize,
                                          e.lds_bytes);
+            if (rc == hipSuccess && e.fn_ring)
+                rc = hipFuncSetAttribute((const void *)e.fn_ring, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         e.ring_lds_bytes);
             if (rc != hipSuccess) {
                 st->status = FA_ERR_LAUNCH;
                 snprintf(st->err, sizeof(st->err), "hipFuncSetAttribute(%d B LDS) on device %d: %s",
@@ -349,15 +352,23 @@ int launch(const fa_fwd_args *a, const fa::KernelEntry *e, const DeviceState *de
     // (reference: dim3(n_Q_blocks, n_heads, batch), flash_attention.cu:110-112)
     // Persistent variants: one workgroup per CU (a multiple of 8, so an item keeps its XCD) that
     // walks items blockIdx.x, + gridDim.x, ... itself.
+    // the ring form of a 32-rows-per-wave configuration (KernelEntry::fn_ring): seq_len a multiple of 256
+    bool persistent = e->persistent != 0;
+    int lds_bytes = e->lds_bytes;
+    if (e->fn_ring && a->seq_len % 256 == 0 && !causal) {
+        fn = e->fn_ring;
+        lds_bytes = e->ring_lds_bytes;
+        persistent = true;
+    }
     unsigned n_wg = (unsigned)(ka.n_bh * ka.n_q_blocks);
-    if (e->persistent) {
+    if (persistent) {
         const unsigned cap = (unsigned)(dev->num_cus & ~7) ? (unsigned)(dev->num_cus & ~7) : 8u;
         if (n_wg > cap) n_wg = cap;
     }
     const dim3 grid(n_wg);
     const dim3 block((unsigned)e->threads);
     void *params[] = {&ka};
-    hipError_t rc = hipLaunchKernel((const void *)fn, grid, block, params, (size_t)e->lds_bytes, stream);
+    hipError_t rc = hipLaunchKernel((const void *)fn, grid, block, params, (size_t)lds_bytes, stream);
     if (rc != hipSuccess) return fail(FA_ERR_LAUNCH, "hipLaunchKernel: %s", hipGetErrorString(rc));
     return FA_OK;
 }
@@ -727,6 +738,17 @@ static void fill_info(const fa::KernelEntry &e, fa_kernel_info *out) {
         out->scratch_bytes = (int32_t)attr.localSizeBytes;
     } else {
         (void)hipGetLastError();  // no device: resource fields stay -1
+    }
+    out->ring_form = e.fn_ring ? 1 : 0;
+    out->ring_softmax_mode = e.fn_ring ? FA_SOFTMAX_LAZY : 0;
+    out->ring_num_regs = out->ring_scratch_bytes = e.fn_ring ? -1 : 0;
+    if (e.fn_ring) {
+        if (hipFuncGetAttributes(&attr, (const void *)e.fn_ring) == hipSuccess) {
+            out->ring_num_regs = attr.numRegs;
+            out->ring_scratch_bytes = (int32_t)attr.localSizeBytes;
+        } else {
+            (void)hipGetLastError();
+        }
     }
 }
 

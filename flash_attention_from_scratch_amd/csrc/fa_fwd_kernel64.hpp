@@ -125,6 +125,69 @@ constexpr bool plan64_ok(const Plan64 &p, int rot_k = 0) {
     return e == 32 && ee == rot_k && m == (chain ? 32 : 0) && d == 8;
 }
 
+// Geometry of the persistent ring kernel (its own traits: FwdTraits describes fa_fwd_kernel.hpp's kernels, whose QT = 1
+// forms have two LDS stages): 4 waves, 64-key tiles, d_head 128, four K and four V stages + 8 KB of staging per wave.
+template <int QT> struct RingTraits {
+    static constexpr int kRowsPerWave = 32 * QT;
+    static constexpr int kBr = kRowsPerWave * 4;
+    static constexpr int kTileBytes = 64 * 2 * 128;
+    static constexpr int kStages = 4;
+    static constexpr int kThreads = 256;
+    static constexpr int kLdsBytes = 2 * kStages * kTileBytes + 4 * 32 * 2 * 128;
+};
+
+// One Q tile per wave (QTP = 1 below): a visit is 32 MFMAs, one gap per operand step -- gaps 0..15 S(it+1) = K(it+1) Q^T
+// (step = 2 ks + nt), gaps 16..31 O += V(it) P(it) (step 16 + 4 s16 + t).  Per visit: 16 softmax units (u = 4 s16 + j),
+// 16 row-max units over S(it+1) (complete behind gap 15), the merged end-of-visit chain (steps 10..14), the 8 DMA
+// pieces at the even gaps 2..16 (each needs the gap before it for its M0), the barrier in gap 1; the operand wait and
+// the two reads of the next pair sit in the even gaps.  Unit u's P slice s16 = u / 4 is consumed from gap 16 + 4 s16.
+constexpr Plan64 make_plan32() {
+    Plan64 p{};
+    int e = 0, m = 0, d = 0;
+    for (int g = 0; g < 32; ++g) {
+        const int h = g - 16;
+        int ne = 0, nm = 0, dm = -1, tl = 0;
+        if ((g & 1) == 0 && g >= 2 && g <= 16) dm = d++;
+        if (g < 16) {
+            // 11 units: the odd gaps 3..15, and the even gaps 4, 8, 12, 14 (the lighter ones: no DMA issue cost twice)
+            if (g >= 3 && ((g & 1) || g == 4 || g == 8 || g == 12 || g == 14)) ne = 1;
+        } else {
+            if ((h & 1) && h <= 9) ne = 1;                       // units 11..15 at gaps 17, 19, 21, 23, 25
+            if (h <= 10) nm = (!(h & 1) && h < 10) ? 2 : 1;      // 2 1 2 1 2 1 2 1 2 1 1 = 16
+            if (h >= 11) tl = 10 + (h - 11);                     // merged chain steps 10..14
+        }
+        p.exp_first[g] = (signed char)e; p.exp_n[g] = (signed char)ne; e += ne;
+        p.max_first[g] = (signed char)m; p.max_n[g] = (signed char)nm; m += nm;
+        p.dma[g] = (signed char)dm; p.tail[g] = (signed char)tl;
+        p.barrier[g] = g == 1 ? 1 : 0;
+        p.early_first[g] = 0; p.early_n[g] = 0;
+    }
+    for (int g = 32; g < 64; ++g) { p.dma[g] = -1; }
+    return p;
+}
+constexpr int plan_barrier_gap(const Plan64 &p, int n_gaps) {
+    for (int g = 0; g < n_gaps; ++g)
+        if (p.barrier[g]) return g;
+    return -1;
+}
+constexpr bool plan32_ok(const Plan64 &p) {
+    int e = 0, m = 0, d = 0, bar = -1;
+    for (int g = 0; g < 32; ++g) {
+        for (int u = p.exp_first[g]; u < p.exp_first[g] + p.exp_n[g]; ++u)
+            if (g + 2 > 16 + 4 * (u >> 2)) return false;             // packed >= 2 gaps before its slice is consumed
+        // S(it+1): nt = 0 last written at gap 14, nt = 1 at gap 15; read >= 2 MFMAs later
+        for (int u = p.max_first[g]; u < p.max_first[g] + p.max_n[g]; ++u)
+            if (g < ((u >> 3) ? 17 : 16)) return false;
+        if (p.tail[g] == 10 && m < 16) return false;
+        if (p.barrier[g]) bar = g;
+        if (p.dma[g] >= 0 && (bar < 0 || g <= bar)) return false;    // DMA overwrites what the barrier frees
+        if (p.dma[g] >= 0 && g > 0 && p.dma[g - 1] >= 0) return false;
+        if (p.barrier[g] && g >= 28) return false;                   // K(it+2) is first read at gap 30
+        e += p.exp_n[g]; m += p.max_n[g]; d += p.dma[g] >= 0;
+    }
+    return e == 16 && m == 16 && d == 8 && bar >= 0;
+}
+
 // (the reference's meaning of optimized_softmax -- the first tile skips the rescale -- holds here by
 // construction, so the flag changes nothing on this kernel; SPEC and PSQ below are asked for through fa_fwd_opts)
 // ABL: 0 in the product.  tools/tune64.hip instantiates the kernel with experiment / timing-only bits so that a
@@ -154,18 +217,26 @@ constexpr bool plan64_ok(const Plan64 &p, int rot_k = 0) {
 // -(m c) rides in the C operand of each S tile's first MFMA (a 16-register splat per Q tile, constant over the item)
 // and the softmax unit is just exp2, row sum, pack: 160 instead of 224 vector instructions per visit.  The second pass
 // (running max, which moves) adds -(m c) with one v_add per logit where the exact kernel has its v_fma.
-template <int DT, bool MASK = false, int ABL = 0, bool RAG = false, bool SPEC = false, bool PSQ = false>
+// QTP (round 5): 32-row Q tiles per wave.  2 = the kernel described above, (B_r 256, B_c 64, 4 waves).  1 = the same
+// machinery -- rings, counted waits, persistent walk, three-region item loop, hand-placed gaps -- for the reference's own
+// winning tile shape (B_r 128, B_c 64, 4 warps) + buffer (kernel_sass/16_A100.asm:5, kernel_configs.py:389-423): one
+// 32-row Q tile per wave, 128-row items, 32 MFMAs per visit, every K / V operand read feeds ONE MFMA (1.5 LDS operand
+// reads per MFMA instead of 0.75).  Built plain, with the running max (lazy rescale): what a reference user's 13-field
+// config asks for.  Needs seq_len % 256 == 0 like the 64-row form (four ring stages = four tiles to a group); the
+// compiler-scheduled 32-rows-per-wave body of fa_fwd_kernel.hpp serves the other multiples of 128.
+template <int DT, bool MASK = false, int ABL = 0, bool RAG = false, bool SPEC = false, bool PSQ = false, int QTP = 2>
 __global__ void
 __launch_bounds__(256, 1)
 fa_fwd_kernel64(const KernelArgs args) {
     static_assert(!RAG || MASK, "the ragged form is a masked variant");
     static_assert(!PSQ || !MASK, "the pre-scaled Q is built for the plain form");
-    constexpr int QT = 2, NWAVES = 4, BC = 64, D = 128;
+    static_assert(QTP == 2 || (QTP == 1 && !MASK && !RAG && !SPEC && !PSQ), "one Q tile per wave: the plain form with the running max");
+    constexpr int QT = QTP, NWAVES = 4, BC = 64, D = 128;
     constexpr bool SWZ = true, EAGER = true, PIPE = true, DMA = true;
 
     using E = Elem<DT>;
     using vec8 = typename E::vec8;
-    using TR = FwdTraits<DT, QT, NWAVES, BC, SWZ, EAGER, false, PIPE, DMA, MASK, D>;
+    using TR = RingTraits<QT>;
 #if defined(FA_TRACE) && FA_TRACE == 3
 #define FA_TL() tl()
 #define FA_TLP(i) tl_stamp(i)
@@ -464,7 +535,7 @@ fa_fwd_kernel64(const KernelArgs args) {
             // reference's eager rescale (softmax.cuh:36-49); only the rounding point of P differs,
             // with the same relative error.  With O in the accumulator file a rescale costs ~200
             // issue slots per Q tile, and for random data some row of 32 finds a new max in most tiles.
-            static_assert(DMA && D == 128 && BC == 64 && NT == 2 && NWAVES == 4, "64-row pinned schedule");
+            static_assert(DMA && D == 128 && BC == 64 && NT == 2 && NWAVES == 4, "pinned schedule");
             static_assert(TR::kStages == 4, "ring depth");
             constexpr float TAU = 8.0f;
             // rotated units (make_plan64): ABL bits 24..27 = rot_k for tools/tune64.hip (15 = off, 0 = the shipped value),
@@ -472,17 +543,20 @@ fa_fwd_kernel64(const KernelArgs args) {
             constexpr int ROT_REQ = (ABL >> 24) & 15;
             constexpr int ROT_K = (FAST && !MASK) ? (ROT_REQ == 15 ? 0 : (ROT_REQ ? ROT_REQ : FA_ROT_DEFAULT)) : 0;
             constexpr int CHAIN_GAP = (FAST && (ABL & (1 << 28))) ? 58 : 63;
-            constexpr Plan64 plan = make_plan64(((ABL >> 8) & 3) | (MASK ? 4 : 0) | (FAST ? 8 : 0) | ((ABL & 8192) ? 16 : 0),
-                                                ((ABL & 1024) ? 20 : ((ABL & 16384) ? 23 : 22)) - ROT_K, ROT_K, CHAIN_GAP);
-            static_assert(plan64_ok(plan, ROT_K), "filler plan violates a wait-state distance");
-            f32x16 Sa[2][NT], Sb[2][NT];
-            u32x4 Pw[2][4] = {};     // P[qt][16-key slice]: B operand of O^T += V^T P^T
-            float neg_msc[2];        // -(m c)
-            float thr[2];            // m + TAU / c: a row max above it moves the reference max
+            constexpr Plan64 plan = QT == 1 ? make_plan32()
+                                            : make_plan64(((ABL >> 8) & 3) | (MASK ? 4 : 0) | (FAST ? 8 : 0) | ((ABL & 8192) ? 16 : 0),
+                                                          ((ABL & 1024) ? 20 : ((ABL & 16384) ? 23 : 22)) - ROT_K, ROT_K, CHAIN_GAP);
+            static_assert(QT == 1 ? plan32_ok(plan) : plan64_ok(plan, ROT_K), "filler plan violates a wait-state distance");
+            constexpr int GAPS = 32 * QT, PH2 = 16 * QT;   // MFMAs of a visit; the first one of phase 2 (O += V P)
+            constexpr int BAR_GAP = plan_barrier_gap(plan, GAPS);   // -1: the sync point sits at the visit's top
+            f32x16 Sa[QT][NT], Sb[QT][NT];
+            u32x4 Pw[QT][4] = {};     // P[qt][16-key slice]: B operand of O^T += V^T P^T
+            float neg_msc[QT];       // -(m c)
+            float thr[QT];           // m + TAU / c: a row max above it moves the reference max
             // running row sums (fp32 P, before rounding: softmax.cuh:66-83), two chains per Q tile; l = their
             // sum, taken in the epilogue (the reference adds a per-tile sum to l: same terms, other order)
-            float rs[2][2] = {{0.0f, 0.0f}, {0.0f, 0.0f}};
-            float m_pend[2];         // candidate reference max found during the previous visit
+            float rs[QT][2] = {};
+            float m_pend[QT];        // candidate reference max found during the previous visit
             unsigned resc_any = 0;   // bit qt: Q tile qt moves its reference max at the next visit's top
             auto k_frag = [&](const char *kt, int step) -> vec8 {  // step = 2*ks + nt
                 const int ks = step >> 1, nt = step & 1;
@@ -499,17 +573,17 @@ fa_fwd_kernel64(const KernelArgs args) {
             // PSQ, speculative first pass: C operand of the first MFMA of every S tile = -(m c) of the row this lane
             // owns, 16 equal registers per Q tile, constant over an item.  Zero while the NEXT item's S(0) is formed (an
             // item's last visit, and the prologue): its reference is its own row max, subtracted once it is known.
-            f32x16 Cinit[2];
+            f32x16 Cinit[QT];
             if constexpr (PSQ && FAST) {
 #pragma unroll
-                for (int qt = 0; qt < 2; ++qt)
+                for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) Cinit[qt][r] = 0.0f;
             }
             auto zero_cinit = [&]() {
                 if constexpr (PSQ && FAST) {
 #pragma unroll
-                    for (int qt = 0; qt < 2; ++qt)
+                    for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
                         for (int r = 0; r < 16; ++r) Cinit[qt][r] = 0.0f;
                     asm volatile("s_nop 1" : "+v"(Cinit[0]), "+v"(Cinit[1]));  // VALU write -> MFMA C read
@@ -518,7 +592,7 @@ fa_fwd_kernel64(const KernelArgs args) {
             auto set_cinit = [&](auto &S0) {  // S0 = the item's S(0), formed against C = 0: bring it to the reference too
                 if constexpr (PSQ && FAST) {
 #pragma unroll
-                    for (int qt = 0; qt < 2; ++qt) {
+                    for (int qt = 0; qt < QT; ++qt) {
 #pragma unroll
                         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -584,7 +658,7 @@ fa_fwd_kernel64(const KernelArgs args) {
                     if (delta > 0) {  // wave-uniform: the last tiles of a sequence only
                         const int lim = delta - 4 * hi;
 #pragma unroll
-                        for (int qt = 0; qt < 2; ++qt)
+                        for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
                             for (int nt = (only_nt < 0 ? 0 : only_nt); nt < (only_nt < 0 ? NT : only_nt + 1); ++nt)
 #pragma unroll
@@ -594,7 +668,7 @@ fa_fwd_kernel64(const KernelArgs args) {
                     const int row_min = 256 * qb_rows + 64 * wave;  // this wave's first row
                     if (causal && r0 + 63 > row_min) {  // wave-uniform: some key of the window lies above some row's diagonal
 #pragma unroll
-                        for (int qt = 0; qt < 2; ++qt) {
+                        for (int qt = 0; qt < QT; ++qt) {
                             const int lim = row_min + 32 * qt + r31 - r0 - 4 * hi;  // key-in-window > lim: above the diagonal
 #pragma unroll
                             for (int nt = (only_nt < 0 ? 0 : only_nt); nt < (only_nt < 0 ? NT : only_nt + 1); ++nt)
@@ -607,7 +681,7 @@ fa_fwd_kernel64(const KernelArgs args) {
                     const int d = tile - (4 * qb_rows + wave);
                     if (causal && d >= 0) {  // wave-uniform
 #pragma unroll
-                        for (int qt = 0; qt < 2; ++qt)
+                        for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
                             for (int nt = (only_nt < 0 ? 0 : only_nt); nt < (only_nt < 0 ? NT : only_nt + 1); ++nt)
 #pragma unroll
@@ -643,11 +717,13 @@ fa_fwd_kernel64(const KernelArgs args) {
             // in front of step s+2 is gone: eight s_waitcnt fewer per visit.  Measured +0.2 % at S = 4096, 0 at 16384
             // (profiles/r05/tune64_ring8_wait4.txt; the eight-slot ring alone: +0.1 %, profiles/r04/ring_slots_4_vs_8.txt):
             // a satisfied s_waitcnt is not what the issue-bound stream pays for.  Not adopted (16 registers).
+            // (One Q tile per wave: a step is ONE gap there, so the four-slot ring reads only two gaps ahead; eight slots -- six
+            // gaps -- measured +0.3 %: that form is issue bound too, 7.9 instructions per MFMA, not latency bound.)
             constexpr int RS = ((ABL & 64) && !PSQ) ? 8 : FA_RING_SLOTS, LA = RS - 2;
             constexpr bool WAIT4 = RS >= 8;
             vec8 ring[RS];
-            vec8 Qr2[2][KS];  // the next item's Q (AGPRs), requested during the item's first visit
-            float mraw[2];   // row max of the S tile formed by the last visit (the next item's S(0))
+            vec8 Qr2[QT][KS];  // the next item's Q (AGPRs), requested during the item's first visit
+            float mraw[QT];  // row max of the S tile formed by the last visit (the next item's S(0))
             // the first two visits after a seam: the epilogue's row stores are in flight in front of the pieces
             // the counted waits allow -- 16 of them, or fewer (RAG: a wave whose rows reach beyond the sequence
             // skips stores; counted down to a multiple of 8, which only waits for more)
@@ -734,11 +810,11 @@ fa_fwd_kernel64(const KernelArgs args) {
             // the first unit of a Q tile starts them: no add), folded into rs by the next visit; SUM_NONE nowhere (the guard's
             // rare path forming the early units' packed P again)
             constexpr int SUM_RS = 0, SUM_EARLY = 1, SET_EARLY = 2, SUM_NONE = 3;
-            float rs_e[2][2] = {{0.0f, 0.0f}, {0.0f, 0.0f}};
+            float rs_e[QT][2] = {};
             auto exp_unit_on = [&](auto &S_src, int u, auto sum_tag) {
                 constexpr int SUM = decltype(sum_tag)::value;
                 if constexpr (ABL & 2) return;
-                const int qt = u & 1, j = (u >> 1) & 3, s16 = u >> 3, r = 8 * (s16 & 1) + 2 * j;
+                const int qt = u % QT, j = (u / QT) & 3, s16 = u / (4 * QT), r = 8 * (s16 & 1) + 2 * j;   // QT = 2: u = 8 s16 + 2 j + qt
                 // exp2(s c - m c), softmax.cuh:51-64.  Scalar f32 forms on purpose: v_pk_fma_f32 /
                 // v_pk_add_f32 here measured -6 % / -12 %; splitting the unit into stages over three
                 // gaps (no dependent pair inside a gap) measured -1.5 %.
@@ -840,17 +916,18 @@ fa_fwd_kernel64(const KernelArgs args) {
                         return;
                     }
                     const int q8 = has_next ? 8 : 0;
-                    const int allow = (it < 2) ? 8 + seam_st + q8 : 8 + q8;
+                    // (it == 2: the pieces of Q tile 1, requested at visit 1 -- the 64-row form only)
+                    const int allow = (it < 2) ? 8 + seam_st + q8 : 8 + (QT == 2 ? q8 : 0);
                     if (allow == 8) asm volatile("s_waitcnt vmcnt(" FA_VM8 ")\n\ts_barrier" ::: "memory");
                     else if (allow == 16) asm volatile("s_waitcnt vmcnt(" FA_VM16 ")\n\ts_barrier" ::: "memory");
                     else if (allow == 24) asm volatile("s_waitcnt vmcnt(" FA_VM24 ")\n\ts_barrier" ::: "memory");
                     else asm volatile("s_waitcnt vmcnt(" FA_VM32 ")\n\ts_barrier" ::: "memory");
-                    if constexpr (R == 1 || R == 2) {
+                    if constexpr (R >= 1 && R <= QT) {   // (Q tile R - 1 of the next item: the wave has QT of them)
                         if (it == R && has_next) {
                             // Q tile R-1 landed (only pieces(R-1) are younger)
                             asm volatile("s_waitcnt vmcnt(" FA_VM8 ")" ::: "memory");
                             read_next_q(Qr2[R - 1]);
-                            if constexpr (R == 1) {
+                            if constexpr (R == 1 && QT == 2) {
                                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // ... and read: its image may be overwritten
                                 request_next_q(1);
                             }
@@ -862,7 +939,7 @@ fa_fwd_kernel64(const KernelArgs args) {
                     if (it + 1 == nkc && has_next) {
                         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the LDS reads into the spare set (visits 1, 2)
 #pragma unroll
-                        for (int qt = 0; qt < 2; ++qt)
+                        for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
                             for (int ks = 0; ks < KS; ++ks) {
                                 asm volatile("" : "+a"(Qr2[qt][ks]));  // value defined by the asm loads
@@ -872,7 +949,7 @@ fa_fwd_kernel64(const KernelArgs args) {
                         zero_cinit();  // this visit forms the NEXT item's S(0): no reference yet
                     }
                 }
-                if constexpr (plan.barrier[2] == 0) {
+                if constexpr (BAR_GAP < 0) {
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     sync_point();
                 }
@@ -881,7 +958,7 @@ fa_fwd_kernel64(const KernelArgs args) {
                 if (!FAST && resc_any) {  // wave-uniform, rare: move the reference max of one or both Q tiles
                     asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");  // MFMA D (O) -> VALU read
 #pragma unroll
-                    for (int qt = 0; qt < 2; ++qt) {
+                    for (int qt = 0; qt < QT; ++qt) {
                         if (!(resc_any & (1u << qt))) continue;
                         const float m_new = fmaxf(m[qt], m_pend[qt]);
                         const float alpha = __builtin_amdgcn_exp2f((m[qt] - m_new) * cs);
@@ -907,10 +984,10 @@ fa_fwd_kernel64(const KernelArgs args) {
                 }
                 const char *kt = smem + ((R + 1) & 3) * TILE;
                 const char *vt = smem + V_BASE + R * TILE;
-                float vm[2][2];
+                float vm[QT][2];
                 unsigned any01 = 0;
                 auto max_unit = [&](int u) {  // u = 0..31: tile (nt = u>>4, qt = (u>>3)&1), elements 2(u&7), +1
-                    const int nt = u >> 4, qt = (u >> 3) & 1, e = 2 * (u & 7), a = u & 1;  // two chains per Q tile
+                    const int nt = u / (8 * QT), qt = (u >> 3) % QT, e = 2 * (u & 7), a = u & 1;  // two chains per Q tile
                     if constexpr (ABL & 2) { vm[qt][a] = 0.0f; return; }
                     if constexpr (ABL & 4096) return;  // (timing only: no per-tile row max)
                     // asm forms: fmaxf() on MFMA results makes hipcc canonicalise both inputs first
@@ -931,18 +1008,22 @@ fa_fwd_kernel64(const KernelArgs args) {
                     if constexpr (FAST || (ABL & 4096)) { if (k < 8) return; }
                     if (k == 1) {
                         asm volatile("v_max_f32 %0, %0, %1" : "+v"(vm[0][0]) : "v"(vm[0][1]));
-                        asm volatile("v_max_f32 %0, %0, %1" : "+v"(vm[1][0]) : "v"(vm[1][1]));
+                        if constexpr (QT == 2) asm volatile("v_max_f32 %0, %0, %1" : "+v"(vm[QT - 1][0]) : "v"(vm[QT - 1][1]));
                     }
                     if (k == 2) vm[0][0] = lane_pair_max(vm[0][0]);
-                    if (k == 3) vm[1][0] = lane_pair_max(vm[1][0]);
+                    if (k == 3 && QT == 2) vm[QT - 1][0] = lane_pair_max(vm[QT - 1][0]);
                     if (k == 4) {
                         mraw[0] = m_pend[0] = vm[0][0];
-                        mraw[1] = m_pend[1] = vm[1][0];
-                        asm volatile("" : "+v"(m_pend[0]), "+v"(m_pend[1]));
+                        if constexpr (QT == 2) {
+                            mraw[QT - 1] = m_pend[QT - 1] = vm[QT - 1][0];
+                            asm volatile("" : "+v"(m_pend[0]), "+v"(m_pend[QT - 1]));
+                        } else {
+                            asm volatile("" : "+v"(m_pend[0]));
+                        }
                     }
                     if (k == 6 || k == 7) {
                         const int qt = k - 6;
-                        any01 |= (__ballot(m_pend[qt] > thr[qt]) != 0 ? 1u : 0u) << qt;
+                        if (qt < QT) any01 |= (__ballot(m_pend[qt < QT ? qt : 0] > thr[qt < QT ? qt : 0]) != 0 ? 1u : 0u) << qt;
                     }
                     if (k == 8) {
                         if constexpr (!FAST) resc_any = any01;
@@ -972,12 +1053,12 @@ fa_fwd_kernel64(const KernelArgs args) {
                 // latency is exposed at the visit seam
                 const char *kt_next = smem + ((R + 2) & 3) * TILE;
                 auto operand = [&](int u) -> vec8 {
-                    if constexpr (ABL & 4) return __builtin_bit_cast(vec8, Pw[u & 1][(u >> 1) & 3]);
+                    if constexpr (ABL & 4) return __builtin_bit_cast(vec8, Pw[u % QT][(u >> 1) & 3]);
                     return u < 16 ? k_frag(kt, u) : (u < 32 ? v_frag(vt, u - 16) : k_frag(kt_next, u - 32));
                 };
                 auto gap_body = [&](auto gap_tag) {
                     constexpr int g = decltype(gap_tag)::value;
-                    constexpr int step = g >> 1, qt = g & 1;
+                    constexpr int step = g / QT, qt = g % QT;
                     // An MFMA reads its A / B registers for a few cycles after it issues, and hipcc -- to
                     // which the MFMAs are opaque asm -- is free to hand a register that just died to the very
                     // next VALU instruction (seen: the pair-max temporary landing in the A operand of the
@@ -1005,7 +1086,7 @@ fa_fwd_kernel64(const KernelArgs args) {
                         ring[(step + LA) % RS] = operand(step + LA);
                         ring[(step + LA + 1) % RS] = operand(step + LA + 1);
                     }
-                    if constexpr (g < 32) {
+                    if constexpr (g < PH2) {
                         qk_mfma(S_nxt, step, qt, ring[step % RS]);
                     } else {
                         constexpr int s2 = step - 16, s16 = s2 >> 2, t = s2 & 3;
@@ -1015,11 +1096,11 @@ fa_fwd_kernel64(const KernelArgs args) {
                     if constexpr (g >= 48) asm volatile("s_memtime %0" : "=s"(ts[2 + g - 48]));  // fine trace of the visit's last 16 gaps
 #endif
                     if constexpr (qt == 0) asm volatile("" ::"v"(prev_a));
-                    if constexpr (g >= 33) {
-                        constexpr int pg = g - 1, ps2 = (pg >> 1) - 16;
-                        asm volatile("" ::"v"(Pw[pg & 1][ps2 >> 2]));  // B operand of the previous P.V MFMA
+                    if constexpr (g >= PH2 + 1) {
+                        constexpr int pg = g - 1, ps2 = (pg / QT) - 16;
+                        asm volatile("" ::"v"(Pw[pg % QT][ps2 >> 2]));  // B operand of the previous P.V MFMA
                     }
-                    if constexpr (g == 0) asm volatile("" ::"v"(Pw[1][3]));  // ... of the previous visit's last one
+                    if constexpr (g == 0) asm volatile("" ::"v"(Pw[QT - 1][3]));  // ... of the previous visit's last one
                     if constexpr (plan.barrier[g] != 0) sync_point();
                     if constexpr (MASK && (g == 34 || g == 35) && (!HOTB || (R == 3 && !HOT))) {
                         // S(it+1) is complete (last written at gap 31): causal mask, before its row max (whose units start at
@@ -1033,7 +1114,7 @@ fa_fwd_kernel64(const KernelArgs args) {
                             mask_tile(S_nxt, nkn - 1, qb_n, g - 34);
                         }
                     }
-                    if constexpr (g < 63 && plan.dma[g + 1] >= 0 && !(ABL & 16)) {
+                    if constexpr (g < GAPS - 1 && plan.dma[g + 1] >= 0 && !(ABL & 16)) {
                         // M0 (LDS destination) of the DMA piece of the NEXT gap: the write needs one instruction
                         // between it and the DMA, and that gap's MFMA is one (hipcc itself never touches M0 here)
                         constexpr int j = plan.dma[g + 1] >> 1;
@@ -1074,7 +1155,7 @@ fa_fwd_kernel64(const KernelArgs args) {
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 };
-                static_for<0, 64>([&](auto gap_tag) { gap_body(gap_tag); });
+                static_for<0, GAPS>([&](auto gap_tag) { gap_body(gap_tag); });
                 if constexpr (FAST && MASK && !HOTB) {
                     // masked forms, speculative: a wave's reference is the row max of the FIRST tile it visits that is
                     // not masked whole -- causal: its diagonal tile 4 qb + wave; ragged: the last tile that holds keys
@@ -1089,7 +1170,7 @@ fa_fwd_kernel64(const KernelArgs args) {
                     if (it + 1 < nkc && nkc - 2 - it == t_ref) {
                         asm volatile("s_nop 7" ::: "memory");
 #pragma unroll
-                        for (int qt = 0; qt < 2; ++qt) {
+                        for (int qt = 0; qt < QT; ++qt) {
                             float v0 = vmax2(S_nxt[qt][0][0], S_nxt[qt][0][1]), v1 = vmax2(S_nxt[qt][1][0], S_nxt[qt][1][1]);
 #pragma unroll
                             for (int r = 2; r < 16; r += 2) {
@@ -1131,7 +1212,7 @@ fa_fwd_kernel64(const KernelArgs args) {
                     asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");  // the last P.V MFMAs -> VALU reads of O
                     float nonfinite = 0.0f;  // sum of (o - o): 0 while every element of O is finite, NaN otherwise
 #pragma unroll
-                    for (int qt = 0; qt < 2; ++qt) {
+                    for (int qt = 0; qt < QT; ++qt) {
                         const float lq = pair_max(qt ? l1 : l0);      // the two lanes of a row decide together
                         if (__ballot(!(lq < kLimit)) != 0) item_bad = true;
                         const bool big = !(lq <= kResc);
@@ -1202,13 +1283,16 @@ fa_fwd_kernel64(const KernelArgs args) {
             // K(2), V(1) | K(3), V(2) under S(0), in the order the counted waits assume.
             FA_TLP(0);  // K(0) requested, next item known
             request_q(Qg, qb, 0, q_stage);
-            request_q(Qg, qb, 1, smem_base + (wave < 2 ? 3 * TILE : V_BASE + 3 * TILE) + (wave & 1) * 8192);
+            if constexpr (QT == 2) request_q(Qg, qb, 1, smem_base + (wave < 2 ? 3 * TILE : V_BASE + 3 * TILE) + (wave & 1) * 8192);
             dma_k(tile_g(Kc, Kn, 1), 1);
             dma_v(tile_g(Vc, Vn, 0), 0);
             FA_TLP(1);  // Q, K(1), V(0) requested
             // S(0) of the wave's first 32 rows needs only K(0) and Q tile 0, which land ~1.5 k cycles before Q tile 1
             // (the requests return in issue order at the CU's start-up rate): start on them, take tile 1 when it is in
-            if (!(ABL & 8)) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");  // K(0), Q tile 0 landed: Q tile 1, K(1), V(0) fly on
+            if (!(ABL & 8)) {  // K(0), Q tile 0 landed: [Q tile 1,] K(1), V(0) fly on
+                if constexpr (QT == 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            }
             FA_TLP(2);  // K(0), Q tile 0 landed
             read_q(Qr[0], q_stage);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1221,10 +1305,12 @@ fa_fwd_kernel64(const KernelArgs args) {
 #pragma unroll
                 for (int step = 0; step < 16; ++step) a_all[step] = k_frag(kt, step);
                 static_for<0, 16>([&](auto step_tag) { qk_mfma(Sa, decltype(step_tag)::value, 0, a_all[decltype(step_tag)::value]); });
-                if (!(ABL & 8)) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // Q tile 1 landed: K(1), V(0) fly on
-                read_q(Qr[1], smem_base + (wave < 2 ? 3 * TILE : V_BASE + 3 * TILE) + (wave & 1) * 8192);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                static_for<0, 16>([&](auto step_tag) { qk_mfma(Sa, decltype(step_tag)::value, 1, a_all[decltype(step_tag)::value]); });
+                if constexpr (QT == 2) {
+                    if (!(ABL & 8)) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // Q tile 1 landed: K(1), V(0) fly on
+                    read_q(Qr[QT - 1], smem_base + (wave < 2 ? 3 * TILE : V_BASE + 3 * TILE) + (wave & 1) * 8192);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    static_for<0, 16>([&](auto step_tag) { qk_mfma(Sa, decltype(step_tag)::value, QT - 1, a_all[decltype(step_tag)::value]); });
+                }
                 // the rest of the first requests, issued while the matrix pipe works through S(0): a CU keeps
                 // only ~32 KB of requests in flight, so asking for all 176 KB up front held the waves at the
                 // issue of the last pieces (~11 k cycles) long after K(0) and Q had landed
@@ -1246,7 +1332,7 @@ fa_fwd_kernel64(const KernelArgs args) {
                 for (int step = 0; step < 16; ++step) asm volatile("" ::"v"(a_all[step]));
                 mask_tile(Sa, nkc - 1, qb_c);
 #pragma unroll
-                for (int qt = 0; qt < 2; ++qt) {
+                for (int qt = 0; qt < QT; ++qt) {
                     float v = Sa[qt][0][0];
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt)
@@ -1290,7 +1376,7 @@ fa_fwd_kernel64(const KernelArgs args) {
                 const int r31 = lane & 31, hi = lane >> 5;
                 const int rsub = lane / CPR, chunk = lane & (CPR - 1);
 #pragma unroll
-                for (int qt = 0; qt < 2; ++qt) {
+                for (int qt = 0; qt < QT; ++qt) {
                     const float l_row = pair_sum(rs[qt][0] + rs[qt][1]);
                     if constexpr (FAST) {
                         // every P of the row is <= l: below the limit nothing overflowed on the way (fp32 exp2, the
@@ -1323,7 +1409,7 @@ fa_fwd_kernel64(const KernelArgs args) {
                         // one d tile at a time: S(0) of the next item is live (ABL & 131072, experiment: two at a time)
                         if (!(ABL & 131072) || (t & 1)) __builtin_amdgcn_sched_barrier(0);
                     }
-                    if (qt == 1 && zero_behind) zero_o();
+                    if (qt == QT - 1 && zero_behind) zero_o();
                     // rows RPP i + rsub of the tile: one scalar base for the 32 rows, a 32-bit lane offset per store;
                     // all reads first (the waits then count down), and the read address is one XOR per row
                     // group: row = RPP i + rsub, so chunk ^ swz_of(row) = (chunk ^ rsub) ^ (RPP i & 15)
@@ -1432,7 +1518,7 @@ fa_fwd_kernel64(const KernelArgs args) {
                 kq = tile_g(Kc, Kn, 4);  // visit 0 requests K(4), V(3) (for n_kv == 4 that is already the item after)
                 vq = tile_g(Vc, Vn, 3);
                 if (has_next) request_next_q(0);  // (the staging area is free again: store_item's reads have retired)
-                seam_st = 16;
+                seam_st = 8 * QT;
                 if constexpr (RAG) {  // stores the epilogue above issued: one per four rows inside the sequence (16 per 64 rows)
                     const int rows_in = args.seq_len - (qb_st * TR::kBr + wave * TR::kRowsPerWave);
                     seam_st = rows_in >= 64 ? 16 : (rows_in >= 32 ? 8 : 0);
@@ -1445,7 +1531,7 @@ fa_fwd_kernel64(const KernelArgs args) {
                     // the row max of the S tile the last visit formed (the next item's S(0)): the speculative
                     // schedule has no row-max units, this is the only one an item needs (behind store_item's pads)
 #pragma unroll
-                    for (int qt = 0; qt < 2; ++qt) {
+                    for (int qt = 0; qt < QT; ++qt) {
                         float v0 = vmax2(Sa[qt][0][0], Sa[qt][0][1]), v1 = vmax2(Sa[qt][1][0], Sa[qt][1][1]);
 #pragma unroll
                         for (int r = 2; r < 16; r += 2) {
@@ -1456,7 +1542,7 @@ fa_fwd_kernel64(const KernelArgs args) {
                     }
                 }
 #pragma unroll
-                for (int qt = 0; qt < 2; ++qt) {
+                for (int qt = 0; qt < QT; ++qt) {
                     m[qt] = mraw[qt];
                     neg_msc[qt] = -(finite_or_zero(m[qt]) * cs);
                     thr[qt] = m[qt] + TAU / cs;

@@ -86,11 +86,13 @@ def lint(path, window=3, raw=2, only=None):
     functions whose (mangled) name contains this string."""
     findings = []
     kernels = []
+    names = []
     for name, code, own in split_kernels(path):
         if only and only not in name:
             continue
         kidx = len(kernels)
         kernels.append(code)
+        names.append(name)
         # M0: the hand-placed DMA writes M0 (the LDS destination) in one asm statement and reads it in a
         # later one, with no save / restore.  That is only sound while hipcc itself never touches M0 in
         # the function (it is compiler-reserved and NOT preserved around asm statements): no dynamic
@@ -219,29 +221,31 @@ def lint(path, window=3, raw=2, only=None):
         # (the rescale of O sits in front of it) no compiler-made accumulator copy may appear: hipcc has
         # been seen hoisting the rescale path's 128 v_accvgpr_read to the end of the PREVIOUS visit,
         # 16 behind every P.V MFMA, each waiting for that MFMA to retire (a trace build; +25 % per visit).
+        # The one-Q-tile-per-wave form (template argument QTP = 1, round 5) has visits of 16 + 16.
         mf = [i for i, l in enumerate(code) if l.startswith("v_mfma")]
         kinds = "".join("a" if code[i].split()[1].startswith("a[") else "v" for i in mf)
+        half = 16 if re.search(r"fa_fwd_kernel64I.*ELi1EEEvNS_10KernelArgsE", names[kidx]) else 32
         pos = 0
         while True:
-            j = kinds.find("v" * 32 + "a" * 32, pos)
+            j = kinds.find("v" * half + "a" * half, pos)
             if j < 0:
                 break
             # (a copy that touches none of the visit's own matrix registers -- O, the accumulators, and Q, the B operands --
             # is not one of those: the pre-scaled Q of the NEXT item is written into the spare Q set on the slow path of an
             # item's first visits, through VGPRs, while the MFMAs work on the current set)
             used = set()
-            for i in mf[j:j + 64]:
+            for i in mf[j:j + 2 * half]:
                 for tok in code[i].split()[1:]:
                     used |= {r for r in regs2(tok) if r[0] == "a"}
-            for i in range(mf[j + 2], mf[j + 63] + 1):
+            for i in range(mf[j + 2], mf[j + 2 * half - 1] + 1):
                 if code[i].startswith("v_accvgpr_"):
                     touched = set()
                     for tok in code[i].split()[1:]:
                         touched |= {r for r in regs2(tok) if r[0] == "a"}
                     if touched & used:
-                        findings.append(("AGPR", kidx, i, code[mf[j + 63]], code[i]))
+                        findings.append(("AGPR", kidx, i, code[mf[j + 2 * half - 1]], code[i]))
                         break
-            pos = j + 64
+            pos = j + 2 * half
     return findings
 
 

@@ -2,6 +2,7 @@
 // schedule on the headline shape, random data (the chip is power-limited: constant data
 // clocks ~20 % higher and hides everything).
 #include "../csrc/fa_fwd_kernel64.hpp"
+#include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -37,9 +38,32 @@ template <bool SPEC> void launch_prev(const fa::KernelArgs &a) {
     prev::launch(SPEC, a.q, a.k, a.v, a.o, a.batch_stride, a.seq_stride, a.head_stride, a.seq_len, a.n_heads, a.n_bh, a.n_q_blocks, a.n_kv_blocks);
 }
 #endif
+// -3: the hand-placed ONE-Q-tile-per-wave form (QTP = 1: the reference's (128, 64, 4)+buffer shape, 128-row items); -4: the
+// compiler-scheduled 32-rows-per-wave body the same configuration ran on through round 4 (two workgroups per CU)
+static void launch_qt1(const fa::KernelArgs &a) {
+    auto kern = fa::fa_fwd_kernel64<15, false, 0, false, false, false, 1>;
+    static bool init = false;
+    if (!init) { CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 163840)); init = true; }
+    fa::KernelArgs b = a;
+    b.n_q_blocks = a.seq_len / 128;
+    hipLaunchKernelGGL(kern, dim3(b.n_bh * b.n_q_blocks < 256 ? b.n_bh * b.n_q_blocks : 256), dim3(256), 163840, 0, b);
+}
+static void launch_32row(const fa::KernelArgs &a) {
+    using TR = fa::FwdTraits<15, 1, 4, 64, true, true, false, true, true, false, 128>;
+    auto kern = fa::fa_fwd_kernel<15, 1, 4, 64, true, true, false, true, true, false, 128>;
+    static bool init = false;
+    if (!init) { CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, TR::kLdsBytes)); init = true; }
+    fa::KernelArgs b = a;
+    b.n_q_blocks = a.seq_len / 128;
+    hipLaunchKernelGGL(kern, dim3(b.n_bh * b.n_q_blocks), dim3(256), TR::kLdsBytes, 0, b);
+}
 template <int ABL> void add(const char *name) {
     if (!only_list.empty() && std::find(only_list.begin(), only_list.end(), ABL) == only_list.end()) return;
-    if constexpr (ABL < 0) {
+    if constexpr (ABL == -3) {
+        variants.push_back({name, ABL, launch_qt1, 0.0, 0, 1e9f});
+    } else if constexpr (ABL == -4) {
+        variants.push_back({name, ABL, launch_32row, 0.0, 0, 1e9f});
+    } else if constexpr (ABL < 0) {
 #ifdef TUNE64_PREV
         variants.push_back({name, ABL, launch_prev<ABL == -1>, 0.0, 0, 1e9f});
 #endif
@@ -75,15 +99,19 @@ static void time_all() {
     const double fl = 4.0 * Bx * H * (double)S * S * D;
     // a hash of each variant's output: variants that only move work around (not the arithmetic) must agree bit for bit
     const size_t n_o = (size_t)Bx * S * H * D;
-    std::vector<uint16_t> ho(n_o);
+    std::vector<uint16_t> ho(n_o), ho0;   // ho0: the first variant's output, the yardstick for the others' largest difference
+    auto bf = [](uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; };
     for (auto &v : variants) {
         CHECK(hipMemset(o, 0xff, n_o * 2));
         v.launch(a);
         CHECK(hipMemcpy(ho.data(), o, n_o * 2, hipMemcpyDeviceToHost));
         unsigned long long hsh = 1469598103934665603ull;
         for (size_t i = 0; i < n_o; ++i) hsh = (hsh ^ ho[i]) * 1099511628211ull;
-        printf("%-52s abl=%8d S=%5d : mean %.4f ms  %7.1f TF   best %7.1f TF   out %016llx\n", v.name, v.abl, S, v.sum_ms / v.n,
-               fl / (v.sum_ms / v.n * 1e-3) / 1e12, fl / (v.best * 1e-3) / 1e12, hsh);
+        double worst = 0.0; size_t n_diff = 0;
+        if (ho0.empty()) ho0 = ho;
+        else for (size_t i = 0; i < n_o; ++i) if (ho[i] != ho0[i]) { ++n_diff; const double d = fabs((double)bf(ho[i]) - (double)bf(ho0[i])) / (1.0 + fabs((double)bf(ho0[i]))); if (d > worst || d != d) worst = d != d ? 1e30 : d; }
+        printf("%-52s abl=%8d S=%5d : mean %.4f ms  %7.1f TF   best %7.1f TF   out %016llx  vs first: %zu differ, worst %.2e\n", v.name, v.abl, S, v.sum_ms / v.n,
+               fl / (v.sum_ms / v.n * 1e-3) / 1e12, fl / (v.best * 1e-3) / 1e12, hsh, n_diff, worst);
     }
 }
 

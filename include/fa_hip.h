@@ -137,6 +137,14 @@ typedef struct fa_kernel_info {
                                 (256, 64, 4) kernel, which needs seq_len >= B_c when seq_len % B_r != 0 */
     int32_t softmax_mode;    /* fa_softmax_mode of this device variant */
     int32_t prescaled_q;     /* 1: the variant folds the softmax scale into a 16-bit copy of Q (fa_fwd_opts.prescaled_q) */
+    /* ABI 5: the RING FORM of a 32-rows-per-wave configuration -- (B_r 128, B_c 64, 4 warps) + buffer, the reference's own
+     * winning tile shape: launches with seq_len % 256 == 0 are served by the hand-placed persistent kernel with one
+     * 32-row Q tile per wave (the machinery of the (256, 64, 4) kernel; lazy rescale; bit-identical to that kernel's
+     * non-speculative form), the other multiples of B_r by the variant described above. */
+    int32_t ring_form;           /* 1: such a form exists for this variant */
+    int32_t ring_softmax_mode;   /* its fa_softmax_mode (FA_SOFTMAX_LAZY) */
+    int32_t ring_num_regs;       /* VGPR+AGPR per lane of the ring form */
+    int32_t ring_scratch_bytes;  /* 0 = no spills */
 } fa_kernel_info;
 
 /* Device-side statistics (optional, fa_fwd_opts.stats): a DEVICE pointer to two 32-bit counters the
@@ -272,7 +280,7 @@ int fa_get_kernel_sized(int index, fa_kernel_info *out, uint32_t out_size);
 int fa_fwd_query_sized(const fa_fwd_config *cfg, const fa_fwd_opts *opts, fa_kernel_info *out, uint32_t out_size);
 
 /* Increases whenever a struct of this header grows or an entry point changes meaning (5 = this header: the adaptive
- * record is per device variant, fa_adaptive_state_for added). */
+ * record is per device variant, fa_adaptive_state_for added; fa_kernel_info grew by the four ring_* fields). */
 #define FA_ABI_VERSION 5
 int fa_abi_version(void);
 

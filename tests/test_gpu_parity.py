@@ -53,9 +53,15 @@ def test_library_loaded_and_device_is_gfx950():
     assert os.path.exists(_capi.LIB_PATH)
     assert _capi.check(_capi.load().fa_init()) == 0
     assert ut.is_mi355x()
+    n_ring = 0
     for info in _capi.kernels():
         assert info.scratch_bytes == 0, "register spill in a device variant"
         assert 0 < info.num_regs <= 512
+        if info.ring_form:   # the hand-placed ring form of (B_r 128, B_c 64, 4 warps) + buffer (round 5)
+            n_ring += 1
+            assert info.ring_scratch_bytes == 0 and 0 < info.ring_num_regs <= 512 and info.ring_softmax_mode == 2
+            assert (info.cfg.B_r, info.cfg.B_c, info.cfg.n_warps, info.masked, info.rows_per_wave) == (128, 64, 4, 0, 32)
+    assert n_ring == 2   # one per dtype
 
 
 def test_c_abi_per_device_state():
@@ -578,17 +584,22 @@ def test_speculative_softmax_on_the_32_row_kernels_starts_over():
     shapes = [(128, 64, 4, True), (128, 64, 4, False), (128, 32, 4, True), (256, 128, 8, False), (64, 64, 4, True),
               (64, 64, 4, False), (256, 64, 8, True), (64, 32, 4, False)]
     for dtype, name in ((torch.bfloat16, kc.DType.BF16), (torch.float16, kc.DType.FP16)):
-        qc = ut.QKVConfig(n_heads=3, d_head=128, batch_size=2, seq_len=1024, dtype=dtype, device=torch.device(DEV))
-        q, k, v = ut.generate_qkv(qc, seed=19)
-        u = _sign_vector(5).to(dtype)
-        k[1, 3, 2] = 30.0 * u            # key 3 lies in the LAST visited tile
-        q[1, 600:604, 2] = 30.0 * u      # rows 600..603 of (batch 1, head 2)
-        ref = ut.py_flash_attention(q, k, v, upcast=True).float()
-        tol = TOL[dtype] * (1 + ref.abs())
+        data = {}
+        for S in (1024, 896):   # 896: a multiple of 128 that is not one of 256 (see below)
+            qc = ut.QKVConfig(n_heads=3, d_head=128, batch_size=2, seq_len=S, dtype=dtype, device=torch.device(DEV))
+            q, k, v = ut.generate_qkv(qc, seed=19)
+            u = _sign_vector(5).to(dtype)
+            k[1, 3, 2] = 30.0 * u            # key 3 lies in the LAST visited tile
+            q[1, 600:604, 2] = 30.0 * u      # rows 600..603 of (batch 1, head 2)
+            ref = ut.py_flash_attention(q, k, v, upcast=True).float()
+            data[S] = (q, k, v, ref, TOL[dtype] * (1 + ref.abs()))
         for B_r, B_c, nw, buf in shapes:
             spec = _native(name, B_r, B_c, nw, buf, True)
             plain = replace(spec, speculative_softmax=False)
             assert kc.uses_speculative_softmax(spec) and not kc.uses_speculative_softmax(plain)
+            # (128, 64, 4) + buffer without the flag is served by its hand-placed RING FORM (lazy rescale) where seq_len is
+            # a multiple of 256: "the same variant without the flag" is the 32-rows-per-wave body only off those lengths
+            q, k, v, ref, tol = data[896 if kc.has_ring_form(plain) else 1024]
             out, out_plain = flash_attention.forward(spec, q, k, v), flash_attention.forward(plain, q, k, v)
             assert torch.isfinite(out.float()).all(), str(spec)
             blk = slice((600 // B_r) * B_r, (600 // B_r) * B_r + B_r)   # the workgroup that holds rows 600..603
@@ -1212,7 +1223,10 @@ def test_masked_variant_equals_plain_kernel_when_nothing_is_masked():
     for cfg in MASKED:
         dtype = cfg.dtype.to_torch_dtype()
         gen = torch.Generator(device=DEV).manual_seed(3)
-        q, k, v = (torch.randn((2, 1024, 4, 128), dtype=dtype, device=DEV, generator=gen) for _ in range(3))
+        # (a configuration with a ring form -- (128, 64, 4) + buffer -- runs another device form, with the lazy rescale, at
+        # multiples of 256: its masked variant is compared with the 32-rows-per-wave body, i.e. off those lengths)
+        S = 896 if kc.has_ring_form(cfg) else 1024
+        q, k, v = (torch.randn((2, S, 4, 128), dtype=dtype, device=DEV, generator=gen) for _ in range(3))
         assert kc.uses_speculative_softmax(cfg, masked=True) == kc.uses_speculative_softmax(cfg)  # (by construction of MASKED)
         masked_out, plain_out = flash_attention.forward_ex(cfg, q, k, v), flash_attention.forward(cfg, q, k, v)
         if kc.uses_lazy_rescale(cfg) and kc.uses_speculative_softmax(cfg):
@@ -1713,3 +1727,45 @@ print(json.dumps(_capi.adaptive_state(0, cfg)))
     assert mine["launches"] == before["launches"] and mine["demoted"] == before["demoted"] and mine["mode"] == 0
     out = flash_attention.forward(cfg, q, k, v)
     assert torch.equal(out, flash_attention.forward(replace(cfg, adaptive_softmax=False), q, k, v))
+
+
+def test_ring_form_of_the_reference_winning_shape():
+    """(B_r 128, B_c 64, 4 warps) + buffer -- the reference's own winning tile shape (kernel_sass/16_A100.asm:5,
+    kernel_configs.py:389-423 there) -- is served, for seq_len % 256 == 0, by the hand-placed persistent kernel with ONE
+    32-row Q tile per wave (fa_fwd_kernel64<..., QTP = 1>; fa_kernel_info.ring_form), for the other
+    multiples of 128 by the compiler-scheduled 32-rows-per-wave body.  The ring form runs the lazy rescale per 32-row tile
+    exactly as the (256, 64, 4) kernel's non-speculative form does, so the two agree BIT FOR BIT; both forms are inside
+    the reference's tolerance rule against the eager golden; every reference config of the shape reaches it (the
+    operand-fetch hints and optimized_softmax do not change the device variant)."""
+    shape_cfgs = [c for c in kc.get_kernels_to_build() if (c.B_r, c.B_c, c.n_warps) == (128, 64, 4) and c.mma_double_buffer_loads]
+    assert len(shape_cfgs) >= 8 and all(kc.has_ring_form(c) for c in shape_cfgs)
+    for name, dtype in ((kc.DType.BF16, torch.bfloat16), (kc.DType.FP16, torch.float16)):
+        cfgs = [c for c in shape_cfgs if c.dtype == name]
+        big = kc.as_native(kc.best_config(name), speculative_softmax=False)       # (256, 64, 4)+buffer, lazy
+        assert kc.softmax_mode(big) == "lazy" and kc.softmax_mode(cfgs[0], seq_len=512) == "lazy" and kc.softmax_mode(cfgs[0], seq_len=384) == "eager"
+        for (B, S, H) in ((2, 512, 3), (1, 1024, 8), (3, 256, 5), (2, 2048, 16)):
+            gen = torch.Generator(device=DEV).manual_seed(S + H)
+            q, k, v = (torch.randn((B, S, H, 128), dtype=dtype, device=DEV, generator=gen) for _ in range(3))
+            # a logit spike, so that the lazy rescale actually moves a reference max somewhere
+            u = _sign_vector(7).to(dtype)
+            k[0, S // 3, 1] = 12.0 * u
+            q[0, S // 2:S // 2 + 3, 1] = 12.0 * u
+            want = flash_attention.forward(big, q, k, v)
+            eager = ut.py_flash_attention(q, k, v, upcast=True).float()
+            for c in cfgs:
+                out = flash_attention.forward(c, q, k, v)
+                assert torch.equal(out, want), (str(c), B, S, H)
+            assert ((want.float() - eager).abs() <= TOL[dtype] * (1 + eager.abs())).all()
+        # a multiple of 128 that is not one of 256: the compiler-scheduled body, the reference's eager arithmetic
+        gen = torch.Generator(device=DEV).manual_seed(384)
+        q, k, v = (torch.randn((2, 384, 4, 128), dtype=dtype, device=DEV, generator=gen) for _ in range(3))
+        out = flash_attention.forward(cfgs[0], q, k, v)
+        eager = ut.py_flash_attention(q, k, v, upcast=True).float()
+        assert ((out.float() - eager).abs() <= TOL[dtype] * (1 + eager.abs())).all()
+        # many items per workgroup (the persistent walk's seams) at a C1-like head count, against the 64-row kernel
+        gen = torch.Generator(device=DEV).manual_seed(11)
+        q, k, v = (torch.randn((4, 2048, 16, 128), dtype=dtype, device=DEV, generator=gen) for _ in range(3))
+        assert torch.equal(flash_attention.forward(cfgs[-1], q, k, v), flash_attention.forward(big, q, k, v))
+        # determinism
+        first = flash_attention.forward(cfgs[0], q, k, v)
+        assert all(torch.equal(flash_attention.forward(cfgs[0], q, k, v), first) for _ in range(3))

@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layout_matches_header():
     assert ctypes.sizeof(_capi.FaFwdConfig) == 13 * 4
     assert ctypes.sizeof(_capi.FaFwdArgs) == 4 * 8 + 7 * 8 + 13 * 4 + 4  # tail padding to 8
-    assert ctypes.sizeof(_capi.FaKernelInfo) == 13 * 4 + 8 * 4
+    assert ctypes.sizeof(_capi.FaKernelInfo) == 13 * 4 + 8 * 4 + 4 * 4   # (+ the four ring_* fields of ABI 5)
     assert ctypes.sizeof(_capi.FaFwdStats) == 8
     assert ctypes.sizeof(_capi.FaFwdOpts) == 5 * 4 + 4 + 2 * 8   # five 32-bit fields, padding, two pointers
     # the header's own view, compiled: sizes and offsets of the structs ctypes mirrors
@@ -140,6 +140,15 @@ def test_one_flag_one_meaning_softmax_mode_of_every_config():
     never = replace(best, speculative_softmax=False)
     assert not never.adaptive_softmax and kc.softmax_mode(never) == "lazy" and "+adaptive" not in never.short_form()
     assert kc.softmax_mode(kc.best_config(kc.DType.BF16, 1000, masked=True), masked=True) == "speculative"
+    # the ring form (round 5): (B_r 128, B_c 64, 4 warps) + buffer, plain -- the mirror of fa_kernel_info.ring_form
+    ring = [c for c in kc.get_kernels_to_build() if kc.has_ring_form(c)]
+    assert len(ring) == 8 and all((c.B_r, c.B_c, c.n_warps) == (128, 64, 4) and c.mma_double_buffer_loads for c in ring)   # four per dtype
+    infos = [_capi.query(c) for c in ring]
+    assert all(i.ring_form == 1 and i.ring_softmax_mode == 2 and i.softmax_mode in (0, 1) for i in infos)
+    others = [c for c in kc.get_kernels_to_build() if not kc.has_ring_form(c)]
+    assert all(_capi.query(c).ring_form == 0 for c in others)
+    assert kc.softmax_mode(ring[0], seq_len=1024) == "lazy" and kc.softmax_mode(ring[0], seq_len=640) != "lazy" and kc.softmax_mode(ring[0]) != "lazy"
+    assert not kc.has_ring_form(ring[0], masked=True) and not kc.has_ring_form(kc.as_native(ring[0], speculative_softmax=True))
     assert kc.softmax_mode(kc.best_config(kc.DType.BF16, 100, masked=True), masked=True) == "eager"
 
 
@@ -578,11 +587,11 @@ def test_adaptive_mode_abi():
     assert _capi.make_opts(speculative="adaptive").speculative == 2 and _capi.make_opts(speculative=True).speculative == 1
     assert _capi.make_opts(speculative=False).speculative == 0
     info = _capi.FaKernelInfo()
-    small = ctypes.sizeof(_capi.FaKernelInfo) - 8     # a client built against the 0.2 header (no softmax_mode / prescaled_q)
+    small = ctypes.sizeof(_capi.FaKernelInfo) - 8 - 16     # a client built against the 0.2 header (no softmax_mode / prescaled_q, no ring_* fields)
     buf = (ctypes.c_char * ctypes.sizeof(_capi.FaKernelInfo))()
     ctypes.memset(buf, 0x5A, ctypes.sizeof(buf))
     assert lib.fa_get_kernel_sized(0, ctypes.cast(buf, ctypes.POINTER(_capi.FaKernelInfo)), small) == 0
-    assert bytes(buf)[small:] == b"\x5a" * 8          # nothing written beyond the caller's size
+    assert bytes(buf)[small:] == b"\x5a" * 24         # nothing written beyond the caller's size
     assert lib.fa_get_kernel(0, ctypes.byref(info)) == 0 and bytes(buf)[:small] == bytes(info)[:small]
 
 
