@@ -740,7 +740,7 @@ static void fill_info(const fa::KernelEntry &e, fa_kernel_info *out) {
         (void)hipGetLastError();  // no device: resource fields stay -1
     }
     out->ring_form = e.fn_ring ? 1 : 0;
-    out->ring_softmax_mode = e.fn_ring ? FA_SOFTMAX_LAZY : 0;
+    out->ring_softmax_mode = e.fn_ring ? (e.softmax_mode == FA_SOFTMAX_SPECULATIVE ? FA_SOFTMAX_SPECULATIVE : FA_SOFTMAX_LAZY) : 0;
     out->ring_num_regs = out->ring_scratch_bytes = e.fn_ring ? -1 : 0;
     if (e.fn_ring) {
         if (hipFuncGetAttributes(&attr, (const void *)e.fn_ring) == hipSuccess) {

@@ -141,7 +141,7 @@ template <int QT> struct RingTraits {
 // 16 row-max units over S(it+1) (complete behind gap 15), the merged end-of-visit chain (steps 10..14), the 8 DMA
 // pieces at the even gaps 2..16 (each needs the gap before it for its M0), the barrier in gap 1; the operand wait and
 // the two reads of the next pair sit in the even gaps.  Unit u's P slice s16 = u / 4 is consumed from gap 16 + 4 s16.
-constexpr Plan64 make_plan32() {
+constexpr Plan64 make_plan32(bool nomax = false) {
     Plan64 p{};
     int e = 0, m = 0, d = 0;
     for (int g = 0; g < 32; ++g) {
@@ -155,6 +155,7 @@ constexpr Plan64 make_plan32() {
             if ((h & 1) && h <= 9) ne = 1;                       // units 11..15 at gaps 17, 19, 21, 23, 25
             if (h <= 10) nm = (!(h & 1) && h < 10) ? 2 : 1;      // 2 1 2 1 2 1 2 1 2 1 1 = 16
             if (h >= 11) tl = 10 + (h - 11);                     // merged chain steps 10..14
+            if (nomax) { nm = 0; tl = (g == 31) ? 8 : 0; }       // speculative schedule: only the next request pointers
         }
         p.exp_first[g] = (signed char)e; p.exp_n[g] = (signed char)ne; e += ne;
         p.max_first[g] = (signed char)m; p.max_n[g] = (signed char)nm; m += nm;
@@ -170,7 +171,7 @@ constexpr int plan_barrier_gap(const Plan64 &p, int n_gaps) {
         if (p.barrier[g]) return g;
     return -1;
 }
-constexpr bool plan32_ok(const Plan64 &p) {
+constexpr bool plan32_ok(const Plan64 &p, bool nomax = false) {
     int e = 0, m = 0, d = 0, bar = -1;
     for (int g = 0; g < 32; ++g) {
         for (int u = p.exp_first[g]; u < p.exp_first[g] + p.exp_n[g]; ++u)
@@ -185,7 +186,7 @@ constexpr bool plan32_ok(const Plan64 &p) {
         if (p.barrier[g] && g >= 28) return false;                   // K(it+2) is first read at gap 30
         e += p.exp_n[g]; m += p.max_n[g]; d += p.dma[g] >= 0;
     }
-    return e == 16 && m == 16 && d == 8 && bar >= 0;
+    return e == 16 && m == (nomax ? 0 : 16) && d == 8 && bar >= 0;
 }
 
 // (the reference's meaning of optimized_softmax -- the first tile skips the rescale -- holds here by
@@ -221,16 +222,18 @@ constexpr bool plan32_ok(const Plan64 &p) {
 // machinery -- rings, counted waits, persistent walk, three-region item loop, hand-placed gaps -- for the reference's own
 // winning tile shape (B_r 128, B_c 64, 4 warps) + buffer (kernel_sass/16_A100.asm:5, kernel_configs.py:389-423): one
 // 32-row Q tile per wave, 128-row items, 32 MFMAs per visit, every K / V operand read feeds ONE MFMA (1.5 LDS operand
-// reads per MFMA instead of 0.75).  Built plain, with the running max (lazy rescale): what a reference user's 13-field
-// config asks for.  Needs seq_len % 256 == 0 like the 64-row form (four ring stages = four tiles to a group); the
-// compiler-scheduled 32-rows-per-wave body of fa_fwd_kernel.hpp serves the other multiples of 128.
+// reads per MFMA instead of 0.75).  Built plain: with the running max (lazy rescale), what a reference user's 13-field
+// config asks for, and with the speculative schedule (SPEC: no rotated units there, so its row sums add up in the lazy
+// schedule's order; the guard's checkpoint rides in gaps 27 / 29 of every fourth visit; an item given up on is redone
+// by the lazy schedule like everywhere).  Needs seq_len % 256 == 0 like the 64-row form (four ring stages = four tiles
+// to a group); the compiler-scheduled 32-rows-per-wave body of fa_fwd_kernel.hpp serves the other multiples of 128.
 template <int DT, bool MASK = false, int ABL = 0, bool RAG = false, bool SPEC = false, bool PSQ = false, int QTP = 2>
 __global__ void
 __launch_bounds__(256, 1)
 fa_fwd_kernel64(const KernelArgs args) {
     static_assert(!RAG || MASK, "the ragged form is a masked variant");
     static_assert(!PSQ || !MASK, "the pre-scaled Q is built for the plain form");
-    static_assert(QTP == 2 || (QTP == 1 && !MASK && !RAG && !SPEC && !PSQ), "one Q tile per wave: the plain form with the running max");
+    static_assert(QTP == 2 || (QTP == 1 && !MASK && !RAG && !PSQ), "one Q tile per wave: the plain forms (lazy / speculative)");
     constexpr int QT = QTP, NWAVES = 4, BC = 64, D = 128;
     constexpr bool SWZ = true, EAGER = true, PIPE = true, DMA = true;
 
@@ -541,12 +544,12 @@ fa_fwd_kernel64(const KernelArgs args) {
             // rotated units (make_plan64): ABL bits 24..27 = rot_k for tools/tune64.hip (15 = off, 0 = the shipped value),
             // bit 28 = the next request pointers in gap 58 instead of behind the last MFMA
             constexpr int ROT_REQ = (ABL >> 24) & 15;
-            constexpr int ROT_K = (FAST && !MASK) ? (ROT_REQ == 15 ? 0 : (ROT_REQ ? ROT_REQ : FA_ROT_DEFAULT)) : 0;
+            constexpr int ROT_K = (FAST && !MASK && QT == 2) ? (ROT_REQ == 15 ? 0 : (ROT_REQ ? ROT_REQ : FA_ROT_DEFAULT)) : 0;
             constexpr int CHAIN_GAP = (FAST && (ABL & (1 << 28))) ? 58 : 63;
-            constexpr Plan64 plan = QT == 1 ? make_plan32()
+            constexpr Plan64 plan = QT == 1 ? make_plan32(FAST)
                                             : make_plan64(((ABL >> 8) & 3) | (MASK ? 4 : 0) | (FAST ? 8 : 0) | ((ABL & 8192) ? 16 : 0),
                                                           ((ABL & 1024) ? 20 : ((ABL & 16384) ? 23 : 22)) - ROT_K, ROT_K, CHAIN_GAP);
-            static_assert(QT == 1 ? plan32_ok(plan) : plan64_ok(plan, ROT_K), "filler plan violates a wait-state distance");
+            static_assert(QT == 1 ? plan32_ok(plan, FAST) : plan64_ok(plan, ROT_K), "filler plan violates a wait-state distance");
             constexpr int GAPS = 32 * QT, PH2 = 16 * QT;   // MFMAs of a visit; the first one of phase 2 (O += V P)
             constexpr int BAR_GAP = plan_barrier_gap(plan, GAPS);   // -1: the sync point sits at the visit's top
             f32x16 Sa[QT][NT], Sb[QT][NT];
@@ -733,6 +736,7 @@ fa_fwd_kernel64(const KernelArgs args) {
             // (tools/tune64.hip): behind the visit instead, as first built.
             constexpr bool GUARD_IN_VISIT = FAST && !(ABL & 32768) && !(ABL & 262144);
             float g_l0 = 0.0f, g_l1 = 0.0f, g_lm = 0.0f;
+            (void)g_l0; (void)g_l1;
             bool guard_hit = false;
             // ---- the next item's Q, through LDS -------------------------------------------------------
             // The MFMA wants a lane to hold one Q row's 16-byte chunk; fetched like that from global memory
@@ -1147,11 +1151,15 @@ fa_fwd_kernel64(const KernelArgs args) {
                     }
                     static_for<0, plan.max_n[g]>([&](auto i) { max_unit(plan.max_first[g] + decltype(i)::value); });
                     if constexpr (plan.tail[g] > 0) tail_step(plan.tail[g]);
-                    if constexpr (GUARD_IN_VISIT && R == 3) {
+                    if constexpr (GUARD_IN_VISIT && R == 3 && QT == 2) {
                         if constexpr (g == 56) g_l0 = vadd(rs[0][0], rs[0][1]);
-                        if constexpr (g == 57) g_l1 = vadd(rs[1][0], rs[1][1]);
+                        if constexpr (g == 57) g_l1 = vadd(rs[QT - 1][0], rs[QT - 1][1]);
                         if constexpr (g == 58) g_lm = vmax2(g_l0, g_l1);
                         if constexpr (g == 60) guard_hit = __ballot(!(g_lm <= spec_guard<DT>())) != 0;
+                    }
+                    if constexpr (GUARD_IN_VISIT && R == 3 && QT == 1) {  // (all 16 units have issued by gap 25)
+                        if constexpr (g == 27) g_lm = vadd(rs[0][0], rs[0][1]);
+                        if constexpr (g == 29) guard_hit = __ballot(!(g_lm <= spec_guard<DT>())) != 0;
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 };
@@ -1204,8 +1212,10 @@ fa_fwd_kernel64(const KernelArgs args) {
                     if constexpr (GUARD_IN_VISIT) {
                         if (__builtin_expect(!guard_hit, 1)) return;  // (decided inside the visit that just ended)
                     }
-                    const float l0 = vadd(rs[0][0], rs[0][1]), l1 = vadd(rs[1][0], rs[1][1]);
-                    const float lm = vmax2(l0, l1);
+                    float l_q[QT];
+#pragma unroll
+                    for (int qt = 0; qt < QT; ++qt) l_q[qt] = vadd(rs[qt][0], rs[qt][1]);
+                    const float lm = QT == 2 ? vmax2(l_q[0], l_q[QT - 1]) : l_q[0];
                     if (__builtin_expect(__ballot(!(lm <= kResc)) == 0, 1)) return;
                     // ---- rare ----  (per ROW: a row that does not need it keeps its scale -- dragged along by its neighbours'
                     // rescues it would sink towards l = 0 -- and a row that does is brought to l in [1, 2) in one step)
@@ -1213,7 +1223,7 @@ fa_fwd_kernel64(const KernelArgs args) {
                     float nonfinite = 0.0f;  // sum of (o - o): 0 while every element of O is finite, NaN otherwise
 #pragma unroll
                     for (int qt = 0; qt < QT; ++qt) {
-                        const float lq = pair_max(qt ? l1 : l0);      // the two lanes of a row decide together
+                        const float lq = pair_max(l_q[qt]);           // the two lanes of a row decide together
                         if (__ballot(!(lq < kLimit)) != 0) item_bad = true;
                         const bool big = !(lq <= kResc);
                         int e = big ? __builtin_amdgcn_frexp_expf(lq) - 1 : 0;   // lq in [2^e, 2^(e+1))

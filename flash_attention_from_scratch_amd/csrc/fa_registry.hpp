@@ -33,7 +33,8 @@ struct KernelEntry {
     int prescaled_q;      // 1: logits from a 16-bit Q * c (fa_fwd_opts.prescaled_q); persistent kernel only
     // Round 5: the RING FORM of a 32-rows-per-wave configuration -- the hand-placed persistent kernel with one Q tile per
     // wave (fa_fwd_kernel64<..., QTP = 1>), which serves launches with seq_len % 256 == 0 (four ring stages = four tiles to
-    // a group); `fn` serves the other multiples of B_r.  Null where none is built.  Its softmax is the lazy rescale.
+    // a group); `fn` serves the other multiples of B_r.  Null where none is built.  Its softmax: the lazy rescale for the
+    // plain variant, the speculative schedule (softmax_mode 3) for the speculative one.
     kernel_fn fn_ring = nullptr;
     int ring_lds_bytes = 0;
 };
@@ -64,14 +65,14 @@ constexpr KernelEntry make_entry() {
             return KernelEntry{DT, 64, 4, 64, 1, 1, OPT, 1, 1, 0, 128, TR::kThreads, TR::kLdsBytes, 1,
                                (kernel_fn)&fa_fwd_kernel64<DT, false, 0, false, OPT>, nullptr,  // OPT: speculative softmax
                                softmax_mode_of(true, OPT, true, true, false), 0};
-    } else if constexpr (QT == 1 && NWAVES == 4 && BC == 64 && SWZ && EAGER && !OPT && PIPE && DMA && !MASK && D == 128) {
+    } else if constexpr (QT == 1 && NWAVES == 4 && BC == 64 && SWZ && EAGER && PIPE && DMA && !MASK && D == 128) {
         // the reference's winning tile shape, (B_r 128, B_c 64, 4 warps) + buffer (kernel_sass/16_A100.asm:5): the
-        // compiler-scheduled body, and the hand-placed ring form for seq_len % 256 == 0.  (The OPT = true build of this
-        // shape is the speculative softmax of the 32-row body, asked for through fa_fwd_opts only: no ring form there.)
+        // compiler-scheduled body, and the hand-placed ring form for seq_len % 256 == 0.  OPT = true is the speculative
+        // softmax (asked for through fa_fwd_opts only) in both.
         return KernelEntry{DT, 32, 4, 64, 1, 1, OPT, 1, 1, 0, 128, TR::kThreads, TR::kLdsBytes, 0,
                            (kernel_fn)&fa_fwd_kernel<DT, QT, NWAVES, BC, SWZ, EAGER, OPT, PIPE, DMA, MASK, D>, nullptr,
                            softmax_mode_of(false, OPT, EAGER, DMA, MASK), 0,
-                           (kernel_fn)&fa_fwd_kernel64<DT, false, 0, false, false, false, 1>, RingTraits<1>::kLdsBytes};
+                           (kernel_fn)&fa_fwd_kernel64<DT, false, 0, false, OPT, false, 1>, RingTraits<1>::kLdsBytes};
     } else {
         return KernelEntry{DT, 32 * QT, NWAVES, BC, SWZ, EAGER, OPT, PIPE, DMA, MASK ? 1 : 0, D, TR::kThreads,
                            TR::kLdsBytes, 0,

@@ -574,10 +574,10 @@ def has_ring_form(cfg, masked=False) -> bool:
     """(B_r 128, B_c 64, 4 warps) + buffer, the reference's own winning tile shape (kernel_configs.py:389-423 there,
     kernel_sass/16_A100.asm:5): launches with ``seq_len % 256 == 0`` run the hand-placed persistent kernel with one 32-row
     Q tile per wave (``fa_kernel_info.ring_form``), the other multiples of 128 the compiler-scheduled body.
-    Not its speculative or masked forms."""
+    The plain configuration runs that kernel's lazy rescale, the speculative one its speculative schedule
+    (``fa_kernel_info.ring_softmax_mode``).  Not the masked forms."""
     return (not masked and cfg.d_head == 128 and (cfg.B_r, cfg.B_c, cfg.n_warps) == (128, 64, 4) and bool(cfg.async_copy)
-            and bool(cfg.eager_load_blocks) and bool(cfg.swizzled) and bool(cfg.mma_double_buffer_loads)
-            and not (wants_speculative(cfg) and has_speculative_variant(cfg, masked)))
+            and bool(cfg.eager_load_blocks) and bool(cfg.swizzled) and bool(cfg.mma_double_buffer_loads))
 
 
 def softmax_mode(cfg, masked=False, seq_len=None) -> str:
@@ -585,8 +585,8 @@ def softmax_mode(cfg, masked=False, seq_len=None) -> str:
     ``fa_kernel_info.softmax_mode`` (include/fa_hip.h): 'eager' (the reference, softmax.cuh:85-105),
     'first_block_skip' (the reference's optimized_softmax), 'lazy' (persistent kernel: the reference max
     moves only when a row max rose by more than 8 binades), 'speculative' (DESIGN.md 3.6).  ``seq_len``: where the
-    config has a ring form (``has_ring_form``) and the length is a multiple of 256, that form's mode ('lazy':
-    ``fa_kernel_info.ring_softmax_mode``)."""
+    config has a ring form (``has_ring_form``) and the length is a multiple of 256, that form's mode ('lazy', or
+    'speculative' where the configuration asks for it: ``fa_kernel_info.ring_softmax_mode``)."""
     if wants_speculative(cfg) and has_speculative_variant(cfg, masked):
         return "speculative"
     if is_persistent_shape(cfg):

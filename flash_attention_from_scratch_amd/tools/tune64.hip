@@ -39,18 +39,19 @@ template <bool SPEC> void launch_prev(const fa::KernelArgs &a) {
 }
 #endif
 // -3: the hand-placed ONE-Q-tile-per-wave form (QTP = 1: the reference's (128, 64, 4)+buffer shape, 128-row items); -4: the
-// compiler-scheduled 32-rows-per-wave body the same configuration ran on through round 4 (two workgroups per CU)
-static void launch_qt1(const fa::KernelArgs &a) {
-    auto kern = fa::fa_fwd_kernel64<15, false, 0, false, false, false, 1>;
+// compiler-scheduled 32-rows-per-wave body the same configuration ran on through round 4 (two workgroups per CU);
+// -5 / -6: the same two with the speculative softmax
+template <bool SPEC> static void launch_qt1(const fa::KernelArgs &a) {
+    auto kern = fa::fa_fwd_kernel64<15, false, 0, false, SPEC, false, 1>;
     static bool init = false;
     if (!init) { CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 163840)); init = true; }
     fa::KernelArgs b = a;
     b.n_q_blocks = a.seq_len / 128;
     hipLaunchKernelGGL(kern, dim3(b.n_bh * b.n_q_blocks < 256 ? b.n_bh * b.n_q_blocks : 256), dim3(256), 163840, 0, b);
 }
-static void launch_32row(const fa::KernelArgs &a) {
-    using TR = fa::FwdTraits<15, 1, 4, 64, true, true, false, true, true, false, 128>;
-    auto kern = fa::fa_fwd_kernel<15, 1, 4, 64, true, true, false, true, true, false, 128>;
+template <bool SPEC> static void launch_32row(const fa::KernelArgs &a) {
+    using TR = fa::FwdTraits<15, 1, 4, 64, true, true, SPEC, true, true, false, 128>;
+    auto kern = fa::fa_fwd_kernel<15, 1, 4, 64, true, true, SPEC, true, true, false, 128>;
     static bool init = false;
     if (!init) { CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, TR::kLdsBytes)); init = true; }
     fa::KernelArgs b = a;
@@ -59,10 +60,10 @@ static void launch_32row(const fa::KernelArgs &a) {
 }
 template <int ABL> void add(const char *name) {
     if (!only_list.empty() && std::find(only_list.begin(), only_list.end(), ABL) == only_list.end()) return;
-    if constexpr (ABL == -3) {
-        variants.push_back({name, ABL, launch_qt1, 0.0, 0, 1e9f});
-    } else if constexpr (ABL == -4) {
-        variants.push_back({name, ABL, launch_32row, 0.0, 0, 1e9f});
+    if constexpr (ABL == -3 || ABL == -5) {
+        variants.push_back({name, ABL, launch_qt1<ABL == -5>, 0.0, 0, 1e9f});
+    } else if constexpr (ABL == -4 || ABL == -6) {
+        variants.push_back({name, ABL, launch_32row<ABL == -6>, 0.0, 0, 1e9f});
     } else if constexpr (ABL < 0) {
 #ifdef TUNE64_PREV
         variants.push_back({name, ABL, launch_prev<ABL == -1>, 0.0, 0, 1e9f});

@@ -139,10 +139,11 @@ typedef struct fa_kernel_info {
     int32_t prescaled_q;     /* 1: the variant folds the softmax scale into a 16-bit copy of Q (fa_fwd_opts.prescaled_q) */
     /* ABI 5: the RING FORM of a 32-rows-per-wave configuration -- (B_r 128, B_c 64, 4 warps) + buffer, the reference's own
      * winning tile shape: launches with seq_len % 256 == 0 are served by the hand-placed persistent kernel with one
-     * 32-row Q tile per wave (the machinery of the (256, 64, 4) kernel; lazy rescale; bit-identical to that kernel's
-     * non-speculative form), the other multiples of B_r by the variant described above. */
+     * 32-row Q tile per wave (the machinery of the (256, 64, 4) kernel: its lazy rescale for the plain variant,
+     * bit-identical to that kernel's non-speculative form, and its speculative schedule for the speculative variant,
+     * whose failed items are redone by the lazy one), the other multiples of B_r by the variant described above. */
     int32_t ring_form;           /* 1: such a form exists for this variant */
-    int32_t ring_softmax_mode;   /* its fa_softmax_mode (FA_SOFTMAX_LAZY) */
+    int32_t ring_softmax_mode;   /* its fa_softmax_mode (FA_SOFTMAX_LAZY or FA_SOFTMAX_SPECULATIVE) */
     int32_t ring_num_regs;       /* VGPR+AGPR per lane of the ring form */
     int32_t ring_scratch_bytes;  /* 0 = no spills */
 } fa_kernel_info;

@@ -59,9 +59,10 @@ def test_library_loaded_and_device_is_gfx950():
         assert 0 < info.num_regs <= 512
         if info.ring_form:   # the hand-placed ring form of (B_r 128, B_c 64, 4 warps) + buffer (round 5)
             n_ring += 1
-            assert info.ring_scratch_bytes == 0 and 0 < info.ring_num_regs <= 512 and info.ring_softmax_mode == 2
+            assert info.ring_scratch_bytes == 0 and 0 < info.ring_num_regs <= 512
+            assert info.ring_softmax_mode == (3 if info.softmax_mode == 3 else 2)   # speculative variant: speculative ring
             assert (info.cfg.B_r, info.cfg.B_c, info.cfg.n_warps, info.masked, info.rows_per_wave) == (128, 64, 4, 0, 32)
-    assert n_ring == 2   # one per dtype
+    assert n_ring == 4   # plain + speculative, per dtype
 
 
 def test_c_abi_per_device_state():
@@ -115,16 +116,16 @@ def test_seam_golden_with_spikes_and_the_redo_counter(tag):
     sane = torch.isfinite(g["o_b16"].float()).all(dim=-1)   # (fp16: the reference's 16-bit eager overflows on the 30-sigma rows)
     n_items = {256: 3 * 24 * 4, 128: 3 * 24 * 8}
 
-    def predicted_redone(B_r):
+    def predicted_redone(B_r, ring=True):
         """Items whose first pass must fail, from the fp32 logits: a row fails when l = sum_k 2^((s_k - m_first) c) reaches
-        the limit (bf16: spec_limit 2^64 on the 32-rows-per-wave kernel, spec_limit64 2^120 on the persistent one, whose
-        guard looks at O itself; fp16 2^15), m_first = the row's max over the LAST 64 keys (visited first); an item fails
+        the limit (bf16: spec_limit 2^64 on the compiler-scheduled 32-rows-per-wave kernel, spec_limit64 2^120 on the
+        persistent one -- both its forms, ring = True -- whose guard looks at O itself; fp16 2^15), m_first = the row's max over the LAST 64 keys (visited first); an item fails
         when one of its rows does.  (One spiked key per row and N(0, 1) elsewhere: no reference has moved before the spike
         arrives, so the guarded kernel's criterion is the same comparison.)  A 30-sigma K row gives EVERY query of its head
         logits of ~+-43 binades, so (nearly) all Q blocks of the two spiked heads fail; the mild spike fails in fp16 only,
         and only in its own Q block."""
         c = 1.4426950408889634 / 128 ** 0.5
-        limit = (2.0 ** 120 if B_r == 256 else 2.0 ** 64) if tag == "bf16" else 2.0 ** 15
+        limit = (2.0 ** 120 if ring else 2.0 ** 64) if tag == "bf16" else 2.0 ** 15
         n = 0
         for bb in range(q.shape[0]):
             sc = torch.einsum("qhd,khd->hqk", q[bb].float(), k[bb].float())
@@ -134,10 +135,14 @@ def test_seam_golden_with_spikes_and_the_redo_counter(tag):
             n += int(bad.view(bad.shape[0], -1, B_r).any(dim=-1).sum())
         return n
 
+    # (seq_len % 256 == 0 here: the (128, 64, 4)+buffer configurations run their ring form, the persistent kernel with
+    # one Q tile per wave -- its limit, per 128-row item)
     expect = {256: predicted_redone(256), 128: predicted_redone(128)}
-    assert expect[256] == (7 if tag == "bf16" else 9) and expect[128] == (16 if tag == "bf16" else 17), expect
+    assert expect[256] == (7 if tag == "bf16" else 9) and expect[128] == (8 if tag == "bf16" else 17), expect
+    assert predicted_redone(128, ring=False) == (16 if tag == "bf16" else 17)   # (the compiler-scheduled body's limit)
     if tag == "fp16":
-        expect[256] = (8, 9)   # the mild spike: 20 binades at once fail fp16 -- unless the guard has moved that row's reference up by then
+        # the mild spike: 20 binades at once fail fp16 -- unless the guard has moved that row's reference up by then
+        expect[256], expect[128] = (8, 9), (16, 17)
     for cfg, redone in ((_persistent_cfg(name, True), expect[256]), (_persistent_cfg(name, False), 0),
                         (_native(name, 128, 64, 4, True, True), expect[128]), (_native(name, 128, 64, 4, True, False), 0),
                         (kc.FlashForwardKernelConfig(name, 128, 128, 64, 4, True, True, True, 2, 2, 0, True, True), 0)):
@@ -180,7 +185,13 @@ def test_optimized_softmax_keeps_the_reference_meaning(monkeypatch):
         stats.zero_()
         out2, _ = flash_attention_kernels.forward(cfg, q, k, v, None, stats=stats)
         # (a 30-sigma K row sends EVERY query of its head ~+-43 binades off: all S / B_r workgroups of that head start over)
-        assert kc.softmax_mode(cfg) == "speculative" and stats[1].item() == 1024 // cfg.B_r
+        # (... of the compiler-scheduled body and of fp16; the bf16 ring form of (128, 64, 4)+buffer -- seq_len % 256 == 0 --
+        # has the persistent kernel's 2^120 limit, which +-43 binades stay under: only the spiked queries' items are redone)
+        assert kc.softmax_mode(cfg) == "speculative"
+        if kc.has_ring_form(cfg) and cfg.dtype == kc.DType.BF16:
+            assert 1 <= stats[1].item() < 1024 // cfg.B_r, stats.tolist()
+        else:
+            assert stats[1].item() == 1024 // cfg.B_r, stats.tolist()
         ref = ut.py_flash_attention(q, k, v, upcast=True).float()
         for o in (out, out2):
             assert ((o.float() - ref).abs() <= TOL[dtype] * (1 + ref.abs())).all()
@@ -505,21 +516,26 @@ def test_speculative_softmax_second_pass(rise, psq):
                 assert torch.equal(flash_attention.forward(spec, q, k, v), out)
 
 
-@pytest.mark.parametrize("family", ["persistent", "32-row", "16-row"])
+@pytest.mark.parametrize("family", ["persistent", "ring", "32-row", "16-row"])
 def test_speculative_softmax_limit_and_large_values(family):
     """The bf16 limit of the first pass.  32- and 16-rows-per-wave kernels: l < 2^64 (spec_limit) -- a rise of ~50 binades
     above the first visited tile stays in the first pass, ~75 binades takes the second; there the rows equal the
     speculative_softmax = False build bit for bit.  The persistent kernel guards its first pass (spec_guard: above l = 2^32 it
     rescales O and l by an exact power of two and looks at O itself), so its limit only has to keep P finite: 2^120 --
     50 and 75 binades stay in the first pass (with V scaled by 2^40: |O| <= 2^115 finite), ~135 binades takes the second.
+    `ring`: (128, 64, 4)+buffer at seq_len % 256 == 0 IS the persistent kernel (one Q tile per wave), with its guard and its
+    limit; `32-row`: the same configuration at another multiple of 128 is the compiler-scheduled body with the 2^64 limit.
     Everything stays finite and within relative tolerance of fp32 eager; the counter says which pass ran."""
     cfg_of = {"persistent": lambda o: _persistent_cfg(kc.DType.BF16, o),
+              "ring": lambda o: _native(kc.DType.BF16, 128, 64, 4, True, o),
               "32-row": lambda o: _native(kc.DType.BF16, 128, 64, 4, True, o),
               "16-row": lambda o: _native(kc.DType.BF16, 64, 32, 4, False, o)}[family]
     spec, safe = cfg_of(True), cfg_of(False)
-    B, H, S, b_, h_ = 2, 3, 1024, 1, 2
-    vscale = 2.0 ** 40 if family == "persistent" else 2.0 ** 50
-    cases = ((50.0, False), (75.0, False), (135.0, True)) if family == "persistent" else ((50.0, False), (75.0, True))
+    B, H, S, b_, h_ = 2, 3, (896 if family == "32-row" else 1024), 1, 2
+    guarded = family in ("persistent", "ring")
+    assert kc.has_ring_form(spec) == (family in ("ring", "32-row"))
+    vscale = 2.0 ** 40 if guarded else 2.0 ** 50
+    cases = ((50.0, False), (75.0, False), (135.0, True)) if guarded else ((50.0, False), (75.0, True))
     for binades, second in cases:
         a = (binades / (128 * 1.4426950408889634 / 128 ** 0.5)) ** 0.5   # q.k c = a^2 128 c binades above an N(0, 1) tile
         qc = ut.QKVConfig(n_heads=H, d_head=128, batch_size=B, seq_len=S, dtype=torch.bfloat16, device=torch.device(DEV))
@@ -562,17 +578,19 @@ def test_speculative_guard_rescues_rising_logits():
         tile_from_end = (S - 1 - torch.arange(S, device=DEV)) // 64
         q[..., 0] = a
         k[..., 0] = (a * tile_from_end.float()).view(1, S, 1).to(dtype)
-        spec, safe = _persistent_cfg(name, True), _persistent_cfg(name, False)
-        stats = torch.zeros(2, dtype=torch.int32, device=DEV)
-        out, _ = flash_attention_kernels.forward(spec, q, k, v, None, stats=stats)
-        assert torch.isfinite(out.float()).all()
-        assert (stats[1].item() > 0) == redo, (str(dtype), step, stats.tolist())
         ref = ut.py_flash_attention(q, k, v, upcast=True).float()
         tol = TOL[dtype] * (1 + ref.abs())
-        assert ((out.float() - ref).abs() <= tol).all(), (str(dtype), step)
-        out_safe = flash_attention.forward(safe, q, k, v)
-        assert ((out.float() - out_safe.float()).abs() <= 2 * tol).all()
-        assert torch.equal(flash_attention.forward(spec, q, k, v), out)
+        # the (256, 64, 4) kernel, and its one-Q-tile-per-wave form behind (128, 64, 4)+buffer (seq_len % 256 == 0)
+        for spec, safe in ((_persistent_cfg(name, True), _persistent_cfg(name, False)),
+                           (_native(name, 128, 64, 4, True, True), _native(name, 128, 64, 4, True, False))):
+            stats = torch.zeros(2, dtype=torch.int32, device=DEV)
+            out, _ = flash_attention_kernels.forward(spec, q, k, v, None, stats=stats)
+            assert torch.isfinite(out.float()).all()
+            assert (stats[1].item() > 0) == redo, (str(spec), step, stats.tolist())
+            assert ((out.float() - ref).abs() <= tol).all(), (str(spec), step)
+            out_safe = flash_attention.forward(safe, q, k, v)
+            assert ((out.float() - out_safe.float()).abs() <= 2 * tol).all()
+            assert torch.equal(flash_attention.forward(spec, q, k, v), out)
 
 
 def test_speculative_softmax_on_the_32_row_kernels_starts_over():
@@ -1736,7 +1754,10 @@ def test_ring_form_of_the_reference_winning_shape():
     multiples of 128 by the compiler-scheduled 32-rows-per-wave body.  The ring form runs the lazy rescale per 32-row tile
     exactly as the (256, 64, 4) kernel's non-speculative form does, so the two agree BIT FOR BIT; both forms are inside
     the reference's tolerance rule against the eager golden; every reference config of the shape reaches it (the
-    operand-fetch hints and optimized_softmax do not change the device variant)."""
+    operand-fetch hints and optimized_softmax do not change the device variant).  The speculative sibling of the
+    configuration runs the same kernel's speculative schedule: no rotated units there, so its row sums add up in the
+    lazy schedule's order and an item it gives up on is redone BY the lazy schedule -- bit-identical again, wherever no
+    reference moves (and in the items fa_fwd_stats counts as run twice)."""
     shape_cfgs = [c for c in kc.get_kernels_to_build() if (c.B_r, c.B_c, c.n_warps) == (128, 64, 4) and c.mma_double_buffer_loads]
     assert len(shape_cfgs) >= 8 and all(kc.has_ring_form(c) for c in shape_cfgs)
     for name, dtype in ((kc.DType.BF16, torch.bfloat16), (kc.DType.FP16, torch.float16)):
@@ -1756,6 +1777,26 @@ def test_ring_form_of_the_reference_winning_shape():
                 out = flash_attention.forward(c, q, k, v)
                 assert torch.equal(out, want), (str(c), B, S, H)
             assert ((want.float() - eager).abs() <= TOL[dtype] * (1 + eager.abs())).all()
+            spec = kc.as_native(cfgs[0], speculative_softmax=True)
+            assert kc.has_ring_form(spec) and kc.softmax_mode(spec, seq_len=S) == "speculative"
+            stats = torch.zeros(2, dtype=torch.int32, device=DEV)
+            out, _ = flash_attention_kernels.forward(spec, q, k, v, None, stats=stats)
+            assert stats[0].item() == B * H * (S // 128) and 1 <= stats[1].item() <= 2 * (S // 128), stats.tolist()
+            # the spiked queries' item was redone by the lazy schedule, every (batch, head) without a spike never left
+            # the common path: the same bits; the other items of the spiked head may have met the guard (a reference moved
+            # by an exact power of two, at another moment than the lazy schedule moves its own): the tolerance rule
+            blk = slice((S // 2) // 128 * 128, (S // 2) // 128 * 128 + 128)
+            assert torch.equal(out[0, blk, 1], want[0, blk, 1]), (str(spec), B, S, H)
+            rest = out.clone(); rest[0, :, 1] = want[0, :, 1]
+            assert torch.equal(rest, want), (str(spec), B, S, H)
+            assert ((out.float() - eager).abs() <= TOL[dtype] * (1 + eager.abs())).all()
+            # nothing to give up on: the same bits, nothing redone
+            k2, q2 = k.clone(), q.clone()
+            k2[0, S // 3, 1] = k[0, S // 3, 0]
+            q2[0, S // 2:S // 2 + 3, 1] = q[0, S // 2:S // 2 + 3, 0]
+            stats.zero_()
+            out, _ = flash_attention_kernels.forward(spec, q2, k2, v, None, stats=stats)
+            assert torch.equal(out, flash_attention.forward(big, q2, k2, v)) and stats[1].item() == 0
         # a multiple of 128 that is not one of 256: the compiler-scheduled body, the reference's eager arithmetic
         gen = torch.Generator(device=DEV).manual_seed(384)
         q, k, v = (torch.randn((2, 384, 4, 128), dtype=dtype, device=DEV, generator=gen) for _ in range(3))

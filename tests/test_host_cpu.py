@@ -148,7 +148,12 @@ def test_one_flag_one_meaning_softmax_mode_of_every_config():
     others = [c for c in kc.get_kernels_to_build() if not kc.has_ring_form(c)]
     assert all(_capi.query(c).ring_form == 0 for c in others)
     assert kc.softmax_mode(ring[0], seq_len=1024) == "lazy" and kc.softmax_mode(ring[0], seq_len=640) != "lazy" and kc.softmax_mode(ring[0]) != "lazy"
-    assert not kc.has_ring_form(ring[0], masked=True) and not kc.has_ring_form(kc.as_native(ring[0], speculative_softmax=True))
+    assert not kc.has_ring_form(ring[0], masked=True)
+    # ... and its speculative sibling (asked for through fa_fwd_opts): the same kernel's speculative schedule
+    spec = kc.as_native(ring[0], speculative_softmax=True)
+    assert kc.has_ring_form(spec) and kc.softmax_mode(spec, seq_len=1024) == kc.softmax_mode(spec, seq_len=640) == "speculative"
+    i = _capi.query(ring[0], speculative=1)
+    assert i.ring_form == 1 and i.ring_softmax_mode == 3 and i.softmax_mode == 3
     assert kc.softmax_mode(kc.best_config(kc.DType.BF16, 100, masked=True), masked=True) == "eager"
 
 
