@@ -63,11 +63,22 @@ echo "== masked build with nothing masked"; timeout 300 python tools/masked_prob
 fi
 if has tune; then
 echo "== tune64 (this tree's variants + the previous round's kernel, one process, interleaved; twice)"; timeout 600 $L/tune64 reps=8 > $OUT/tune64.txt 2>&1; timeout 600 $L/tune64 reps=8 > $OUT/tune64_again.txt 2>&1; grep -h "S= 4096\|S=  512" $OUT/tune64.txt | cut -c1-140
+echo "== check_qt1: the one-Q-tile-per-wave forms (lazy, speculative) against the 64-row lazy kernel, bit for bit"; timeout 120 $L/check_qt1 > $OUT/check_qt1.txt 2>&1; tail -3 $OUT/check_qt1.txt
 echo "== trace64_items / seam"; for a in "512 16 16" "1024 16 16" "4096 4 16"; do timeout 120 $L/trace64_items $a 2>&1 | grep -E "^==|mean over" | tail -2; done > $OUT/trace64_items.txt; for a in "512 16 16" "4096 4 16"; do timeout 120 $L/trace64_seam $a 2>&1 | grep -E "first seam" | tail -1 >> $OUT/trace64_items.txt; done; cut -c1-300 $OUT/trace64_items.txt
 echo "== trace64_tl: the prologue and the visits of a two-item walk (S = 512), warm and flushed"; timeout 120 $L/trace64_tl 512 16 2>&1 | grep -E "^==|^mean|^spread|^wg   0" > $OUT/trace64_timeline_s512.txt; cut -c1-260 $OUT/trace64_timeline_s512.txt
 echo "== mfma_energy"; timeout 300 $L/mfma_energy > $OUT/mfma_energy.txt 2>&1; $L/mfma_energy quick >> $OUT/mfma_energy.txt 2>&1; tail -6 $OUT/mfma_energy.txt
 fi
 if has sweeps; then
+echo "== the reference's winning shape at C1 under the driver's protocol: ring form lazy / speculative, and the shape without +buffer (compiler-scheduled body)"
+RB="(BF16, 128, 128, 64, 4): async+eager+swizzled+load_0_0_0_tiles"
+for rep in 1 2; do for kk in "$RB+buffer" "$RB+buffer+spec_softmax" "$RB" "${RB/BF16/FP16}+buffer" "${RB/BF16/FP16}+buffer+spec_softmax"; do
+  dt=bf16; case "$kk" in "(FP16"*) dt=fp16;; esac
+  python bench.py --steps 20 --warmup 5 --dtype $dt --kernel "$kk" --no-variants --no-traffic --no-cpu-baseline --no-mfma-roof --hermetic-reps 20 2>/dev/null | python -c "
+import sys, json
+for l in sys.stdin:
+    if l.startswith('{'):
+        d = json.loads(l); print('$rep', d['config']['kernel'].ljust(88), '%.1f TFLOP/s  sustained %.1f  hermetic %.1f' % (d['value'], d.get('sustained', {}).get('tflops', 0), d.get('protocols', {}).get('hermetic', {}).get('tflops', 0)))"
+done; done > $OUT/ring_c1.txt; cat $OUT/ring_c1.txt
 echo "== sweeps (native; the reference's 80 configs with the reference's meaning of opt_softmax)"
 KERNELS=native timeout 900 python flash_attention_from_scratch_amd/tools/pt_bench.py --seq_lens 4096 --batch 4 --num_repeats 20 --num_warmups 5 > $OUT/sweep_native_c1.csv 2> $OUT/sweep.err
 KERNELS=tune timeout 900 python flash_attention_from_scratch_amd/tools/pt_bench.py --seq_lens 4096 --batch 4 --num_repeats 20 --num_warmups 5 > $OUT/sweep_tune_c1.csv 2>> $OUT/sweep.err

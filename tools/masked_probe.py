@@ -15,10 +15,17 @@ from flash_attention_from_scratch_amd import _capi  # noqa: E402
 from flash_helpers import kernel_configs as kc  # noqa: E402
 
 
-def timed(fn, reps=30):
+def timed(fn, reps=30, warm_s=0.3):
+    # clocks preconditioned like bench.py does (the governor ramps from idle over ~0.2 s; without it the FIRST row of the
+    # table read 10 % low), no synchronize between the warm launches and the timed ones
+    import time
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < warm_s:
+        for _ in range(16):
+            fn()
+        torch.cuda.current_stream().synchronize()
     for _ in range(8):
         fn()
-    torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps):
