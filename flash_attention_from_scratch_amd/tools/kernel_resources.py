@@ -28,7 +28,7 @@ def demangle_variant(name):
         spec = int(nums[4]) if len(nums) >= 5 else 0  # the speculative softmax = optimized_softmax
         qtp = int(nums[6]) if len(nums) >= 7 else 2   # 1: the ring form of (B_r 128, B_c 64, 4 waves) + buffer
         return dict(dtype=dt, rows_per_wave=32 * qtp, n_waves=4, B_c=64, swizzled=1, eager=1, opt_softmax=spec,
-                    pipelined=1, dma=1, masked=2 * masked + rag, d_head=128)
+                    pipelined=1, dma=1, masked=2 * masked + rag, d_head=128, ring_kernel=1)
     if "fa_fwd_kernel16" in name and len(nums) >= 6:
         dt, nw, bc, swz, eager, opt = map(int, nums[:6])
         return dict(dtype=dt, rows_per_wave=16, n_waves=nw, B_c=bc, swizzled=swz, eager=eager,
@@ -72,8 +72,9 @@ def collect():
         r["B_r"] = r.get("rows_per_wave", 0) * r.get("n_waves", 0)
         stages = 2 if r.get("eager") else 1
         r["lds_bytes"] = max(2 * stages * r.get("B_c", 0), r["B_r"]) * 2 * r.get("d_head", 128)
-        if r.get("rows_per_wave") == 64 and r.get("pipelined"):
-            # the persistent schedule: 4-stage K and V rings + 8 KiB of O staging per wave
+        if r.get("ring_kernel"):
+            # the persistent schedule (fa_fwd_kernel64, either number of Q tiles per wave): 4-stage K and V rings + 8 KiB of
+            # staging per wave (RingTraits::kLdsBytes)
             r["lds_bytes"] = (2 * 4 * r.get("B_c", 0) + 32 * r.get("n_waves", 0)) * 2 * r.get("d_head", 128)
     return rows
 
