@@ -93,6 +93,8 @@ fi
 if has soak; then
 echo "== soak 60 s"; timeout 300 python tools/soak.py 60 3 > $OUT/soak.txt 2>&1; tail -2 $OUT/soak.txt
 echo "== soak 60 s under the jitter build"; FA_HIP_LIB=$PWD/$L/libfa_hip_jitter.so timeout 300 python tools/soak.py 60 17 > $OUT/soak_jitter.txt 2>&1; tail -2 $OUT/soak_jitter.txt
+echo "== soak 45 s, every device variant of the library"; timeout 300 python tools/soak.py 45 7 all > $OUT/soak_all.txt 2>&1; tail -2 $OUT/soak_all.txt
+echo "== soak 45 s + 45 s under the jitter build: the ring forms of (128, 64, 4)+buffer, plain and speculative"; timeout 300 python tools/soak.py 45 9 ring > $OUT/soak_ring.txt 2>&1; FA_HIP_LIB=$PWD/$L/libfa_hip_jitter.so timeout 300 python tools/soak.py 45 11 ring >> $OUT/soak_ring.txt 2>&1; grep "^soak\|FAIL" $OUT/soak_ring.txt | tail -4
 echo "== soak, many items per workgroup"; timeout 300 python tools/soak_many_items.py 30 5 > $OUT/soak_many_items.txt 2>&1; tail -2 $OUT/soak_many_items.txt
 echo "== jitter_check (product, then jitter build)"; timeout 300 python tools/jitter_check.py > $OUT/jitter_check.txt 2>&1; FA_HIP_LIB=$PWD/$L/libfa_hip_jitter.so timeout 300 python tools/jitter_check.py >> $OUT/jitter_check.txt 2>&1; grep -c "repeat=1" $OUT/jitter_check.txt
 fi

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Soak of the persistent kernel: random (batch, heads, seq_len, causal, dtype, speculative) launches for a time budget,
 each checked against fp32 attention computed by torch on the same device, launched twice (bits must repeat) and, every
-few launches, with another stream hammering the memory system.  Usage: python tools/soak.py [seconds] [seed] [all]   (all: every device variant of the library, plain launches)"""
+few launches, with another stream hammering the memory system.  Usage: python tools/soak.py [seconds] [seed] [all | ring]   (all: every device variant of the library; ring: the one-Q-tile-per-wave forms of (128, 64, 4)+buffer)"""
 import random
 import sys
 import time
@@ -32,6 +32,13 @@ def main():
     t0, n, bad = time.time(), 0, 0
     every = len(sys.argv) > 3 and sys.argv[3] == "all"   # every device variant of the library instead of the persistent kernel
     pool = kc.get_all_supported_configs() + kc.get_d64_kernel_configs() if every else []
+    # "ring": only the reference's winning shape, (B_r 128, B_c 64, 4 warps) + buffer, plain and speculative, at multiples
+    # of 256 keys -- the persistent kernel's one-Q-tile-per-wave forms (round 5), spiked every second launch
+    ring = len(sys.argv) > 3 and sys.argv[3] == "ring"
+    if ring:
+        every = True
+        pool = [kc.as_native(c, speculative_softmax=sp) for c in kc.get_kernels_to_build() if kc.has_ring_form(c) for sp in (False, True)]
+        assert pool and all(kc.has_ring_form(c) for c in pool)
     while time.time() - t0 < budget:
         dtype, name = rng.choice(((torch.bfloat16, kc.DType.BF16), (torch.float16, kc.DType.FP16)))
         spec = rng.random() < 0.7
@@ -39,9 +46,9 @@ def main():
         if every:
             cfg = rng.choice(pool)
             dtype, spec = cfg.dtype.to_torch_dtype(), kc.wants_speculative(cfg)
-        masked = rng.random() < 0.5
+        masked = rng.random() < 0.5 and not ring
         S = rng.choice([64, 100, 200, 256, 300, 500, 512, 768, 1000, 1024, 1500, 2048, 3000, 4096]) if masked else 256 * rng.randint(1, 20)
-        if every and not masked:
+        if every and not masked and not ring:
             S = max(cfg.B_r, cfg.B_c) * rng.randint(1, 24)
         causal = masked and rng.random() < 0.6
         B, H = rng.randint(1, 6), rng.choice([1, 2, 3, 5, 8, 16, 24])
@@ -50,7 +57,7 @@ def main():
             H = max(1, H // 2)
         gen = torch.Generator(device=DEV).manual_seed(rng.randrange(1 << 30))
         q, k, v = (torch.randn((B, S, H, cfg.d_head), dtype=dtype, device=DEV, generator=gen) for _ in range(3))
-        if rng.random() < 0.3:   # a spike: the speculative first pass fails somewhere
+        if rng.random() < (0.5 if ring else 0.3):   # a spike: the speculative first pass fails somewhere
             b_, h_, key = rng.randrange(B), rng.randrange(H), rng.randrange(S)
             u = (torch.randint(0, 2, (cfg.d_head,), device=DEV, generator=gen).float() * 2 - 1).to(dtype)
             a = rng.choice([1.2, 3.0, 30.0])
