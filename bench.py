@@ -746,16 +746,20 @@ def _interleaved(named_cfgs, q, k, v, o, args, flop, sync, rounds=5):
 
 
 def side_by_side(cfg, q, k, v, o, args, flop, sync):
-    """`variants` of the driver line: the default kernel beside (a) the same with the speculative softmax always on (when the
-    default is adaptive), (b) the running-max (lazy rescale) kernel -- north_star's "fp32 running max/sum" literally --
-    and (c) the opt-in pre-scaled Q (NOT the reference's arithmetic: DESIGN.md 3.7; never `value`)."""
+    """`variants` of the driver line: the default kernel (the stateless speculative softmax since round 6) beside (a) the
+    running-max (lazy rescale) kernel -- the reference's arithmetic family, north_star's "fp32 running max/sum" literally;
+    its number is also the line's top-level `value_reference_arithmetic` --, (b) the opt-in adaptive mode of rounds 4-5 (on
+    benign data the same kernel as the default) and (c) the opt-in pre-scaled Q (NOT the reference's arithmetic: DESIGN.md
+    3.7; never `value`)."""
     from dataclasses import replace as _replace
 
     named = [("default", cfg)]
-    if getattr(cfg, "adaptive_softmax", False):
-        named.append(("speculative_always", _replace(cfg, adaptive_softmax=False)))
     if getattr(cfg, "speculative_softmax", False):
         named.append(("lazy", _replace(cfg, speculative_softmax=False, adaptive_softmax=False)))
+        if not getattr(cfg, "adaptive_softmax", False):
+            named.append(("adaptive_opt_in", _replace(cfg, adaptive_softmax=True)))
+        else:
+            named.append(("speculative_always", _replace(cfg, adaptive_softmax=False)))
     named.append(("prescaled_q", _replace(cfg, prescaled_q=True, adaptive_softmax=False)))
     out = _interleaved(named, q, k, v, o, args, flop, sync)
     if isinstance(out.get("prescaled_q"), dict) and "tflops" in out["prescaled_q"]:
@@ -767,8 +771,10 @@ def side_by_side(cfg, q, k, v, o, args, flop, sync):
 
 def robustness(cfg, shape, dtype, device, args, flop, sync):
     """`robustness` of the driver line: the same workload shape on data that is not N(0, 1) (make_inputs: `heavy` = Student-t
-    K, `sink` = +12 nats on the first four keys, visited last), the default (adaptive) kernel beside the always-speculative
-    and the running-max one, interleaved; items_redone of one always-speculative launch; what the adaptive mode did."""
+    K, `sink` = +12 nats on the first four keys -- which the speculative first pass visits FIRST since round 6), the
+    always-speculative kernel (`speculative_always`: what best_config() is since round 6, so `default` is the same kernel)
+    beside the running-max one (`lazy`) and the opt-in adaptive mode, interleaved; `items_redone` of one speculative launch;
+    what the adaptive mode did."""
     from dataclasses import replace as _replace
 
     import flash_attention
@@ -779,6 +785,7 @@ def robustness(cfg, shape, dtype, device, args, flop, sync):
         return None
     spec = _replace(cfg, adaptive_softmax=False)
     lazy = _replace(cfg, speculative_softmax=False, adaptive_softmax=False)
+    adaptive = _replace(cfg, adaptive_softmax=True)
     out = {}
     cases = [("heavy", dtype), ("sink", dtype)]
     if dtype == torch.bfloat16:
@@ -790,17 +797,21 @@ def robustness(cfg, shape, dtype, device, args, flop, sync):
         from flash_helpers import kernel_configs as kc
 
         name = kc.DType.BF16 if dt == torch.bfloat16 else kc.DType.FP16
-        c_def, c_spec, c_lazy = (_replace(c, dtype=name) for c in (cfg, spec, lazy))
+        c_def, c_spec, c_lazy, c_ada = (_replace(c, dtype=name) for c in (cfg, spec, lazy, adaptive))
         _capi.adaptive_reset(device.index or 0)
         before = _capi.adaptive_state(device.index or 0)
         stats = torch.zeros(2, dtype=torch.int32, device=device)
         flash_attention_kernels.forward(c_spec, q, k, v, o, stats=stats)
         sync()
         items, redone = (int(x) for x in stats.tolist())
-        rec = _interleaved([("lazy", c_lazy), ("default", c_def), ("speculative_always", c_spec)], q, k, v, o, args, flop, sync, rounds=4)
+        rec = _interleaved([("lazy", c_lazy), ("default", c_def), ("speculative_always", c_spec), ("adaptive_opt_in", c_ada)],
+                           q, k, v, o, args, flop, sync, rounds=4)
         after = _capi.adaptive_state(device.index or 0)
         rec["items"] = items
+        rec["items_redone"] = redone
         rec["items_redone_by_an_always_speculative_launch"] = redone
+        if isinstance(rec.get("speculative_always"), dict):
+            rec["speculative_always"]["items_redone"] = redone
         rec["adaptive"] = {"launches": after["launches"] - before["launches"], "demoted": after["demoted"],
                            "reports": after["reports"], "hold": after["hold"]}
         rec["default_over_lazy"] = (rec["default"].get("ratio_to_lazy", {}).get("mean")
@@ -847,7 +858,7 @@ def main():
     ap.add_argument("--rocprof-rank", type=int, default=-1,
                     help="N > 1: rank R runs under `rocprofv3 --kernel-trace --stats` and leaves --rocprof-dir/scale_rank<R>*.csv "
                          "(one rank only: the profiled rank clocks a few % lower, see MI355X_MICROARCH.md DVFS)")
-    ap.add_argument("--rocprof-dir", default=os.path.join("profiles", "r05"))
+    ap.add_argument("--rocprof-dir", default=os.path.join("profiles", "r06"))
     ap.add_argument("--dist-backend", default="gloo", choices=["gloo", "nccl"],
                     help="barrier + max-over-ranks only (the data path has no collective): gloo (default; on "
                          "a box with fewer GPUs than ranks the ranks share devices and the timings mean "
@@ -1129,6 +1140,13 @@ def main():
             }
         if world == 1 and not args.kernel and not args.no_variants and hasattr(cfg, "prescaled_q") and not cfg.prescaled_q:
             line["variants"] = side_by_side(cfg, q, k, v, o, args, flop_per_step_rank, sync)
+            lz = line["variants"].get("lazy")
+            if isinstance(lz, dict) and "tflops" in lz:
+                # the reference-arithmetic family (running max, lazy rescale) beside `value`, which is the speculative form
+                # (say both numbers whenever the headline is quoted).  Same run, interleaved rounds.
+                line["value_reference_arithmetic"] = lz["tflops"]
+                line["value_reference_arithmetic_what"] = ("TFLOP/s of the running-max (lazy rescale) kernel " + lz["kernel"]
+                                                           + ": variants.lazy of this run; `value` is the speculative softmax")
             line["robustness"] = robustness(cfg, (hi - lo, seq, heads, d), dtype, device, args, flop_per_step_rank, sync)
         if world == 1 and not args.no_mfma_roof:
             del flush_buf

@@ -30,7 +30,7 @@ EXPORTED_SYMBOLS = (
     "fa_adaptive_state", "fa_adaptive_state_for", "fa_adaptive_reset", "fa_adaptive_simulate", "fa_get_kernel_sized", "fa_fwd_query_sized", "fa_abi_version",
 )
 FA_SPECULATIVE_OFF, FA_SPECULATIVE_ALWAYS, FA_SPECULATIVE_ADAPTIVE = 0, 1, 2  # fa_speculative_mode
-FA_ABI_VERSION = 5
+FA_ABI_VERSION = 6
 SOFTMAX_MODES = ("eager", "first_block_skip", "lazy", "speculative")  # fa_softmax_mode
 
 
@@ -59,6 +59,7 @@ class FaKernelInfo(ctypes.Structure):
         # ABI 5: the ring form of a 32-rows-per-wave configuration (include/fa_hip.h)
         ("ring_form", ctypes.c_int32), ("ring_softmax_mode", ctypes.c_int32),
         ("ring_num_regs", ctypes.c_int32), ("ring_scratch_bytes", ctypes.c_int32),
+        ("ring_lds_bytes", ctypes.c_int32), ("persistent", ctypes.c_int32),
     ]
 
 

@@ -178,7 +178,6 @@ struct AdaptivePolicy {
 // its own report word and probe event: a failing workload demotes its own configuration only -- an fp16 attention-sink layer
 // no longer drags a benign bf16 one down with it, and a clean probe of one configuration no longer resets another's hold
 // (ADVICE r04).  What stays shared is the mutex (launches are enqueued one at a time per device anyway).
-constexpr int kAdaptiveSlots = 512;   // >= registry().size(), checked at init
 struct AdaptiveSlot {
     AdaptivePolicy p;
     hipEvent_t probe_done = nullptr;  // created at the slot's first probe
@@ -187,7 +186,9 @@ struct AdaptiveState {
     std::mutex mu;
     uint32_t *flag_host = nullptr;  // hipHostMalloc'ed (mapped, coherent) words, one per slot; null: no pinned memory -> always speculative
     uint32_t *flag_dev = nullptr;   // the same words as the device addresses them
-    AdaptiveSlot slot[kAdaptiveSlots];
+    std::vector<AdaptiveSlot> slot; // registry().size() records, allocated with the report words at the device's init (ADVICE
+                                    // r05: a fixed 512 x 64 static array put 1.3 MB of initialised data into the library)
+    int n_slots() const { return (int)slot.size(); }
 };
 struct DeviceState {
     std::once_flag once;
@@ -217,20 +218,16 @@ void do_init_body(int dev, DeviceState *st) {
     // flash_attention.cu:142-149: opt in to large dynamic shared memory per kernel (a per-device
     // attribute of the function: applied with `dev` current)
     for (const auto &e : registry()) {
-        if (e.lds_bytes > 48 * 1024) {
-            hipError_t rc = hipFuncSetAttribute((const void *)e.fn,
-                                                hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                e.lds_bytes);
-            if (rc == hipSuccess && e.fn_ragged)
-                rc = hipFuncSetAttribute((const void *)e.fn_ragged, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         e.lds_bytes);
-            if (rc == hipSuccess && e.fn_ring)
-                rc = hipFuncSetAttribute((const void *)e.fn_ring, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         e.ring_lds_bytes);
+        // (each function by ITS OWN LDS size: the ring form's 160 KB does not depend on what the compiler-scheduled body of
+        // the same entry uses -- ADVICE r05)
+        const struct { fa::kernel_fn fn; int bytes; } fns[] = {{e.fn, e.lds_bytes}, {e.fn_ragged, e.lds_bytes}, {e.fn_ring, e.ring_lds_bytes}};
+        for (const auto &f : fns) {
+            if (!f.fn || f.bytes <= 48 * 1024) continue;
+            const hipError_t rc = hipFuncSetAttribute((const void *)f.fn, hipFuncAttributeMaxDynamicSharedMemorySize, f.bytes);
             if (rc != hipSuccess) {
                 st->status = FA_ERR_LAUNCH;
-                snprintf(st->err, sizeof(st->err), "hipFuncSetAttribute(%d B LDS) on device %d: %s",
-                         e.lds_bytes, dev, hipGetErrorString(rc));
+                snprintf(st->err, sizeof(st->err), "hipFuncSetAttribute(%d B LDS) on device %d: %s", f.bytes, dev,
+                         hipGetErrorString(rc));
                 return;
             }
         }
@@ -241,11 +238,11 @@ void do_init(int dev, DeviceState *st) {
     do_init_body(dev, st);
     if (st->status == FA_OK) {  // the adaptive mode's report word (see AdaptiveState); without it the mode stays speculative
         void *h = nullptr, *d = nullptr;
-        const size_t bytes = sizeof(uint32_t) * kAdaptiveSlots;
-        if ((int)registry().size() <= kAdaptiveSlots &&
-            hipHostMalloc(&h, bytes, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess && h &&
+        const size_t bytes = sizeof(uint32_t) * registry().size();
+        if (hipHostMalloc(&h, bytes, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess && h &&
             hipHostGetDevicePointer(&d, h, 0) == hipSuccess && d) {
             memset(h, 0, bytes);
+            st->adaptive.slot = std::vector<AdaptiveSlot>(registry().size());
             st->adaptive.flag_host = (uint32_t *)h;
             st->adaptive.flag_dev = (uint32_t *)d;
         } else {
@@ -560,7 +557,7 @@ int fa_fwd_launch_ex(const fa_fwd_args *args, const fa_fwd_opts *opts, void *str
         AdaptiveState &ad = dev->adaptive;
         const int idx = (int)(e - registry().data());   // the record of THIS device variant
         bool demote = false;
-        if (cap == hipStreamCaptureStatusNone && idx >= 0 && idx < kAdaptiveSlots) {
+        if (cap == hipStreamCaptureStatusNone && idx >= 0 && idx < ad.n_slots()) {
             AdaptiveSlot &sl = ad.slot[idx];
             probe_lock = std::unique_lock<std::mutex>(ad.mu);
             int probe = AdaptivePolicy::PROBE_NA;
@@ -618,8 +615,7 @@ int fa_adaptive_state(int device, fa_adaptive_info *out) {
     std::lock_guard<std::mutex> lock(ad.mu);
     // the device's records taken together: counters summed; mode / hold / remaining of the record that is demoted (or was
     // demoted longest)
-    const int n = (int)registry().size() < kAdaptiveSlots ? (int)registry().size() : kAdaptiveSlots;
-    for (int i = 0; i < n; ++i) add_slot(ad, i, out);
+    for (int i = 0; i < ad.n_slots(); ++i) add_slot(ad, i, out);
     out->available = ad.flag_host != nullptr;
     return FA_OK;
 }
@@ -645,7 +641,7 @@ int fa_adaptive_state_for(int device, const fa_fwd_config *cfg, const fa_fwd_opt
     AdaptiveState &ad = st.adaptive;
     std::lock_guard<std::mutex> lock(ad.mu);
     const int idx = (int)(e - registry().data());
-    if (idx >= 0 && idx < kAdaptiveSlots) {
+    if (idx >= 0 && idx < ad.n_slots()) {
         const AdaptivePolicy &p = ad.slot[idx].p;
         out->launches = p.seq; out->demoted = p.demoted; out->reports = p.reports;
         out->hold = p.hold; out->mode = p.mode; out->remaining = p.remaining;
@@ -679,7 +675,7 @@ int fa_adaptive_reset(int device) {
     if (!st.inited.load(std::memory_order_acquire)) return FA_OK;
     AdaptiveState &ad = st.adaptive;
     std::lock_guard<std::mutex> lock(ad.mu);
-    for (int i = 0; i < kAdaptiveSlots; ++i)
+    for (int i = 0; i < ad.n_slots(); ++i)
         ad.slot[i].p.reset(ad.flag_host ? __atomic_load_n(ad.flag_host + i, __ATOMIC_RELAXED) : 0u);
     return FA_OK;
 }
@@ -740,6 +736,8 @@ static void fill_info(const fa::KernelEntry &e, fa_kernel_info *out) {
         (void)hipGetLastError();  // no device: resource fields stay -1
     }
     out->ring_form = e.fn_ring ? 1 : 0;
+    out->ring_lds_bytes = e.fn_ring ? e.ring_lds_bytes : 0;
+    out->persistent = e.persistent;
     out->ring_softmax_mode = e.fn_ring ? (e.softmax_mode == FA_SOFTMAX_SPECULATIVE ? FA_SOFTMAX_SPECULATIVE : FA_SOFTMAX_LAZY) : 0;
     out->ring_num_regs = out->ring_scratch_bytes = e.fn_ring ? -1 : 0;
     if (e.fn_ring) {
@@ -774,6 +772,6 @@ int fa_abi_version(void) { return FA_ABI_VERSION; }
 
 const char *fa_last_error(void) { return g_err; }
 
-const char *fa_version(void) { return "fa_hip 0.5 gfx950"; }
+const char *fa_version(void) { return "fa_hip 0.6 gfx950"; }
 
 }  // extern "C"

@@ -458,6 +458,13 @@ fa_fwd_kernel64(const KernelArgs args) {
     // (same encoding) of the items whose check failed in any row of this wave.
     auto walk = [&](auto fast_tag, const unsigned long long todo) -> unsigned long long {
         constexpr bool FAST = decltype(fast_tag)::value;
+        // FWD (round 6): the speculative first pass of the plain forms visits an item's K / V tiles FIRST-TO-LAST.  Its
+        // reference is the row max of the first tile it visits, and attention-sink keys sit at the START of a sequence: walked
+        // last-to-first (forward_kernel.cuh:142) they arrived last, ~17 binades above a reference taken at the other end --
+        // beyond fp16's 2^15, every item redone.  The order is the only difference (same tiles, same arithmetic per tile; the
+        // fp32 sums add up in the other order).  The second pass (running max) and the masked forms (a causal item's diagonal
+        // tiles are its first) keep the reference's order.
+        constexpr bool FWD = FAST && !MASK;
         unsigned long long failed = 0;  // FAST: the ordinals whose check failed; the second pass: the number of items it computed
         const int n_items = args.n_bh * nq;
         auto next_ord = [&](int o) {  // next ordinal of this pass behind o, or -1 (scalar; item seams only)
@@ -485,7 +492,7 @@ fa_fwd_kernel64(const KernelArgs args) {
         if (!(ABL & 16)) {
 #pragma unroll
             for (int j = 0; j < DMA_PER_WAVE; ++j)
-                glds16_sv(tile_at(Kg, n_kv - 1), k_off[j], smem_base + (wave + NWAVES * j) * 1024);
+                glds16_sv(tile_at(Kg, FWD ? 0 : n_kv - 1), k_off[j], smem_base + (wave + NWAVES * j) * 1024);
         }
 
         vec8 Qr[QT][KS];  // Q of the current item (AGPRs), filled through LDS (request_q / read_q below)
@@ -637,6 +644,7 @@ fa_fwd_kernel64(const KernelArgs args) {
             const bool causal = MASK && args.causal;
             int nkc = n_kv, nkn = n_kv;  // tiles of the current / next item
             auto tile_g = [&](const uint16_t *cur, const uint16_t *nxt, int j) {
+                if constexpr (FWD) return j < nkc ? tile_at(cur, j) : tile_at(nxt, j - nkc);
                 return j < nkc ? tile_at(cur, nkc - 1 - j) : tile_at(nxt, nkn - 1 - (j - nkc));
             };
             auto lane_now = [&]() {  // volatile: anything derived from threadIdx would be kept live across the walk
@@ -1034,9 +1042,12 @@ fa_fwd_kernel64(const KernelArgs args) {
                         if constexpr (RAG) {  // (a window per tile: no pointer chain)
                             kq = tile_g(Kc, Kn, it + 5);
                             vq = tile_g(Vc, Vn, it + 4);
-                        } else if constexpr (HOT) {  // (it + 5 < n_kv: the next requests are this item's next tiles down)
-                            kq -= tile_stride;
-                            vq -= tile_stride;
+                        } else if constexpr (HOT) {  // (it + 5 < n_kv: the next requests are this item's next tiles down -- FWD: up)
+                            kq += FWD ? tile_stride : -tile_stride;
+                            vq += FWD ? tile_stride : -tile_stride;
+                        } else if constexpr (FWD) {
+                            kq = (it + 5 == nkc) ? Kn : kq + tile_stride;
+                            vq = (it + 4 == nkc) ? Vn : vq + tile_stride;
                         } else {
                             kq = (it + 5 == nkc) ? Kn + (int64_t)(nkn - 1) * tile_stride : kq - tile_stride;
                             vq = (it + 4 == nkc) ? Vn + (int64_t)(nkn - 1) * tile_stride : vq - tile_stride;

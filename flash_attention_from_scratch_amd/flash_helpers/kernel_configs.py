@@ -221,11 +221,12 @@ class NativeKernelConfig(FlashForwardKernelConfig):
     adaptive_softmax: bool = False
 
     def __post_init__(self):
-        # adaptive_softmax qualifies speculative_softmax: without it there is nothing to adapt.  Cleared rather than refused,
-        # so that dataclasses.replace(best_config(...), speculative_softmax=False) -- what the docstring of best_config
-        # tells a caller who wants "never" to do -- works on its own (round 4 raised ValueError here)
+        # adaptive_softmax qualifies speculative_softmax: without it there is nothing to adapt, and a construction that
+        # asks for it alone is refused (rounds 4-5 cleared the flag silently, because best_config() carried it
+        # and replace(best_config(...), speculative_softmax=False) had to work; the default no longer carries it)
         if self.adaptive_softmax and not self.speculative_softmax:
-            object.__setattr__(self, "adaptive_softmax", False)
+            raise ValueError("adaptive_softmax=True qualifies speculative_softmax=True (fa_speculative_mode ADAPTIVE); "
+                             "it cannot be asked for on its own")
 
     def base(self) -> FlashForwardKernelConfig:
         """The plain 13-field config (what a reference user would pass)."""
@@ -546,10 +547,14 @@ def is_persistent_shape(cfg) -> bool:
         and bool(cfg.async_copy and cfg.eager_load_blocks and cfg.swizzled)
 
 
-def uses_lazy_rescale(cfg) -> bool:
-    """True for the config served by the 64-rows-per-wave device schedule, whose softmax moves
-    its reference max lazily (CPU restatement: oracle blockwise_forward_lazy)."""
-    return (cfg.d_head, cfg.B_r, cfg.B_c, cfg.n_warps, bool(cfg.mma_double_buffer_loads)) == (128, 256, 64, 4, True)
+def uses_lazy_rescale(cfg, seq_len=None) -> bool:
+    """True for the config served by the hand-placed persistent device schedule, whose softmax moves
+    its reference max lazily (CPU restatement: oracle blockwise_forward_lazy): the 64-rows-per-wave
+    shape, and -- given a ``seq_len`` that is a multiple of 256 -- the ring form of (128, 64, 4) + buffer
+    (``has_ring_form``; consistent with ``softmax_mode(cfg, seq_len=...)``)."""
+    if (cfg.d_head, cfg.B_r, cfg.B_c, cfg.n_warps, bool(cfg.mma_double_buffer_loads)) == (128, 256, 64, 4, True):
+        return True
+    return seq_len is not None and seq_len % 256 == 0 and has_ring_form(cfg)
 
 
 def has_speculative_variant(cfg, masked=False) -> bool:
@@ -601,6 +606,18 @@ def softmax_mode(cfg, masked=False, seq_len=None) -> str:
 SOFTMAX_MODES = ("eager", "first_block_skip", "lazy", "speculative")  # index = fa_softmax_mode
 
 
+def walks_kv_forward(cfg, masked=False, seq_len=None) -> bool:
+    """Round 6: the speculative FIRST PASS of the hand-placed persistent kernel (the 64-rows-per-wave shape, and the ring
+    form of (128, 64, 4) + buffer at ``seq_len % 256 == 0``) visits an item's K / V tiles first-to-last -- its reference is
+    the row max of the first tile it visits, and attention sinks sit at the first keys.  Every other
+    variant, the masked forms and the second pass keep the reference's last-to-first order (forward_kernel.cuh:142)."""
+    if masked or not (wants_speculative(cfg) and has_speculative_variant(cfg, masked)):
+        return False
+    if is_persistent_shape(cfg):
+        return True
+    return seq_len is not None and seq_len % 256 == 0 and has_ring_form(cfg, masked)
+
+
 def uses_speculative_softmax(cfg, masked=False) -> bool:
     """True where the config runs the speculative softmax: an item is first run against
     the row max of its first K/V tile only (no per-tile row max, no rescale), its row sums are checked
@@ -623,22 +640,22 @@ def best_config(dtype=DType.BF16, seq_len=4096, masked=False) -> FlashForwardKer
     rounds of four 64-key tiles; measured ahead of the 32-rows-per-wave kernels from seq_len ~1000 up,
     profiles/r01/ragged_persistent.txt), otherwise 4 waves x 32 rows.
 
-    Softmax: the speculative softmax, ADAPTIVELY (``adaptive_softmax``; fa_speculative_mode in include/fa_hip.h), for
-    both dtypes.  The persistent kernel re-centres rising rows every four visits, so in bf16 only a JUMP of ~83 nats
-    inside 256 keys sends an item to the second pass; fp16's 16-bit P leaves ~10 nats, which attention-sink-like logits
-    at the first keys (visited last) exceed.  A failed item costs its workgroup a second item time, and a launch ends
-    with its slowest workgroup (profiles/r03/sink_data.txt: heavy-tailed K, bf16, 5 of 1024 items: -9 %; sink data, fp16,
-    every item: -49 %) -- so the library watches the failure reports of its speculative launches and, once one arrives,
-    serves the following launches with the running-max (lazy) variant, probing the speculative one again every so often
-    (round 3 shipped fp16 without the speculative softmax for this reason, and bf16 with the cliff).  Both variants are
-    inside the same tolerance; ask for ``adaptive_softmax=False`` (always speculative) or ``speculative_softmax=False``
-    (never) where the last bits have to be reproducible from run to run."""
+    Softmax: the speculative softmax (``speculative_softmax``; fa_fwd_opts.speculative = 1), for both dtypes, and nothing
+    else: since round 6 the default keeps NO host-side state -- same inputs, same bits, from any process, thread, stream
+    or launch history, like the reference's launcher (src/flash_attention.cu:42,118,126-131).  What made that possible is on
+    the device: the first pass of the persistent kernel walks an item's keys first-to-last, so
+    attention-sink keys at the start of a sequence ARE its reference instead of arriving last, 17 binades above it (fp16:
+    every item used to be computed twice); it re-centres rising rows every four visits, so only a JUMP of ~83 nats (bf16) /
+    ~1.4-10 nats (fp16) inside 256 keys sends an item to the second pass.  The adaptive mode of rounds 4-5
+    (``adaptive_softmax=True``: the library watches failure reports and serves the running-max variant for a while) is
+    still there, opt-in; ``speculative_softmax=False`` is the running-max (lazy) kernel, the reference's arithmetic
+    family."""
     dtype = DType(dtype)
     pad = (-seq_len) % 256
     if pad == 0 or (masked and seq_len >= 64 and pad * 8 <= seq_len):
         return NativeKernelConfig(
-            dtype, 128, 256, 64, 4, True, True, True, 0, 0, 0, True, False, speculative_softmax=True, adaptive_softmax=True
+            dtype, 128, 256, 64, 4, True, True, True, 0, 0, 0, True, False, speculative_softmax=True
         )
     return NativeKernelConfig(
-        dtype, 128, 128, 64, 4, True, True, True, 0, 0, 0, True, False, speculative_softmax=not masked, adaptive_softmax=not masked
+        dtype, 128, 128, 64, 4, True, True, True, 0, 0, 0, True, False, speculative_softmax=not masked
     )

@@ -1,9 +1,10 @@
 // check_qt1.hip -- the one-Q-tile-per-wave form (QTP = 1) against the 64-rows-per-wave lazy kernel on the same inputs:
 // the two run the same arithmetic per 32-row tile, so their outputs must agree bit for bit.  Prints, per shape, how many
-// rows differ and where the first ones are.  The speculative one-tile form too: it has no rotated units, so its row sums
-// add up in the lazy schedule's order and an item it gives up on is redone BY the lazy schedule -- bit-identical as well,
-// on benign data (nothing redone) and on data with a large key early in the sequence of every second head (visited
-// last: the Q tiles of those heads fail the check and are redone; the lazy forms move their reference max there).
+// rows differ and where the first ones are.  The speculative one-tile form walks K / V first-to-last since round 6 (its
+// first pass; fa_fwd_kernel64.hpp FWD), so its fp32 sums add up in the other order: it is held to 2 ulp of the yardstick
+// instead (rows that agree bit for bit are counted -- the items it gives up on are redone BY the lazy schedule).  Spiky
+// data: a large key early in the sequence of every second head (the lazy forms visit it last and move their reference
+// there; the speculative form takes it as its reference) and a larger one near the end (which fails its first pass).
 #include "../csrc/fa_fwd_kernel64.hpp"
 #include <math.h>
 #include <stdio.h>
@@ -33,11 +34,12 @@ int main(int argc, char **argv) {
         srand(S + B);
         for (int t = 0; t < 3; ++t) {
             for (size_t i = 0; i < n; ++i) { float x = ((rand() & 0xffff) / 65536.0f - 0.5f) * 3.4f; uint32_t u; memcpy(&u, &x, 4); h[i] = (uint16_t)(u >> 16); }
-            if (t == 1 && spiky)  // key 5 of every second head, x 80: logits ~100 binades above the first visited tile's
-                for (int b = 0; b < B; ++b) for (int hh = 0; hh < H; hh += 2) for (int d = 0; d < D; ++d) {
-                    uint16_t &w = h[(((size_t)b * S + 5) * H + hh) * D + d];
-                    float x = bf(w) * 80.0f; uint32_t u; memcpy(&u, &x, 4); w = (uint16_t)(u >> 16);
-                }
+            if (t == 1 && spiky)  // key 5 of every second head x 80 (logits ~100 binades above an N(0, 1) tile's), key S - 6 x 240
+                for (int b = 0; b < B; ++b) for (int hh = 0; hh < H; hh += 2) for (int d = 0; d < D; ++d)
+                    for (int far = 0; far < 2; ++far) {
+                        uint16_t &w = h[(((size_t)b * S + (far ? S - 6 : 5)) * H + hh) * D + d];
+                        float x = bf(w) * (far ? 240.0f : 80.0f); uint32_t u; memcpy(&u, &x, 4); w = (uint16_t)(u >> 16);
+                    }
             CHECK(hipMemcpy(t == 0 ? q : t == 1 ? k : v, h.data(), n * 2, hipMemcpyHostToDevice));
         }
         fa::KernelArgs a;
@@ -59,19 +61,24 @@ int main(int argc, char **argv) {
         }
         for (int which = 1; which < 3; ++which) {
             const auto &o1 = out[which], &o2 = out[0];
-            size_t rows_bad = 0; int shown = 0;
+            size_t rows_bad = 0, rows_equal = 0; int shown = 0;
+            const bool exact = which == 1;   // (the speculative form: 2 ulp, see the header)
             for (int b = 0; b < B; ++b) for (int s = 0; s < S; ++s) for (int hh = 0; hh < H; ++hh) {
                 const size_t off = (((size_t)b * S + s) * H + hh) * D;
                 int nd = 0; double worst = 0;
-                for (int d = 0; d < D; ++d) if (o1[off + d] != o2[off + d]) { ++nd; const double e = fabs(bf(o1[off + d]) - bf(o2[off + d])); if (e > worst || e != e) worst = e != e ? 1e30 : e; }
+                for (int d = 0; d < D; ++d) if (o1[off + d] != o2[off + d]) {
+                    const double e = fabs(bf(o1[off + d]) - bf(o2[off + d])), tol = exact ? 0.0 : 0.0078125 * (1.0 + fabs(bf(o2[off + d])));
+                    if (!(e <= tol)) { ++nd; if (e > worst || e != e) worst = e != e ? 1e30 : e; }
+                }
+                rows_equal += !memcmp(&o1[off], &o2[off], D * 2);
                 if (nd) { ++rows_bad; if (shown < 6) { printf("  S=%d b=%d h=%d row %4d (item %d, wave %d, row in tile %2d): %3d of 128 differ, worst %.3g  e.g. d0: %g vs %g\n", S, b, hh, s, s / 128, (s % 128) / 32, s % 32, nd, worst, bf(o1[off]), bf(o2[off])); ++shown; } }
             }
-            printf("%s vs %s%s  S=%d B=%d H=%d: %zu of %d rows differ   (items / redone: %u / %u)\n", names[which], names[0],
-                   spiky ? ", spiky keys" : "", S, B, H, rows_bad, B * S * H, st[which][0], st[which][1]);
+            printf("%s vs %s%s  S=%d B=%d H=%d: %zu of %d rows differ%s, %zu bit-identical   (items / redone: %u / %u)\n", names[which], names[0],
+                   spiky ? ", spiky keys" : "", S, B, H, rows_bad, B * S * H, exact ? "" : " by more than 2 ulp", rows_equal, st[which][0], st[which][1]);
             bad += rows_bad != 0;
         }
         CHECK(hipFree(q)); CHECK(hipFree(k)); CHECK(hipFree(v)); CHECK(hipFree(o));
     }
-    printf(bad ? "FAILED\n" : "all forms agree bit for bit\n");
+    printf(bad ? "FAILED\n" : "the lazy forms agree bit for bit, the speculative one within 2 ulp\n");
     return bad ? 1 : 0;
 }

@@ -4,10 +4,10 @@
 
 The visit's schedule lives at the edge of hipcc's register allocator: the MFMAs, DMA pieces and stores
 are inline asm the compiler neither pads nor looks into, and a compiler upgrade re-rolls everything around them.  The
-committed digest (profiles/r05/toolchain.json) is what the measured numbers of the round belong to; the CPU test
+committed digest (profiles/r06/toolchain.json) is what the measured numbers of the round belong to; the CPU test
 tests/test_tools_cpu.py::test_visit_histogram_matches_the_committed_digest fails when a rebuild no longer produces it.
 
-    isa_digest.py [--write profiles/r05/toolchain.json]
+    isa_digest.py [--write profiles/r06/toolchain.json]
 
 A "visit" = a basic block of the kernel with >= 56 MFMAs (the barrier two MFMAs into a visit may split off a 3-MFMA
 head, hence 61 or 64; since round 5 a walk is [first group | hot loop | last two groups] = twelve visit bodies, and hipcc

@@ -146,6 +146,10 @@ typedef struct fa_kernel_info {
     int32_t ring_softmax_mode;   /* its fa_softmax_mode (FA_SOFTMAX_LAZY or FA_SOFTMAX_SPECULATIVE) */
     int32_t ring_num_regs;       /* VGPR+AGPR per lane of the ring form */
     int32_t ring_scratch_bytes;  /* 0 = no spills */
+    /* ABI 6: what a launch of the ring form occupies -- lds_bytes / threads above describe the OTHER form */
+    int32_t ring_lds_bytes;      /* dynamic LDS per workgroup of the ring form (160 KiB: one workgroup per CU); 0 without one */
+    int32_t persistent;          /* 1: the variant (`fn`; a ring form always) is launched as one workgroup per CU that walks the
+                                    (batch*head, Q block) items itself -- the grid is min(items, CUs rounded down to 8) */
 } fa_kernel_info;
 
 /* Device-side statistics (optional, fa_fwd_opts.stats): a DEVICE pointer to two 32-bit counters the
@@ -280,9 +284,10 @@ int fa_get_kernel(int index, fa_kernel_info *out);
 int fa_get_kernel_sized(int index, fa_kernel_info *out, uint32_t out_size);
 int fa_fwd_query_sized(const fa_fwd_config *cfg, const fa_fwd_opts *opts, fa_kernel_info *out, uint32_t out_size);
 
-/* Increases whenever a struct of this header grows or an entry point changes meaning (5 = this header: the adaptive
- * record is per device variant, fa_adaptive_state_for added; fa_kernel_info grew by the four ring_* fields). */
-#define FA_ABI_VERSION 5
+/* Increases whenever a struct of this header grows or an entry point changes meaning (6 = this header: fa_kernel_info grew
+ * by ring_lds_bytes and persistent; the speculative first pass of the persistent kernel walks K / V first-to-last; 5: the
+ * adaptive record per device variant, fa_adaptive_state_for, the four ring_* fields). */
+#define FA_ABI_VERSION 6
 int fa_abi_version(void);
 
 /* Message for the last non-zero status on this thread ("" if none). */

@@ -99,6 +99,9 @@ typedef struct {
     int64_t batch, seq, heads, d;
     int64_t bs, ss, hs; /* strides in elements, flash_attention.cu:84-86 */
     int prescale_q;     /* NOT the reference's arithmetic: logits from a 16-bit Q * c (the device's pre-scaled-Q option) */
+    int kv_forward;     /* NOT the reference's order (forward_kernel.cuh:142 walks last-to-first): KV blocks first-to-last, as
+                         * the device's speculative first pass walks them since round 6 (its reference is the row max of the
+                         * first block it visits, and attention sinks sit at the first keys) */
 } tensors_t;
 
 /*
@@ -131,8 +134,9 @@ static void q_block_forward(const tensors_t *t, int64_t b, int64_t h, int64_t qb
     for (int r = 0; r < B_r; ++r) { m[r] = -INFINITY; l[r] = 0.0f; }
     memset(O, 0, sizeof(float) * B_r * d);
 
-    for (int64_t blk = n_kv - 1; blk >= 0; --blk) { /* forward_kernel.cuh:142,179-184 */
-        const int is_first = (blk == n_kv - 1);
+    for (int64_t step = 0; step < n_kv; ++step) { /* forward_kernel.cuh:142,179-184: last to first (kv_forward: first to last) */
+        const int64_t blk = t->kv_forward ? step : n_kv - 1 - step;
+        const int is_first = (step == 0);
         /* S = Q K^T, fp32 accumulate (gemm.cuh:45-87, mma f32 accum) */
         for (int r = 0; r < rows; ++r) {
             const int64_t qi = qb * B_r + r;
@@ -253,12 +257,12 @@ static int blockwise_impl(const uint16_t *q, const uint16_t *k, const uint16_t *
                           int64_t seq_stride, int64_t head_stride, int B_r, int B_c,
                           int round_p, int optimized_softmax, float *m_trace,
                           float *l_trace, int n_threads, int masked, int causal, float lazy_tau,
-                          int prescale_q) {
+                          int prescale_q, int kv_forward) {
     if (dtype != FA_ORACLE_FP16 && dtype != FA_ORACLE_BF16) return -1;
     if (B_r <= 0 || B_c <= 0 || seq <= 0) return -2;
     if (!masked && (seq % B_r != 0 || seq % B_c != 0)) return -2;
     tensors_t t = {q, k, v, o, dtype, batch, seq, heads, d_head,
-                   batch_stride, seq_stride, head_stride, prescale_q};
+                   batch_stride, seq_stride, head_stride, prescale_q, kv_forward};
     const int64_t n_heads_total = batch * heads;
     const int64_t n_q = (seq + B_r - 1) / B_r;
     int failed = 0;
@@ -308,7 +312,7 @@ int fa_oracle_forward_blockwise(const uint16_t *q, const uint16_t *k, const uint
                                 float *l_trace, int n_threads) {
     return blockwise_impl(q, k, v, o, dtype, batch, seq, heads, d_head, batch_stride, seq_stride,
                           head_stride, B_r, B_c, round_p, optimized_softmax, m_trace, l_trace,
-                          n_threads, 0, 0, 0.0f, 0);
+                          n_threads, 0, 0, 0.0f, 0, 0);
 }
 
 /* The lazy-rescale restatement (see q_block_forward): pins the 64-rows-per-wave device variant. */
@@ -318,7 +322,7 @@ int fa_oracle_forward_blockwise_lazy(const uint16_t *q, const uint16_t *k, const
                                      int64_t seq_stride, int64_t head_stride, int B_r, int B_c,
                                      float tau, int n_threads) {
     return blockwise_impl(q, k, v, o, dtype, batch, seq, heads, d_head, batch_stride, seq_stride,
-                          head_stride, B_r, B_c, 1, 0, NULL, NULL, n_threads, 0, 0, tau, 0);
+                          head_stride, B_r, B_c, 1, 0, NULL, NULL, n_threads, 0, 0, tau, 0, 0);
 }
 
 /* ... with the pre-scaled Q (tensors_t.prescale_q): the restatement of fa_fwd_opts.prescaled_q on the same kernel. */
@@ -328,7 +332,19 @@ int fa_oracle_forward_blockwise_lazy_psq(const uint16_t *q, const uint16_t *k, c
                                          int64_t seq_stride, int64_t head_stride, int B_r, int B_c,
                                          float tau, int n_threads) {
     return blockwise_impl(q, k, v, o, dtype, batch, seq, heads, d_head, batch_stride, seq_stride,
-                          head_stride, B_r, B_c, 1, 0, NULL, NULL, n_threads, 0, 0, tau, 1);
+                          head_stride, B_r, B_c, 1, 0, NULL, NULL, n_threads, 0, 0, tau, 1, 0);
+}
+
+/* The speculative first pass of the persistent device kernel (plain forms, round 6): the reference of a row is the row max
+ * of the FIRST block visited and never moves (tau = infinity), the blocks are visited first-to-last (kv_forward = 1; 0 gives
+ * the masked forms' and rounds 2-5's order). */
+int fa_oracle_forward_blockwise_spec(const uint16_t *q, const uint16_t *k, const uint16_t *v,
+                                     uint16_t *o, int dtype, int64_t batch, int64_t seq,
+                                     int64_t heads, int64_t d_head, int64_t batch_stride,
+                                     int64_t seq_stride, int64_t head_stride, int B_r, int B_c,
+                                     int kv_forward, int prescale_q, int n_threads) {
+    return blockwise_impl(q, k, v, o, dtype, batch, seq, heads, d_head, batch_stride, seq_stride,
+                          head_stride, B_r, B_c, 1, 0, NULL, NULL, n_threads, 0, 0, 1e30f, prescale_q, kv_forward);
 }
 
 /* Widened modes (causal mask, any seq): same arithmetic, see q_block_forward. */
@@ -339,7 +355,7 @@ int fa_oracle_forward_blockwise_masked(const uint16_t *q, const uint16_t *k, con
                                        int optimized_softmax, int causal, int n_threads) {
     return blockwise_impl(q, k, v, o, dtype, batch, seq, heads, d_head, batch_stride, seq_stride,
                           head_stride, B_r, B_c, 1, optimized_softmax, NULL, NULL, n_threads, 1,
-                          causal, 0.0f, 0);
+                          causal, 0.0f, 0, 0);
 }
 
 /*

@@ -70,6 +70,11 @@ def lib():
         ]
         L.fa_oracle_forward_blockwise_lazy_psq.restype = ctypes.c_int
         L.fa_oracle_forward_blockwise_lazy_psq.argtypes = L.fa_oracle_forward_blockwise_lazy.argtypes
+        L.fa_oracle_forward_blockwise_spec.restype = ctypes.c_int
+        L.fa_oracle_forward_blockwise_spec.argtypes = [
+            u16p, u16p, u16p, u16p, ctypes.c_int, i64, i64, i64, i64, i64, i64, i64,
+            ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+        ]
         L.fa_oracle_forward_eager.restype = ctypes.c_int
         L.fa_oracle_forward_eager.argtypes = [
             u16p, u16p, u16p, u16p, ctypes.c_void_p, ctypes.c_int, i64, i64, i64, i64,
@@ -142,6 +147,22 @@ def blockwise_forward_lazy(q, k, v, B_r, B_c, tau=8.0, n_threads=0, prescaled_q=
 SPEC_TAU = 1e30  # "never move the reference max": the speculative schedule's first pass
 
 
+def blockwise_forward_spec(q, k, v, B_r, B_c, kv_forward=True, n_threads=0, prescaled_q=False):
+    """The speculative first pass (NOT the reference's arithmetic): a row's reference is the row max of
+    the first K / V block visited and never moves.  kv_forward: blocks first-to-last, as the persistent kernel's plain
+    forms walk them since round 6 (False: last-to-first = blockwise_forward_lazy with tau = SPEC_TAU)."""
+    _check(q, k, v)
+    B, S, H, D = q.shape
+    o = torch.empty_like(q)
+    rc = lib().fa_oracle_forward_blockwise_spec(
+        q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), _code(q.dtype),
+        B, S, H, D, q.stride(0), q.stride(1), q.stride(2), B_r, B_c, int(bool(kv_forward)), int(bool(prescaled_q)), n_threads,
+    )
+    if rc != 0:
+        raise RuntimeError(f"fa_oracle_forward_blockwise_spec failed: {rc}")
+    return o
+
+
 def blockwise_for_config(cfg, q, k, v, n_threads=0, masked=False):
     """The CPU restatement of the arithmetic the device variant behind `cfg` performs on inputs that
     do not trip the speculative schedule's overflow check (those rows are redone with tau = 8).
@@ -150,9 +171,10 @@ def blockwise_for_config(cfg, q, k, v, n_threads=0, masked=False):
 
     psq = bool(getattr(cfg, "prescaled_q", False))
     if kc.uses_speculative_softmax(cfg, masked):
-        return blockwise_forward_lazy(q, k, v, min(cfg.B_r, q.shape[1]), cfg.B_c, tau=SPEC_TAU, n_threads=n_threads,
+        return blockwise_forward_spec(q, k, v, min(cfg.B_r, q.shape[1]), cfg.B_c,
+                                      kv_forward=kc.walks_kv_forward(cfg, masked, q.shape[1]), n_threads=n_threads,
                                       prescaled_q=psq)
-    if kc.uses_lazy_rescale(cfg):
+    if kc.uses_lazy_rescale(cfg, q.shape[1]):
         return blockwise_forward_lazy(q, k, v, cfg.B_r, cfg.B_c, n_threads=n_threads, prescaled_q=psq)
     return blockwise_forward(q, k, v, cfg.B_r, cfg.B_c, optimized_softmax=cfg.optimized_softmax,
                              n_threads=n_threads)

@@ -60,20 +60,3 @@ def load_seam_golden(tag):
 @pytest.fixture(scope="session")
 def golden_loader():
     return load_eager_golden
-
-
-@pytest.fixture(autouse=True)
-def _fresh_adaptive_state(request):
-    """GPU tier: every test starts with the adaptive speculative mode (fa_speculative_mode, what best_config() asks for) in
-    its NORMAL state -- a spike planted by the test before must not leave the device demoted, or bit-for-bit comparisons
-    between a best_config() launch and an explicitly speculative one would depend on the order of the tests."""
-    if request.node.get_closest_marker("gpu") is not None:
-        import torch
-
-        if torch.cuda.is_available():
-            from flash_attention_from_scratch_amd import _capi
-
-            torch.cuda.synchronize()
-            _capi.load().fa_init()
-            _capi.adaptive_reset(torch.cuda.current_device())
-    yield

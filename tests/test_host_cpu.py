@@ -8,6 +8,7 @@ import pytest
 import torch
 
 from flash_attention_from_scratch_amd import _capi
+from dataclasses import fields, replace  # noqa: F401
 from flash_helpers import kernel_configs as kc
 from tests.conftest import ROOT
 
@@ -30,7 +31,7 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layout_matches_header():
     assert ctypes.sizeof(_capi.FaFwdConfig) == 13 * 4
     assert ctypes.sizeof(_capi.FaFwdArgs) == 4 * 8 + 7 * 8 + 13 * 4 + 4  # tail padding to 8
-    assert ctypes.sizeof(_capi.FaKernelInfo) == 13 * 4 + 8 * 4 + 4 * 4   # (+ the four ring_* fields of ABI 5)
+    assert ctypes.sizeof(_capi.FaKernelInfo) == 13 * 4 + 8 * 4 + 4 * 4 + 2 * 4   # (+ the four ring_* fields of ABI 5, + ring_lds_bytes, persistent of ABI 6)
     assert ctypes.sizeof(_capi.FaFwdStats) == 8
     assert ctypes.sizeof(_capi.FaFwdOpts) == 5 * 4 + 4 + 2 * 8   # five 32-bit fields, padding, two pointers
     # the header's own view, compiled: sizes and offsets of the structs ctypes mirrors
@@ -128,17 +129,20 @@ def test_one_flag_one_meaning_softmax_mode_of_every_config():
     finally:
         del os.environ["FA_ALLOW_SPECULATIVE"]
     assert kc.softmax_mode(cfg) == "eager"
-    # best_config: the speculative softmax, adaptively, for both dtypes (round 4: the library demotes a device whose
-    # speculative launches report items computed twice -- fp16's 16-bit P leaves only ~10 nats of headroom)
+    # best_config: the speculative softmax for both dtypes, STATELESS since round 6 (fa_fwd_opts.speculative = 1; the
+    # adaptive mode of rounds 4-5 is opt-in: DESIGN.md 3.6)
     for dt in (kc.DType.BF16, kc.DType.FP16):
         best = kc.best_config(dt)
-        assert kc.softmax_mode(best) == "speculative" and best.adaptive_softmax and best.speculative_softmax
-        assert kc.parse_kernel_name_into_config(best.short_form()) == best
-        assert replace(best, adaptive_softmax=False).short_form() == best.short_form().replace("+adaptive", "")
-    # "never speculative" from the default in ONE step (round 4 raised ValueError here): adaptive qualifies
-    # speculative and is cleared with it
+        assert kc.softmax_mode(best) == "speculative" and best.speculative_softmax and not best.adaptive_softmax
+        assert kc.parse_kernel_name_into_config(best.short_form()) == best and "+adaptive" not in best.short_form()
+        ada = replace(best, adaptive_softmax=True)
+        assert ada.short_form() == best.short_form() + "+adaptive" and kc.parse_kernel_name_into_config(ada.short_form()) == ada
+        assert kc.walks_kv_forward(best) and not kc.walks_kv_forward(best, masked=True)
+    # "never speculative" from the default in ONE step; adaptive on its own is refused
     never = replace(best, speculative_softmax=False)
-    assert not never.adaptive_softmax and kc.softmax_mode(never) == "lazy" and "+adaptive" not in never.short_form()
+    assert not never.adaptive_softmax and kc.softmax_mode(never) == "lazy" and not kc.walks_kv_forward(never)
+    with pytest.raises(ValueError):
+        kc.NativeKernelConfig(*(getattr(best, f.name) for f in fields(kc.FlashForwardKernelConfig)), adaptive_softmax=True)
     assert kc.softmax_mode(kc.best_config(kc.DType.BF16, 1000, masked=True), masked=True) == "speculative"
     # the ring form (round 5): (B_r 128, B_c 64, 4 warps) + buffer, plain -- the mirror of fa_kernel_info.ring_form
     ring = [c for c in kc.get_kernels_to_build() if kc.has_ring_form(c)]
@@ -571,9 +575,9 @@ def test_adaptive_mode_abi():
     """fa_speculative_mode / fa_adaptive_info (include/fa_hip.h): struct layout of the ctypes mirror, the version numbers."""
     assert ctypes.sizeof(_capi.FaAdaptiveInfo) == 8 * 4
     lib = _capi.load()
-    assert lib.fa_abi_version() == _capi.FA_ABI_VERSION == 5
+    assert lib.fa_abi_version() == _capi.FA_ABI_VERSION == 6
     header = open(os.path.join(ROOT, "include", "fa_hip.h")).read()
-    assert "#define FA_ABI_VERSION 5" in header and "FA_SPECULATIVE_ADAPTIVE = 2" in header
+    assert "#define FA_ABI_VERSION 6" in header and "FA_SPECULATIVE_ADAPTIVE = 2" in header
     # the boundary row (SURVEY 8b threading / streams; the reference's launcher is stateless, src/flash_attention.cu:42,118,
     # 126-131): the header says which entry points keep state, and no longer claims that none does
     assert "no global mutable state" not in header and "STATELESS" in header and "per device variant" in header

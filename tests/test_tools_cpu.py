@@ -300,7 +300,7 @@ def test_isa_lint_on_the_built_64_row_kernels(tmp_path):
 
 
 def test_visit_histogram_matches_the_committed_digest():
-    """Toolchain pin (profiles/r05/toolchain.json, tools/isa_digest.py): the hand-placed visit of the persistent kernel
+    """Toolchain pin (profiles/r06/toolchain.json, tools/isa_digest.py): the hand-placed visit of the persistent kernel
     must come out of THIS hipcc as the plan dealt it -- per visit 64 MFMAs, 64 v_exp_f32, 64 v_fmamk (c applied in fp32,
     softmax.cuh:51-64), 64 row-sum adds, 32 packs, 48 LDS operand reads (16 ds_read_b128 + 32 ds_read_b64_tr_b16), 8 LDS-DMA
     pieces, and in the speculative first pass no row max -- and as the digest the round's measurements belong to recorded
@@ -308,7 +308,7 @@ def test_visit_histogram_matches_the_committed_digest():
     into one block of 256 MFMAs, which must carry nothing but the plan: no lane spill, no accumulator copy, <= 385
     instructions per visit.  A compiler upgrade (or any source change) that moves it fails here: look at the new ISA,
     re-measure, then regenerate the digest (python flash_attention_from_scratch_amd/tools/isa_digest.py --write
-    profiles/r05/toolchain.json)."""
+    profiles/r06/toolchain.json)."""
     import json
 
     from flash_attention_from_scratch_amd.tools import isa_digest
@@ -341,7 +341,7 @@ def test_visit_histogram_matches_the_committed_digest():
             assert h["instructions"] <= 4 * 385, (name, h)
         else:
             assert not first_pass and n_visits(second) == 12, (name, n_visits(first_pass), n_visits(second))
-    want = json.load(open(os.path.join(ROOT, "profiles", "r05", "toolchain.json")))
+    want = json.load(open(os.path.join(ROOT, "profiles", "r06", "toolchain.json")))
     assert got["hipcc"] == want["hipcc"], ("the compiler changed: every hand-placed schedule needs re-verification on the GPU "
                                            "(pytest -m gpu, tools/soak.py, bench.py) before the digest is regenerated", got["hipcc"])
     assert got["kernels"] == want["kernels"], "the visit's instruction histogram moved: see the docstring"
