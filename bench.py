@@ -491,12 +491,30 @@ def pin_rank(rank, world, local_rank, gpu_nodes=None):
     mine = cpus[slot * n:(slot + 1) * n] or cpus
     info = {"rank": rank, "numa_node": mine_node, "cpus": _format_cpulist(mine), "n_cpus": len(mine),
             "ranks_on_this_node": per, "source": source}
+    # every thread the process already has (torch and HIP start workers at import / first use, and sched_setaffinity(0)
+    # moves the calling thread only -- ADVICE r05), then the process default for the threads still to come
+    try:
+        tids = [int(t) for t in os.listdir("/proc/self/task")]
+    except OSError:
+        tids = []
+    moved, failed = 0, 0
+    for tid in tids:
+        try:
+            os.sched_setaffinity(tid, mine)
+            moved += 1
+        except (AttributeError, OSError):
+            failed += 1
     try:
         os.sched_setaffinity(0, mine)
         info["pinned"] = True
     except (AttributeError, OSError) as exc:
         info["pinned"] = False
         info["error"] = repr(exc)
+    info["threads_pinned"], info["threads_not_pinned"] = moved, failed
+    try:
+        info["affinity_now"] = _format_cpulist(sorted(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
     return info
 
 
@@ -859,6 +877,11 @@ def main():
                     help="N > 1: rank R runs under `rocprofv3 --kernel-trace --stats` and leaves --rocprof-dir/scale_rank<R>*.csv "
                          "(one rank only: the profiled rank clocks a few % lower, see MI355X_MICROARCH.md DVFS)")
     ap.add_argument("--rocprof-dir", default=os.path.join("profiles", "r06"))
+    ap.add_argument("--batch-per-rank", type=int, default=0,
+                    help="override the workload's per-GPU batch (weak scaling keeps it fixed per rank).  `--gpus 8 --workload c4 "
+                         "--batch-per-rank 1` self-launched on a ONE-GPU box is the eight-launchers-one-host rehearsal "
+                         "(profiles/r06/bench_n8_selflaunch.json): what it measures is the host -- per-rank enqueue time, "
+                         "affinity, barrier latency --, not the device")
     ap.add_argument("--dist-backend", default="gloo", choices=["gloo", "nccl"],
                     help="barrier + max-over-ranks only (the data path has no collective): gloo (default; on "
                          "a box with fewer GPUs than ranks the ranks share devices and the timings mean "
@@ -894,8 +917,6 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     affinity = None
-    if world > 1 and not args.no_pin:
-        affinity = pin_rank(rank, world, local_rank, [_gpu_numa_node(r % n_dev) for r in range(world)])
     reduce_device = device if args.dist_backend == "nccl" else torch.device("cpu")
     if world > 1:
         import torch.distributed as dist
@@ -907,6 +928,12 @@ def main():
             else:
                 dist.init_process_group("gloo")
             dist.barrier()
+        if not args.no_pin:
+            # each rank's ACTUAL device, gathered (not assumed from the rank number: ADVICE r05), then its NUMA node
+            devs = [None] * world
+            dist.all_gather_object(devs, local_rank)
+            affinity = pin_rank(rank, world, local_rank, [_gpu_numa_node(d_) for d_ in devs])
+            affinity["device"] = local_rank
 
     if args.workload == "c2":
         if world != 1:
@@ -915,6 +942,8 @@ def main():
             args.steps = 50
         return run_c2_sweep(args, device)
     dtype_name, batch, heads, seq, d = WORKLOADS[args.workload]
+    if args.batch_per_rank > 0:
+        batch = args.batch_per_rank
     if args.dtype:
         dtype_name = args.dtype
     dtype = {"bf16": torch.bfloat16, "fp16": torch.float16}[dtype_name]
@@ -1011,7 +1040,9 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         timed_step(i)
+    t_enqueued = time.perf_counter()   # (the host's share of the region: K launches enqueued -- SURVEY 8e's shared resource)
     barrier()   # (host side, while the devices still work: see timed_steps)
+    t_barrier = time.perf_counter()
     sync()
     t_end = time.perf_counter()
     seconds = t_end - t0
@@ -1051,9 +1082,25 @@ def main():
         import torch.distributed as dist
 
         clk = sampler.summary(t0, t_end)
+        import hashlib
+
+        # barrier latency with nothing else going on: five back-to-back gloo / RCCL barriers, the median
+        lat = []
+        for _ in range(5):
+            tb = time.perf_counter()
+            dist.barrier()
+            lat.append((time.perf_counter() - tb) * 1e6)
         mine = {"tflops": achieved, "sclk_mhz": clk.get("sclk_mhz", {}).get("mean"), "power_w": clk.get("power_w", {}).get("mean"),
                 "device": local_rank, "kernel_ms": kernel_ms, "affinity": affinity,
-                "under_rocprof": bool(os.environ.get("FA_UNDER_ROCPROF"))}
+                "under_rocprof": bool(os.environ.get("FA_UNDER_ROCPROF")),
+                # what N launchers share is the HOST: this rank's enqueue time per launch inside the timed region, how long
+                # its closing barrier took (host side, devices still working), an idle barrier's latency
+                "host_us_per_launch": (t_enqueued - t0) / args.steps * 1e6,
+                "closing_barrier_us": (t_barrier - t_enqueued) * 1e6,
+                "idle_barrier_us_median": statistics.median(lat),
+                "batch_rows": [lo, hi],
+                # this rank's output of the LAST step (inputs seeded 1000 + rank: a single process can reproduce every shard)
+                "output_sha256": hashlib.sha256(o.cpu().view(torch.int16).numpy().tobytes()).hexdigest()}
         gathered = [None] * world
         dist.all_gather_object(gathered, mine)
         per_rank = [g["tflops"] for g in gathered]

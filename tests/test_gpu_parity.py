@@ -480,7 +480,7 @@ def test_speculative_softmax_against_its_restatement():
         if dtype == torch.bfloat16:  # fp16 takes the second pass on such data (next test)
             # (rising along the walk: first-to-last for this kernel's speculative pass)
             kk_list.append((k.float() * torch.linspace(1, 6, 1024, device=DEV).view(1, -1, 1, 1)).to(dtype))
-        for kk in kk_list:
+        for i_k, kk in enumerate(kk_list):
             out = flash_attention.forward(cfg, q, kk, v)
             ref = ut.py_flash_attention(q, kk, v, upcast=True).float()
             assert kc.walks_kv_forward(cfg)
@@ -488,7 +488,10 @@ def test_speculative_softmax_against_its_restatement():
             assert torch.isfinite(out.float()).all()
             tol = TOL[dtype] * (1 + ref.abs())
             assert ((out.float() - ref).abs() <= tol).all()
-            assert ((out.float().cpu() - oracle).abs() <= tol.cpu()).all()
+            # (the rising keys put a row's weight on its last few keys: P's 16-bit rounding no longer averages out, the
+            # restatement itself sits at 0.67 of the bar against fp32 eager -- two roundings of one function: twice the bar)
+            worst = ((out.float().cpu() - oracle).abs() / tol.cpu()).max().item()
+            assert worst <= (2.0 if i_k else 1.0), (str(dtype), i_k, worst)
 
 
 @pytest.mark.parametrize("psq", [False, True], ids=["exact_c", "prescaled_q"])
@@ -1103,14 +1106,73 @@ def test_full_size_properties(name, dtype, B, H, S):
     ones = torch.ones_like(v)
     oc = flash_attention.forward(cfg, q, k, ones)
     assert (oc.float() - 1).abs().max().item() <= 2.0 ** -7
-    # (5) spot check vs fp32 eager on one (batch, head)
-    sl = (slice(B - 1, B), slice(None), slice(H - 1, H))
-    ref = ut.py_flash_attention(q[sl].contiguous(), k[sl].contiguous(), v[sl].contiguous(), upcast=True)
-    assert (out[sl].float() - ref.float()).abs().max().item() <= TOL[dtype]
+    # (5) every 8th head of every sample against eager attention, under the reference's own rule (test.py:57-61:
+    #     max|out - eager_16| <= 2 max|eager_16 - eager_f32|, eager in the 16-bit type and in fp32 as py_flash_attention
+    #     computes them, here on the device one head at a time) and against fp32 eager to 2 ulp -- the default AND the
+    #     running-max (lazy) variant, the reference's arithmetic family (rounds 1-5 looked at ONE head)
+    lazy = replace(cfg, speculative_softmax=False)
+    out_lazy = flash_attention.forward(lazy, q, k, v)
+    for b_ in range(B):
+        for h_ in range(0, H, 8):
+            sl = (slice(b_, b_ + 1), slice(None), slice(h_, h_ + 1))
+            qs, ks, vs = (t[sl].contiguous() for t in (q, k, v))
+            e32 = ut.py_flash_attention(qs, ks, vs, upcast=True)
+            e16 = ut.py_flash_attention(qs, ks, vs, upcast=False)
+            for tag, o_ in (("default", out), ("lazy", out_lazy)):
+                lhs, rhs = fo.tolerance_rule(o_[sl], e16, e32)
+                assert lhs <= rhs, (name, tag, b_, h_, lhs, rhs)
+                assert (o_[sl].float() - e32.float()).abs().max().item() <= TOL[dtype], (name, tag, b_, h_)
+            del e32, e16
+    if name == "c1":
+        # ... and C1's sample of heads against the C oracle's restatement of the device arithmetic (oracle/fa_oracle.c,
+        # OpenMP over the heads), both variants: <= 2 ulp (v_exp_f32 vs libm exp2f, MFMA vs serial fp32 sums)
+        qh, kh, vh = (t[:, :, ::8].contiguous().cpu() for t in (q, k, v))
+        for tag, c_, o_ in (("default", cfg, out), ("lazy", lazy, out_lazy)):
+            want = fo.blockwise_for_config(c_, qh, kh, vh).float()
+            assert (o_[:, :, ::8].float().cpu() - want).abs().max().item() <= TOL[dtype], (name, tag)
     # (6) a different tile shape computes the same function (different summation order)
     other = kc.as_native(replace(cfg, B_r=128, B_c=64, n_warps=4, optimized_softmax=False), speculative_softmax=False)
     oo = flash_attention.forward(other, q, k, v)
     assert (oo.float() - out.float()).abs().max().item() <= TOL[dtype]
+
+
+def test_eight_launchers_on_one_host_assemble_the_single_process_result():
+    """SURVEY 8e before the 8-GPU node exists: `bench.py --gpus 8 --workload c4 --batch-per-rank 1`,
+    self-launched -- eight processes, one per rank, rendezvous over gloo on 127.0.0.1, each pinned to its own CPUs, all
+    eight sharing THIS box's one GPU (the only thing the path's ranks ever share is the host: src/flash_attention.cu:110-112
+    has no exchange step).  Every rank reports the hash of its shard's output; a single process that builds the same eight
+    samples (rank r's inputs are seeded 1000 + r) and runs them as ONE batch of eight must get the same bits, sample by
+    sample.  The line also carries what the rehearsal is for: per-rank host enqueue time, affinity, barrier latency."""
+    import hashlib
+    import json
+    import subprocess
+    import sys
+    import bench
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--workload", "c4", "--batch-per-rank", "1", "--steps", "4",
+           "--warmup", "2", "--no-cpu-baseline", "--no-traffic", "--hermetic-reps", "0", "--no-mfma-roof", "--no-variants",
+           "--precondition-ms", "0"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1200, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    per = line["per_gpu"]
+    assert line["n_gpus"] == 8 and len(per) == 8 and line["scaling"] == "weak"
+    assert all(p_["batch_rows"] == [i, i + 1] for i, p_ in enumerate(per))
+    assert all(p_["host_us_per_launch"] > 0 and p_["idle_barrier_us_median"] > 0 for p_ in per)
+    cpus = [p_["affinity"]["cpus"] for p_ in per if p_.get("affinity") and p_["affinity"].get("pinned")]
+    assert len(set(cpus)) == len(cpus)          # (pinned ranks never share a CPU slice)
+    _, batch, heads, seq, d = bench.WORKLOADS["c4"]
+    cfg = kc.best_config(kc.DType.BF16, seq)
+    q, k, v = (torch.empty((8, seq, heads, d), dtype=torch.bfloat16, device=DEV) for _ in range(3))
+    for rk in range(8):
+        gen = torch.Generator(device=DEV).manual_seed(1000 + rk)
+        for dst, src in zip((q, k, v), bench.make_inputs("randn", (1, seq, heads, d), torch.bfloat16, torch.device(DEV), gen)):
+            dst[rk:rk + 1].copy_(src)
+    out = flash_attention.forward(cfg, q, k, v)
+    torch.cuda.synchronize()
+    for rk in range(8):
+        mine = hashlib.sha256(out[rk:rk + 1].contiguous().cpu().view(torch.int16).numpy().tobytes()).hexdigest()
+        assert mine == per[rk]["output_sha256"], rk
 
 
 @pytest.mark.parametrize("shape", ["persistent", "32-row", "key-split", "16-row"])
@@ -1270,10 +1332,10 @@ def test_masked_variant_equals_plain_kernel_when_nothing_is_masked():
             # in a visit's last gaps (rotated plan) and adds their share of a row sum as one side sum; the
             # masked forms keep the unrotated plan.  Same P, same O accumulation -- only the fp32 row sum is associated
             # differently, so l may differ in its last bit and an output element by one ulp of the 16-bit type
+            # Round 6: the plain speculative form also walks K / V first-to-last (its reference is the first 64 keys' row max,
+            # the masked form's the last 64 keys'): two roundings of the same function -- the tolerance of every parity test
             diff = (masked_out.float() - plain_out.float()).abs()
-            ulp = torch.clamp(plain_out.float().abs(), min=2.0 ** -14) * (2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -10)
-            assert (diff <= ulp).all(), (str(cfg), diff.max().item())
-            assert (diff > 0).float().mean().item() < 0.05, str(cfg)   # ... and rarely
+            assert (diff <= TOL[dtype] * (1 + plain_out.float().abs())).all(), (str(cfg), diff.max().item())
         else:
             assert torch.equal(masked_out, plain_out), str(cfg)
 
@@ -1611,14 +1673,17 @@ def test_speculative_verdict_looks_at_the_accumulators_bf16():
     return the finite values the non-speculative variant returns."""
     B, S, H = 1, 1024, 2
     q = torch.full((B, S, H, 128), 1.0, device=DEV, dtype=torch.bfloat16)
-    k = torch.full((B, S, H, 128), 30.0 * (128 ** 0.5) / 128, device=DEV, dtype=torch.bfloat16)
-    k[:, S - 64:] = 0.0                                     # the tile visited first: logit 0; every other key: 30 nats
+    k_hi = torch.full((B, S, H, 128), 30.0 * (128 ** 0.5) / 128, device=DEV, dtype=torch.bfloat16)
     gen = torch.Generator(device=DEV).manual_seed(3)
     sign = (torch.randint(0, 2, (B, S, H, 128), device=DEV, generator=gen) * 2 - 1).to(torch.bfloat16)
     v = sign * (2.0 ** 90)
     want = None
     for B_r, B_c, n_w in ((256, 64, 4), (128, 64, 4), (64, 32, 4)):
         spec, safe = _native(kc.DType.BF16, B_r, B_c, n_w, True, True), _native(kc.DType.BF16, B_r, B_c, n_w, True, False)
+        # the tile visited FIRST: logit 0; every other key: 30 nats (the persistent kernel's speculative pass -- both its forms
+        # at this seq_len -- walks first-to-last, the 16-rows-per-wave kernel last-to-first)
+        k = k_hi.clone()
+        k[:, (slice(0, 64) if kc.walks_kv_forward(spec, seq_len=S) else slice(S - 64, S))] = 0.0
         stats = torch.zeros(2, dtype=torch.int32, device=DEV)
         out = flash_attention_kernels.forward(spec, q, k, v, None, stats=stats)[0]   # (plain form: no mask, no ragged length)
         ref = flash_attention.forward(safe, q, k, v)
@@ -1628,9 +1693,11 @@ def test_speculative_verdict_looks_at_the_accumulators_bf16():
         assert items[1] == items[0] > 0, (B_r, B_c, items)    # every item overflowed and was redone
         scale = 2.0 ** -90
         assert ((out.float() * scale) - (ref.float() * scale)).abs().max().item() <= 2.0 ** -6, (B_r, B_c)
-        if want is None:
-            want = ref
-        assert ((ref.float() * scale) - (want.float() * scale)).abs().max().item() <= 2.0 ** -6, (B_r, B_c)
+        # (the variants that walk the same way see the same k: their running-max results agree)
+        fwd = kc.walks_kv_forward(spec, seq_len=S)
+        want = want if want is not None else {}
+        want.setdefault(fwd, ref)
+        assert ((ref.float() * scale) - (want[fwd].float() * scale)).abs().max().item() <= 2.0 ** -6, (B_r, B_c)
 
 
 def test_plain_c_client_runs(tmp_path):
@@ -1799,9 +1866,9 @@ def test_ring_form_of_the_reference_winning_shape():
     exactly as the (256, 64, 4) kernel's non-speculative form does, so the two agree BIT FOR BIT; both forms are inside
     the reference's tolerance rule against the eager golden; every reference config of the shape reaches it (the
     operand-fetch hints and optimized_softmax do not change the device variant).  The speculative sibling of the
-    configuration runs the same kernel's speculative schedule: no rotated units there, so its row sums add up in the
-    lazy schedule's order and an item it gives up on is redone BY the lazy schedule -- bit-identical again, wherever no
-    reference moves (and in the items fa_fwd_stats counts as run twice)."""
+    configuration runs the same kernel's speculative schedule (first-to-last over K / V since round 6: 2 ulp of the lazy
+    form); an item it gives up on is redone BY the lazy schedule (its own workgroup walks it again, whole): bit-identical to
+    the lazy form's rows."""
     shape_cfgs = [c for c in kc.get_kernels_to_build() if (c.B_r, c.B_c, c.n_warps) == (128, 64, 4) and c.mma_double_buffer_loads]
     assert len(shape_cfgs) >= 8 and all(kc.has_ring_form(c) for c in shape_cfgs)
     for name, dtype in ((kc.DType.BF16, torch.bfloat16), (kc.DType.FP16, torch.float16)):
@@ -1826,21 +1893,21 @@ def test_ring_form_of_the_reference_winning_shape():
             stats = torch.zeros(2, dtype=torch.int32, device=DEV)
             out, _ = flash_attention_kernels.forward(spec, q, k, v, None, stats=stats)
             assert stats[0].item() == B * H * (S // 128) and 1 <= stats[1].item() <= 2 * (S // 128), stats.tolist()
-            # the spiked queries' item was redone by the lazy schedule, every (batch, head) without a spike never left
-            # the common path: the same bits; the other items of the spiked head may have met the guard (a reference moved
-            # by an exact power of two, at another moment than the lazy schedule moves its own): the tolerance rule
+            # the spiked queries' item was redone by the lazy schedule (in its own workgroup, whole): the lazy form's bits;
+            # every other item ran the speculative first pass, which walks K / V first-to-last since round 6 -- the lazy
+            # form's arithmetic per tile, its fp32 sums in the other order: 2 ulp of the lazy form
             blk = slice((S // 2) // 128 * 128, (S // 2) // 128 * 128 + 128)
             assert torch.equal(out[0, blk, 1], want[0, blk, 1]), (str(spec), B, S, H)
-            rest = out.clone(); rest[0, :, 1] = want[0, :, 1]
-            assert torch.equal(rest, want), (str(spec), B, S, H)
+            assert ((out.float() - want.float()).abs() <= 2 * TOL[dtype] * (1 + want.float().abs())).all(), (str(spec), B, S, H)
             assert ((out.float() - eager).abs() <= TOL[dtype] * (1 + eager.abs())).all()
-            # nothing to give up on: the same bits, nothing redone
+            # nothing to give up on: nothing redone, the 64-row speculative kernel's neighbourhood
             k2, q2 = k.clone(), q.clone()
             k2[0, S // 3, 1] = k[0, S // 3, 0]
             q2[0, S // 2:S // 2 + 3, 1] = q[0, S // 2:S // 2 + 3, 0]
             stats.zero_()
             out, _ = flash_attention_kernels.forward(spec, q2, k2, v, None, stats=stats)
-            assert torch.equal(out, flash_attention.forward(big, q2, k2, v)) and stats[1].item() == 0
+            want2 = flash_attention.forward(big, q2, k2, v)
+            assert stats[1].item() == 0 and ((out.float() - want2.float()).abs() <= 2 * TOL[dtype] * (1 + want2.float().abs())).all()
         # a multiple of 128 that is not one of 256: the compiler-scheduled body, the reference's eager arithmetic
         gen = torch.Generator(device=DEV).manual_seed(384)
         q, k, v = (torch.randn((2, 384, 4, 128), dtype=dtype, device=DEV, generator=gen) for _ in range(3))
