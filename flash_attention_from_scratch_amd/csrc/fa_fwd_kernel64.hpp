@@ -6,124 +6,18 @@
 // below; shares that file's element traits, DMA helpers and LDS images.
 #pragma once
 #include "fa_fwd_kernel.hpp"
+#include "fa_plan64.hpp"
 
 namespace fa {
 
-// Filler plan of the 64-rows-per-wave schedule: what rides in the gap after MFMA g (g = 0..63 of a
-// visit; 0..31 = QK^T of tile it+1, 32..63 = P.V of tile it).  Built at compile time so that
-// placements can be compared by changing one function (tools/tune64.hip).
-struct Plan64 {
-    signed char exp_first[64], exp_n[64];  // softmax units (2 elements each), 32 per visit, in P.V order
-    signed char max_first[64], max_n[64];  // row-max units over S(it+1), 32 per visit
-    signed char dma[64];                   // DMA piece 0..7 (even = K, odd = V) or -1
-    signed char tail[64];                  // end-of-visit chain step 1.. or 0
-    signed char barrier[64];               // 1: the visit's counted DMA wait + workgroup barrier
-    signed char early_first[64], early_n[64];  // rotated plan: softmax units of the NEXT tile (S(it+1)), first rot_k of its 32
-};
-// variant bits (tools/tune64.hip): 1 barrier at the visit top instead of inside the MFMA stream,
-// 2 DMA pieces late in phase 2 instead of early in phase 1
-#ifndef FA_RING_SLOTS
-#define FA_RING_SLOTS 4
-#endif
 #ifdef FA_JITTER
 #define FA_JIT(rare) jitter(BoolTag<rare>{})
 #else
 #define FA_JIT(rare) ((void)0)
 #endif
 #ifndef FA_ROT_DEFAULT
-#define FA_ROT_DEFAULT 4   // softmax units of the next tile carried in a visit's last gaps (speculative plain forms)
+#define FA_ROT_DEFAULT 4   // softmax units of the next tile carried in a visit's last gaps (speculative plain forms; fa_plan64.hpp)
 #endif
-// rot_k (speculative schedule only, DESIGN.md 3.5 "rotated units"): the last gaps of a visit run at the matrix pipe's own
-// rate with issue slots to spare (the P.V MFMAs of the last 16-key slice; every unit of tile `it` has to be done two gaps
-// before its slice is consumed, i.e. by gap 54), while phase 1 is issue bound.  So the first rot_k units of the NEXT tile
-// -- S(it+1) is complete from gap 32 on, and P's slice 0 registers are free once gap 40 has issued -- ride in those last
-// gaps, and a visit carries units rot_k .. 31 of its own tile + units 0 .. rot_k-1 of the next.  chain_gap: the gap that
-// carries the next request pointers (the end-of-visit chain's last step; 63 = behind the last MFMA, as first built).
-constexpr Plan64 make_plan64(int variant, int n_phase1, int rot_k = 0, int chain_gap = 63) {
-    Plan64 p{};
-    const bool bar_top = variant & 1, dma_late = variant & 2, masked = variant & 4, nomax = variant & 8, even = variant & 16;
-    // nomax (the speculative schedule): no row-max units, no end-of-visit chain (only its last step, the
-    // next request pointers).  even (experiment): the 32 softmax units spread evenly over the gaps that carry
-    // no operand reads (g % 4 != 0, not the barrier gap) up to gap 54, the last one P's consumers allow --
-    // measured 14 % behind the phase-1-heavy placement (phase 2 carries twice the LDS operand reads)
-    // masked: gaps 32..35 of a diagonal visit rewrite S(it+1) (causal mask) before its row max is
-    // taken, so the 32 row-max units start 4 gaps later and the end-of-visit chain runs in 5 steps
-    const int m0 = masked ? 4 : 0, odd0 = masked ? 11 : 9, mend = masked ? 27 : 24;
-    int e = rot_k, m = 0, d = 0, slot_nm = 0, ee = 0;
-    const int e1_end = rot_k + n_phase1;   // phase 1 carries units rot_k .. e1_end - 1
-    // early units, one per gap: the odd gaps 55 .. 63 first (no operand reads there), then the even ones
-    constexpr int early_order[10] = {55, 57, 59, 61, 63, 54, 56, 58, 60, 62};
-    int n_slots_nm = 0;
-    for (int g = 1; g <= 54; ++g) n_slots_nm += ((g & 3) != 0 && g != 2) ? 1 : 0;
-    for (int g = 0; g < 64; ++g) {
-        const int h = g - 32;
-        int ne = 0, nm = 0, dm = -1, tl = 0;
-        if (nomax && even) {
-            if ((g & 3) == 0) {
-                if (g >= 4 && g <= 32) dm = d++;
-            } else if (g != 2 && g <= 54) {
-                if ((slot_nm + 1) * 32 / n_slots_nm > slot_nm * 32 / n_slots_nm) ne = 1;
-                ++slot_nm;
-            }
-            if (g == 63) tl = 8;
-        } else if (g < 32) {
-            // gaps g % 4 == 0 carry the operand wait + two K reads; gap 2 the barrier; the DMA
-            // pieces follow it, one per four gaps
-            if ((g & 3) == 0) {
-                if (!dma_late && (bar_top || g >= 4)) dm = d++;
-            } else if (e < e1_end && (bar_top || g != 2)) {
-                const int slot = (g >> 2) * 3 + (g & 3) - 1;          // 0..23 over the gaps with g % 4 != 0
-                if ((slot + 1) * n_phase1 / 24 > slot * n_phase1 / 24) ne = 1;
-            }
-        } else {
-            if (!dma_late && d < 8 && h == 0) dm = d++;               // the eighth early piece
-            if ((h & 1) && h <= 21 && e < 32) {                       // odd gaps up to 53: the rest of the units
-                const int gaps_left = (21 - h) / 2 + 1;
-                ne = (32 - e + gaps_left - 1) / gaps_left;            // 1, or 2 while behind
-            }
-            if (h >= m0 && h < mend) {
-                if (!(h & 1)) nm = 2;                                 // even gaps (with the V reads): 2
-                else if (h >= odd0) nm = 1;                           // late odd gaps: 1  -> 24 + 8 = 32
-            }
-            if (dma_late && h >= 24) dm = d++;
-            if (masked) { if (h >= 27) tl = 10 + (h - 27); }          // merged chain steps 10..14
-            else if (h >= 24) tl = h - 23;                            // chain steps 1..8
-            if (nomax) { nm = 0; tl = (g == chain_gap) ? 8 : 0; }
-        }
-        int nearly = 0;
-        for (int i = 0; i < rot_k && i < 10; ++i) nearly += early_order[i] == g ? 1 : 0;
-        p.early_first[g] = (signed char)ee; p.early_n[g] = (signed char)nearly; ee += nearly;
-        p.exp_first[g] = (signed char)e; p.exp_n[g] = (signed char)ne; e += ne;
-        p.max_first[g] = (signed char)m; p.max_n[g] = (signed char)nm; m += nm;
-        p.dma[g] = (signed char)dm; p.tail[g] = (signed char)tl;
-        p.barrier[g] = (!bar_top && g == 2) ? 1 : 0;
-    }
-    return p;
-}
-constexpr bool plan64_ok(const Plan64 &p, int rot_k = 0) {
-    int e = rot_k, m = 0, d = 0, bar = -1, ee = 0;
-    bool chain = false;  // the plan carries the row max + the end-of-visit chain (not the speculative schedule)
-    for (int g = 0; g < 64; ++g) {
-        // P of 16-key slice s16 is consumed from gap 32 + 8 s16 on: its units must be >= 2 gaps older
-        for (int u = p.exp_first[g]; u < p.exp_first[g] + p.exp_n[g]; ++u)
-            if (g + 2 > 32 + 8 * (u >> 3)) return false;
-        // an early unit (of the next tile) writes P's slice u >> 3, last read by the MFMA of gap 32 + 8 (u >> 3) + 7 (whose
-        // operands stay allocated until the next MFMA has issued), and reads S(it+1), complete two MFMAs behind gap 31
-        for (int u = p.early_first[g]; u < p.early_first[g] + p.early_n[g]; ++u)
-            if (g < 32 + 8 * (u >> 3) + 9 || g < 34 || u >= 16) return false;
-        ee += p.early_n[g];
-        // S(it+1) tiles: nt = 0 last written at gap 29, nt = 1 at gap 31; read >= 2 MFMAs later
-        for (int u = p.max_first[g]; u < p.max_first[g] + p.max_n[g]; ++u)
-            if (g < ((u >> 4) ? 34 : 32)) return false;
-        if ((p.tail[g] == 1 || p.tail[g] == 10) && m < 32) return false;
-        if (p.tail[g] == 1 || p.tail[g] == 10) chain = true;
-        if (p.barrier[g]) bar = g;
-        if (p.dma[g] >= 0 && bar >= 0 && g <= bar) return false;      // DMA overwrites what the barrier frees
-        if (p.barrier[g] && g >= 28) return false;                    // V(it+1) is first read at gap 30
-        e += p.exp_n[g]; m += p.max_n[g]; d += p.dma[g] >= 0;
-    }
-    return e == 32 && ee == rot_k && m == (chain ? 32 : 0) && d == 8;
-}
 
 // Geometry of the persistent ring kernel (its own traits: FwdTraits describes fa_fwd_kernel.hpp's kernels, whose QT = 1
 // forms have two LDS stages): 4 waves, 64-key tiles, d_head 128, four K and four V stages + 8 KB of staging per wave.
@@ -136,68 +30,17 @@ template <int QT> struct RingTraits {
     static constexpr int kLdsBytes = 2 * kStages * kTileBytes + 4 * 32 * 2 * 128;
 };
 
-// One Q tile per wave (QTP = 1 below): a visit is 32 MFMAs, one gap per operand step -- gaps 0..15 S(it+1) = K(it+1) Q^T
-// (step = 2 ks + nt), gaps 16..31 O += V(it) P(it) (step 16 + 4 s16 + t).  Per visit: 16 softmax units (u = 4 s16 + j),
-// 16 row-max units over S(it+1) (complete behind gap 15), the merged end-of-visit chain (steps 10..14), the 8 DMA
-// pieces at the even gaps 2..16 (each needs the gap before it for its M0), the barrier in gap 1; the operand wait and
-// the two reads of the next pair sit in the even gaps.  Unit u's P slice s16 = u / 4 is consumed from gap 16 + 4 s16.
-constexpr Plan64 make_plan32(bool nomax = false) {
-    Plan64 p{};
-    int e = 0, m = 0, d = 0;
-    for (int g = 0; g < 32; ++g) {
-        const int h = g - 16;
-        int ne = 0, nm = 0, dm = -1, tl = 0;
-        if ((g & 1) == 0 && g >= 2 && g <= 16) dm = d++;
-        if (g < 16) {
-            // 11 units: the odd gaps 3..15, and the even gaps 4, 8, 12, 14 (the lighter ones: no DMA issue cost twice)
-            if (g >= 3 && ((g & 1) || g == 4 || g == 8 || g == 12 || g == 14)) ne = 1;
-        } else {
-            if ((h & 1) && h <= 9) ne = 1;                       // units 11..15 at gaps 17, 19, 21, 23, 25
-            if (h <= 10) nm = (!(h & 1) && h < 10) ? 2 : 1;      // 2 1 2 1 2 1 2 1 2 1 1 = 16
-            if (h >= 11) tl = 10 + (h - 11);                     // merged chain steps 10..14
-            if (nomax) { nm = 0; tl = (g == 31) ? 8 : 0; }       // speculative schedule: only the next request pointers
-        }
-        p.exp_first[g] = (signed char)e; p.exp_n[g] = (signed char)ne; e += ne;
-        p.max_first[g] = (signed char)m; p.max_n[g] = (signed char)nm; m += nm;
-        p.dma[g] = (signed char)dm; p.tail[g] = (signed char)tl;
-        p.barrier[g] = g == 1 ? 1 : 0;
-        p.early_first[g] = 0; p.early_n[g] = 0;
-    }
-    for (int g = 32; g < 64; ++g) { p.dma[g] = -1; }
-    return p;
-}
-constexpr int plan_barrier_gap(const Plan64 &p, int n_gaps) {
-    for (int g = 0; g < n_gaps; ++g)
-        if (p.barrier[g]) return g;
-    return -1;
-}
-constexpr bool plan32_ok(const Plan64 &p, bool nomax = false) {
-    int e = 0, m = 0, d = 0, bar = -1;
-    for (int g = 0; g < 32; ++g) {
-        for (int u = p.exp_first[g]; u < p.exp_first[g] + p.exp_n[g]; ++u)
-            if (g + 2 > 16 + 4 * (u >> 2)) return false;             // packed >= 2 gaps before its slice is consumed
-        // S(it+1): nt = 0 last written at gap 14, nt = 1 at gap 15; read >= 2 MFMAs later
-        for (int u = p.max_first[g]; u < p.max_first[g] + p.max_n[g]; ++u)
-            if (g < ((u >> 3) ? 17 : 16)) return false;
-        if (p.tail[g] == 10 && m < 16) return false;
-        if (p.barrier[g]) bar = g;
-        if (p.dma[g] >= 0 && (bar < 0 || g <= bar)) return false;    // DMA overwrites what the barrier frees
-        if (p.dma[g] >= 0 && g > 0 && p.dma[g - 1] >= 0) return false;
-        if (p.barrier[g] && g >= 28) return false;                   // K(it+2) is first read at gap 30
-        e += p.exp_n[g]; m += p.max_n[g]; d += p.dma[g] >= 0;
-    }
-    return e == 16 && m == (nomax ? 0 : 16) && d == 8 && bar >= 0;
-}
-
 // (the reference's meaning of optimized_softmax -- the first tile skips the rescale -- holds here by
 // construction, so the flag changes nothing on this kernel; SPEC and PSQ below are asked for through fa_fwd_opts)
-// ABL: 0 in the product.  tools/tune64.hip instantiates the kernel with experiment / timing-only bits so that a
-// measured claim in profiles/ can be re-run against the shipped code: 1 2 4 16 2048 4096 delete one part of the stream
-// (results wrong: timing only), 8 drops the waits and barriers (timing only), 256 512 1024 8192 16384 pick another filler
-// plan, 64 an eight-slot operand ring with one counted wait per four steps, 32768 the guard's check behind the visit instead of inside it, 128 the round-4 item loop (no hot region: every
-// visit carries the seam handling), 131072 two d tiles per epilogue step, 262144 no guard, 524288 a prologue that requests only
-// what visit 0 needs (timing only).  Round 4: 32 no row sums (timing only), bits 24..27 the rotated plan's rot_k (0 = the
-// shipped FA_ROT_DEFAULT, 15 = off), bit 28 the next request pointers in gap 58, bits 29..30 the cache policy of the O stores.
+// ABL: 0 in the product -- a translation unit built without -DFA_TUNE cannot instantiate anything else (static_assert
+// below), and every experiment bit is dead code there.  tools/tune64.hip / trace64.hip (-DFA_TUNE) instantiate the kernel
+// with TIMING-ONLY bits, so that a measured claim in profiles/ can be re-run against the shipped code; all but 128 and
+// 262144 compute WRONG results on purpose: 1 no exp2, 2 no softmax vector work at all, 4 no LDS operand reads, 8 no waits
+// and barriers, 16 no DMA, 32 no row sums, 2048 no multiply-add in front of exp2, 4096 no per-tile row max; 128 the round-4
+// item loop (no hot region: every visit carries the seam handling), 262144 no guard.  (The knobs HISTORY.md 0 marks
+// "no" -- barrier at the visit's top, DMA pieces late, units spread evenly, the eight-slot operand ring, the guard behind the
+// visit, two d tiles per epilogue step, the prologue that requests less, the store cache policies, rot_k / chain-gap
+// sweeps -- were deleted in round 6 with the measurements they produced kept in profiles/r01 .. r05.)
 // RAG (a second MASK variant): any seq_len >= 64.  The host rounds the Q blocks up and passes
 // n_kv_blocks = 4 n_q_blocks (the ring arithmetic wants a multiple of four tiles); a tile that would reach
 // beyond the sequence is fetched as the window of its last 64 keys instead (always inside the tensor, no
@@ -234,29 +77,21 @@ fa_fwd_kernel64(const KernelArgs args) {
     static_assert(!RAG || MASK, "the ragged form is a masked variant");
     static_assert(!PSQ || !MASK, "the pre-scaled Q is built for the plain form");
     static_assert(QTP == 2 || (QTP == 1 && !MASK && !RAG && !PSQ), "one Q tile per wave: the plain forms (lazy / speculative)");
+#ifdef FA_TUNE
+    constexpr int TUNE = ABL;
+#else
+    static_assert(ABL == 0, "experiment / timing-only variants exist in tools built with -DFA_TUNE only");
+    constexpr int TUNE = 0;
+#endif
     constexpr int QT = QTP, NWAVES = 4, BC = 64, D = 128;
     constexpr bool SWZ = true, EAGER = true, PIPE = true, DMA = true;
 
     using E = Elem<DT>;
     using vec8 = typename E::vec8;
     using TR = RingTraits<QT>;
-#if defined(FA_TRACE) && FA_TRACE == 3
-#define FA_TL() tl()
-#define FA_TLP(i) tl_stamp(i)
-#define FA_TLF() tl_flush()
-#define FA_VM8 "9"   // the stamp's store is one more vector-memory operation behind the pieces
-#define FA_VM16 "17"
-#define FA_VM24 "25"
-#define FA_VM32 "33"
-#else
-#define FA_TL() ((void)0)
-#define FA_TLP(i) ((void)0)
-#define FA_TLF() ((void)0)
-#define FA_VM8 "8"
-#define FA_VM16 "16"
-#define FA_VM24 "24"
-#define FA_VM32 "32"
-#endif
+#define FA_TRACE64_MACROS
+#include "fa_trace64.inc"
+#undef FA_TRACE64_MACROS
     constexpr int ROWB = 2 * D;              // bytes per K / V / O row (256, or 128 at d_head 64)
     constexpr int CPR = D / 8;               // 16-B chunks per row (16 / 8)
     constexpr int RPP = 64 / CPR;            // tile rows per 1-KiB DMA piece (4 / 8)
@@ -321,55 +156,9 @@ fa_fwd_kernel64(const KernelArgs args) {
         asm volatile("v_mov_b32 %0, %1" : "=v"(jit_state) : "s"(js_));
     };
 #endif
-#if defined(FA_TRACE) && FA_TRACE == 3
-    // timeline build (tools/trace64.hip): every wave stamps (low 32 bits of s_memtime) kernel entry, the
-    // end of the prologue, every visit top and the exit into trace32[(wave * 256 + blockIdx.x) * 96 + n];
-    // every wave, so that all four count the same one extra operation in vmcnt (FA_VM*)
-    unsigned *tl_p = (unsigned *)args.trace + (wave * 256 + (int)blockIdx.x) * 96;
-    auto tl = [&]() {
-        unsigned long long t_;
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");
-        const unsigned lo_ = __builtin_amdgcn_readfirstlane((unsigned)t_);
-        int l_;
-        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l_));
-        if (l_ == 0) *tl_p = lo_;
-        ++tl_p;
-    };
-    tl();
-    unsigned tl_pro[6] = {};  // prologue stamps, kept in SGPRs and stored behind the prologue's last wait
-    auto tl_stamp = [&](int i) {
-        unsigned long long t_;
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");
-        tl_pro[i] = __builtin_amdgcn_readfirstlane((unsigned)t_);
-    };
-    auto tl_flush = [&]() {
-        int l_;
-        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l_));
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            if (l_ == 0) *tl_p = tl_pro[i];
-            ++tl_p;
-        }
-    };
-#endif
-#if defined(FA_TRACE) && FA_TRACE >= 4
-    // item timeline (tools/trace64.hip -DFA_TRACE=4; 5 adds stamps inside the first seam, which slow every visit by ~5 %
-    // through their compares): stamps kept in ONE VGPR (lane n = stamp n: 0 kernel entry,
-    // 1 + ordinal = top of the item's first visit, 62 = S(0) of the first item formed, 63 = exit) and stored once at the
-    // end -- no memory operation is added to the walk, so the counted waits and the visits are the product kernel's
-    unsigned tlv = 0;
-    auto tl_at = [&](int slot) {
-        unsigned long long t_;
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");
-        const unsigned lo_ = __builtin_amdgcn_readfirstlane((unsigned)t_);
-        tlv = (lane == slot) ? lo_ : tlv;
-    };
-    tl_at(0);
-#define FA_TL4(slot) tl_at(slot)
-#else
-#define FA_TL4(slot) ((void)0)
-#endif
-
+#define FA_TRACE64_HELPERS
+#include "fa_trace64.inc"
+#undef FA_TRACE64_HELPERS
     // ---- workgroup -> (batch*head, Q block); XCD-aware when n_bh % 8 == 0 --------
     const int nq = args.n_q_blocks;
     // item -> (batch*head, Q block).  Workgroups are dealt round-robin over the 8 XCDs, so items
@@ -436,8 +225,8 @@ fa_fwd_kernel64(const KernelArgs args) {
             return head + (int64_t)t * tile_stride;
         }
     };
-    auto dma_wait = [&]() { if (DMA && !(ABL & 8)) dma_wait_all(); };
-    auto barrier = [&]() { if (!(ABL & 8)) { FA_JIT(false); wg_barrier(); } };
+    auto dma_wait = [&]() { if (DMA && !(TUNE & 8)) dma_wait_all(); };
+    auto barrier = [&]() { if (!(TUNE & 8)) { FA_JIT(false); wg_barrier(); } };
     // forward_kernel.cuh:150-151 (fp32 product of rsqrt(d) and log2 e)
     const float c = (float)((double)(1.0f / __builtin_sqrtf((float)D)) * 1.4426950408889634074);
     const float cs = PSQ ? 1.0f : c;  // what turns an S element into a base-2 exponent (PSQ: the scale already sits in Q)
@@ -489,7 +278,7 @@ fa_fwd_kernel64(const KernelArgs args) {
         // sequence block n_kv-1-it.  Causal: only the 4 (qb + 1) tiles up to the item's diagonal.
         const int n_kv = (MASK && args.causal) ? 4 * (qb + 1) : args.n_kv_blocks;
         // ---- first requests of the walk: K(0), then Q (all S(0) needs); the rest follows in the prologue
-        if (!(ABL & 16)) {
+        if (!(TUNE & 16)) {
 #pragma unroll
             for (int j = 0; j < DMA_PER_WAVE; ++j)
                 glds16_sv(tile_at(Kg, FWD ? 0 : n_kv - 1), k_off[j], smem_base + (wave + NWAVES * j) * 1024);
@@ -548,17 +337,12 @@ fa_fwd_kernel64(const KernelArgs args) {
             static_assert(DMA && D == 128 && BC == 64 && NT == 2 && NWAVES == 4, "pinned schedule");
             static_assert(TR::kStages == 4, "ring depth");
             constexpr float TAU = 8.0f;
-            // rotated units (make_plan64): ABL bits 24..27 = rot_k for tools/tune64.hip (15 = off, 0 = the shipped value),
-            // bit 28 = the next request pointers in gap 58 instead of behind the last MFMA
-            constexpr int ROT_REQ = (ABL >> 24) & 15;
-            constexpr int ROT_K = (FAST && !MASK && QT == 2) ? (ROT_REQ == 15 ? 0 : (ROT_REQ ? ROT_REQ : FA_ROT_DEFAULT)) : 0;
-            constexpr int CHAIN_GAP = (FAST && (ABL & (1 << 28))) ? 58 : 63;
-            constexpr Plan64 plan = QT == 1 ? make_plan32(FAST)
-                                            : make_plan64(((ABL >> 8) & 3) | (MASK ? 4 : 0) | (FAST ? 8 : 0) | ((ABL & 8192) ? 16 : 0),
-                                                          ((ABL & 1024) ? 20 : ((ABL & 16384) ? 23 : 22)) - ROT_K, ROT_K, CHAIN_GAP);
+            // rotated units (fa_plan64.hpp): the speculative plain form of the 64-row kernel carries the next tile's first units
+            constexpr int ROT_K = (FAST && !MASK && QT == 2) ? FA_ROT_DEFAULT : 0;
+            constexpr Plan64 plan = QT == 1 ? make_plan32(FAST) : make_plan64(MASK, FAST, 22 - ROT_K, ROT_K);
             static_assert(QT == 1 ? plan32_ok(plan, FAST) : plan64_ok(plan, ROT_K), "filler plan violates a wait-state distance");
             constexpr int GAPS = 32 * QT, PH2 = 16 * QT;   // MFMAs of a visit; the first one of phase 2 (O += V P)
-            constexpr int BAR_GAP = plan_barrier_gap(plan, GAPS);   // -1: the sync point sits at the visit's top
+            static_assert(plan_barrier_gap(plan, GAPS) >= 0, "the sync point rides inside the stream");
             f32x16 Sa[QT][NT], Sb[QT][NT];
             u32x4 Pw[QT][4] = {};     // P[qt][16-key slice]: B operand of O^T += V^T P^T
             float neg_msc[QT];       // -(m c)
@@ -719,19 +503,11 @@ fa_fwd_kernel64(const KernelArgs args) {
             };
             const uint16_t *kq = nullptr, *vq = nullptr;  // next K / V tile to request (set per item below)
             // operand ring: slot u % RS holds operand u; the loads of operands step + LA, step + LA + 1 are issued
-            // at (even) step `step`, into the slots of the two operands whose MFMAs have just issued.  RS = 4:
-            // two steps (4 MFMAs, ~170 cycles) between a load and its use -- less than the LDS latency with four
-            // waves reading operands and the DMA writing: tools/trace64.hip (-DFA_TRACE=2) shows the wait in front
-            // of every fourth MFMA stall 25-50 cycles.  RS = 8: six steps.
-            // ABL & 64 (round 5, tools/tune64.hip): RS = 8 and ONE counted wait per FOUR steps -- the wait in front of step s
-            // (s % 4 == 0) retires operands s .. s+3 (requested six and four steps ago) and lets the two youngest fly, the one
-            // in front of step s+2 is gone: eight s_waitcnt fewer per visit.  Measured +0.2 % at S = 4096, 0 at 16384
-            // (profiles/r05/tune64_ring8_wait4.txt; the eight-slot ring alone: +0.1 %, profiles/r04/ring_slots_4_vs_8.txt):
-            // a satisfied s_waitcnt is not what the issue-bound stream pays for.  Not adopted (16 registers).
-            // (One Q tile per wave: a step is ONE gap there, so the four-slot ring reads only two gaps ahead; eight slots -- six
-            // gaps -- measured +0.3 %: that form is issue bound too, 7.9 instructions per MFMA, not latency bound.)
-            constexpr int RS = ((ABL & 64) && !PSQ) ? 8 : FA_RING_SLOTS, LA = RS - 2;
-            constexpr bool WAIT4 = RS >= 8;
+            // at (even) step `step`, into the slots of the two operands whose MFMAs have just issued: two steps (4 MFMAs,
+            // ~170 cycles) between a load and its use.  (Eight slots -- six steps of read-ahead, also with one counted wait
+            // per four steps -- measured +0.1 ... +0.3 % in rounds 1, 4 and 5: the stream is issue bound, not latency bound;
+            // profiles/r05/tune64_ring8_wait4.txt.)
+            constexpr int RS = 4, LA = RS - 2;
             vec8 ring[RS];
             vec8 Qr2[QT][KS];  // the next item's Q (AGPRs), requested during the item's first visit
             float mraw[QT];  // row max of the S tile formed by the last visit (the next item's S(0))
@@ -740,9 +516,8 @@ fa_fwd_kernel64(const KernelArgs args) {
             // skips stores; counted down to a multiple of 8, which only waits for more)
             int seam_st = 0;
             // the guard's common path (see guard() below) rides in the last gaps of every fourth visit, where the vector
-            // stream has room (all 32 softmax units have issued by gap 53): two adds, a max, a compare.  ABL & 32768
-            // (tools/tune64.hip): behind the visit instead, as first built.
-            constexpr bool GUARD_IN_VISIT = FAST && !(ABL & 32768) && !(ABL & 262144);
+            // stream has room (all 32 softmax units have issued by gap 53): two adds, a max, a compare.
+            constexpr bool GUARD_IN_VISIT = FAST && !(TUNE & 262144);
             float g_l0 = 0.0f, g_l1 = 0.0f, g_lm = 0.0f;
             (void)g_l0; (void)g_l1;
             bool guard_hit = false;
@@ -825,13 +600,13 @@ fa_fwd_kernel64(const KernelArgs args) {
             float rs_e[QT][2] = {};
             auto exp_unit_on = [&](auto &S_src, int u, auto sum_tag) {
                 constexpr int SUM = decltype(sum_tag)::value;
-                if constexpr (ABL & 2) return;
+                if constexpr (TUNE & 2) return;
                 const int qt = u % QT, j = (u / QT) & 3, s16 = u / (4 * QT), r = 8 * (s16 & 1) + 2 * j;   // QT = 2: u = 8 s16 + 2 j + qt
                 // exp2(s c - m c), softmax.cuh:51-64.  Scalar f32 forms on purpose: v_pk_fma_f32 /
                 // v_pk_add_f32 here measured -6 % / -12 %; splitting the unit into stages over three
                 // gaps (no dependent pair inside a gap) measured -1.5 %.
                 float p0, p1;
-                if constexpr (ABL & 2048) {  // (timing only: what a pre-scaled Q with -m c fed through the MFMA's C operand would save)
+                if constexpr (TUNE & 2048) {  // (timing only: what a pre-scaled Q with -m c fed through the MFMA's C operand would save)
                     p0 = S_src[qt][s16 >> 1][r];
                     p1 = S_src[qt][s16 >> 1][r + 1];
                 } else if constexpr (PSQ && FAST) {  // -(m c) came in through the C operand of the tile's first MFMA
@@ -844,18 +619,18 @@ fa_fwd_kernel64(const KernelArgs args) {
                     p0 = __builtin_fmaf(S_src[qt][s16 >> 1][r], c, neg_msc[qt]);
                     p1 = __builtin_fmaf(S_src[qt][s16 >> 1][r + 1], c, neg_msc[qt]);
                 }
-                if (!(ABL & 1)) {
+                if (!(TUNE & 1)) {
                     p0 = __builtin_amdgcn_exp2f(p0);
                     p1 = __builtin_amdgcn_exp2f(p1);
                 }
-                if constexpr (SUM == SUM_RS && !(ABL & 32)) {  // (ABL & 32, tools/tune64.hip, TIMING ONLY: no row sums)
+                if constexpr (SUM == SUM_RS && !(TUNE & 32)) {  // (TUNE & 32, tools/tune64.hip, TIMING ONLY: no row sums)
                     rs[qt][0] += p0;  // fp32 P, before rounding (softmax.cuh:66-83)
                     rs[qt][1] += p1;
                     // pin the adds to this gap: hipcc otherwise sinks the whole row-sum chain (and keeps
                     // every p alive) to the first use of l, behind the next visit's barrier
                     asm volatile("" : "+v"(rs[qt][0]), "+v"(rs[qt][1]));
                 }
-                if constexpr (SUM == SUM_EARLY && !(ABL & 32)) {
+                if constexpr (SUM == SUM_EARLY && !(TUNE & 32)) {
                     rs_e[qt][0] += p0;
                     rs_e[qt][1] += p1;
                     asm volatile("" : "+v"(rs_e[qt][0]), "+v"(rs_e[qt][1]));
@@ -913,7 +688,7 @@ fa_fwd_kernel64(const KernelArgs args) {
                 // visit overwrites.  In the default plan it sits two MFMAs into the visit, after the
                 // gap-0 lgkmcnt(0) that retires this wave's last LDS reads of visit it-1.
                 auto sync_point = [&]() {
-                    if (ABL & 8) return;
+                    if (TUNE & 8) return;
                     FA_JIT(false);
                     // One compare and one branch on the common path.  The first three visits of an item take
                     // the slow path: more may be in flight behind the pieces the barrier publishes -- in issue
@@ -921,10 +696,7 @@ fa_fwd_kernel64(const KernelArgs args) {
                     // pieces(0) [Q tile 1: 8] pieces(1) pieces(2) -- and the next item's Q tiles are moved
                     // into the spare Q set here (see request_next_q).
                     if (HOTB || it >= 3) {
-                        // (ABL bit 22, tools/tune64.hip, TIMING ONLY -- results wrong: the workgroup barrier on every second
-                        // visit only, the counted wait on all: what a ring protocol with one barrier per two visits could save)
-                        if constexpr ((ABL & (1 << 22)) != 0 && (R & 1) != 0) asm volatile("s_waitcnt vmcnt(" FA_VM8 ")" ::: "memory");
-                        else asm volatile("s_waitcnt vmcnt(" FA_VM8 ")\n\ts_barrier" ::: "memory");
+                        asm volatile("s_waitcnt vmcnt(" FA_VM8 ")\n\ts_barrier" ::: "memory");
                         return;
                     }
                     const int q8 = has_next ? 8 : 0;
@@ -961,10 +733,6 @@ fa_fwd_kernel64(const KernelArgs args) {
                         zero_cinit();  // this visit forms the NEXT item's S(0): no reference yet
                     }
                 }
-                if constexpr (BAR_GAP < 0) {
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    sync_point();
-                }
                 const unsigned kdst = smem_base + R * TILE + wave * 1024;                        // K(it+4) -> stage of K(it)
                 const unsigned vdst = smem_base + V_BASE + ((R + 3) & 3) * TILE + wave * 1024;   // V(it+3) -> stage of V(it-1)
                 if (!FAST && resc_any) {  // wave-uniform, rare: move the reference max of one or both Q tiles
@@ -1000,8 +768,8 @@ fa_fwd_kernel64(const KernelArgs args) {
                 unsigned any01 = 0;
                 auto max_unit = [&](int u) {  // u = 0..31: tile (nt = u>>4, qt = (u>>3)&1), elements 2(u&7), +1
                     const int nt = u / (8 * QT), qt = (u >> 3) % QT, e = 2 * (u & 7), a = u & 1;  // two chains per Q tile
-                    if constexpr (ABL & 2) { vm[qt][a] = 0.0f; return; }
-                    if constexpr (ABL & 4096) return;  // (timing only: no per-tile row max)
+                    if constexpr (TUNE & 2) { vm[qt][a] = 0.0f; return; }
+                    if constexpr (TUNE & 4096) return;  // (timing only: no per-tile row max)
                     // asm forms: fmaxf() on MFMA results makes hipcc canonicalise both inputs first
                     // volatile: pinned to its gap (S_nxt is rewritten next visit).  Not an empty "+v" asm behind
                     // it: hipcc pads an asm that reads what the asm right before it wrote with an s_nop
@@ -1017,7 +785,7 @@ fa_fwd_kernel64(const KernelArgs args) {
                     return d;
                 };
                 auto tail_unit = [&](int k) {
-                    if constexpr (FAST || (ABL & 4096)) { if (k < 8) return; }
+                    if constexpr (FAST || (TUNE & 4096)) { if (k < 8) return; }
                     if (k == 1) {
                         asm volatile("v_max_f32 %0, %0, %1" : "+v"(vm[0][0]) : "v"(vm[0][1]));
                         if constexpr (QT == 2) asm volatile("v_max_f32 %0, %0, %1" : "+v"(vm[QT - 1][0]) : "v"(vm[QT - 1][1]));
@@ -1068,7 +836,7 @@ fa_fwd_kernel64(const KernelArgs args) {
                 // latency is exposed at the visit seam
                 const char *kt_next = smem + ((R + 2) & 3) * TILE;
                 auto operand = [&](int u) -> vec8 {
-                    if constexpr (ABL & 4) return __builtin_bit_cast(vec8, Pw[u % QT][(u >> 1) & 3]);
+                    if constexpr (TUNE & 4) return __builtin_bit_cast(vec8, Pw[u % QT][(u >> 1) & 3]);
                     return u < 16 ? k_frag(kt, u) : (u < 32 ? v_frag(vt, u - 16) : k_frag(kt_next, u - 32));
                 };
                 auto gap_body = [&](auto gap_tag) {
@@ -1082,19 +850,15 @@ fa_fwd_kernel64(const KernelArgs args) {
                     // that names it, placed behind that MFMA (volatile asm statements keep their order).
                     vec8 prev_a = ring[(step + RS - 1) % RS];  // A operand of the previous step (its slot is reloaded below)
                     if constexpr (qt == 0 && (step & 1) == 0) {  // operands in pairs
-                        // the counted wait: operands step, step + 1 (WAIT4: step .. step + 3, every second pair only) landed;
-                        // the LDS reads of the operands behind them up to step + LA - 1 (one per K fragment, two per V
-                        // fragment; LDS returns in order) may still fly
-                        constexpr int need = WAIT4 ? 4 : 2;
-                        constexpr int fly = [] { int n = 0; for (int u = step + need; u < step + LA; ++u) n += (u >= 16 && u < 32) ? 2 : 1; return n; }();
-                        if constexpr (!WAIT4 || (step & 3) == 0) {
+                        // the counted wait: operands step, step + 1 landed; the LDS reads of the operands behind them up to
+                        // step + LA - 1 (one per K fragment, two per V fragment; LDS returns in order) may still fly
+                        constexpr int fly = [] { int n = 0; for (int u = step + 2; u < step + LA; ++u) n += (u >= 16 && u < 32) ? 2 : 1; return n; }();
                         FA_JIT(true);
 #if defined(FA_TRACE) && FA_TRACE < 4
                         __builtin_amdgcn_s_waitcnt(0xC07F);      // (s_memtime returns out of order: no counting)
 #else
                         __builtin_amdgcn_s_waitcnt(0xC07F | (fly << 8));
 #endif
-                        }
 #if defined(FA_TRACE) && FA_TRACE == 1
                         asm volatile("s_memtime %0" : "=s"(ts[2 + step / 2]));
 #endif
@@ -1129,14 +893,14 @@ fa_fwd_kernel64(const KernelArgs args) {
                             mask_tile(S_nxt, nkn - 1, qb_n, g - 34);
                         }
                     }
-                    if constexpr (g < GAPS - 1 && plan.dma[g + 1] >= 0 && !(ABL & 16)) {
+                    if constexpr (g < GAPS - 1 && plan.dma[g + 1] >= 0 && !(TUNE & 16)) {
                         // M0 (LDS destination) of the DMA piece of the NEXT gap: the write needs one instruction
                         // between it and the DMA, and that gap's MFMA is one (hipcc itself never touches M0 here)
                         constexpr int j = plan.dma[g + 1] >> 1;
                         asm volatile("s_mov_b32 m0, %0" ::"s"((plan.dma[g + 1] & 1) == 0 ? kdst + NWAVES * j * 1024
                                                                                           : vdst + NWAVES * j * 1024));
                     }
-                    if constexpr (plan.dma[g] >= 0 && !(ABL & 16)) {  // one 1-KiB DMA piece (its M0 was set one gap ago)
+                    if constexpr (plan.dma[g] >= 0 && !(TUNE & 16)) {  // one 1-KiB DMA piece (its M0 was set one gap ago)
                         constexpr int j = plan.dma[g] >> 1;
                         static_assert(g > 0 && plan.dma[g - 1] < 0, "a DMA piece needs the gap before it for its M0");
                         // per-piece lane offsets: 6 more VGPRs than one offset + a scalar piece stride (piece j
@@ -1150,8 +914,8 @@ fa_fwd_kernel64(const KernelArgs args) {
                     if constexpr (ROT_K > 0) {
                         // (rotated plan) the side sums of this tile's early units -- formed in the previous visit's last gaps,
                         // or by head_units -- join the row sums, in the last gaps before the next early units start them again
-                        if constexpr (g == 52 && !(ABL & 32)) { rs[0][0] += rs_e[0][0]; rs[0][1] += rs_e[0][1]; asm volatile("" : "+v"(rs[0][0]), "+v"(rs[0][1])); }
-                        if constexpr (g == 53 && !(ABL & 32)) { rs[1][0] += rs_e[1][0]; rs[1][1] += rs_e[1][1]; asm volatile("" : "+v"(rs[1][0]), "+v"(rs[1][1])); }
+                        if constexpr (g == 52 && !(TUNE & 32)) { rs[0][0] += rs_e[0][0]; rs[0][1] += rs_e[0][1]; asm volatile("" : "+v"(rs[0][0]), "+v"(rs[0][1])); }
+                        if constexpr (g == 53 && !(TUNE & 32)) { rs[1][0] += rs_e[1][0]; rs[1][1] += rs_e[1][1]; asm volatile("" : "+v"(rs[1][0]), "+v"(rs[1][1])); }
                         // ... and the next tile's first units, against the same reference.  In an item's LAST visit that tile
                         // is the next item's S(0), whose reference is not known yet: what the units leave then (packed P, side
                         // sums) is formed again by head_units behind the seam, nothing else is touched
@@ -1218,11 +982,9 @@ fa_fwd_kernel64(const KernelArgs args) {
             // at every checkpoint l was below the limit and, wherever l had risen above the threshold, O was finite.
             bool item_bad = false;
             auto guard = [&](auto &S_cur, const bool behind_last_visit) {
-                if constexpr (FAST && !(ABL & 262144)) {  // (ABL & 262144: tools/tune64.hip times the kernel without it)
+                if constexpr (GUARD_IN_VISIT) {  // (= FAST, but for the tool that times the kernel without the guard)
                     constexpr float kResc = spec_guard<DT>(), kLimit = spec_limit64<DT>();
-                    if constexpr (GUARD_IN_VISIT) {
-                        if (__builtin_expect(!guard_hit, 1)) return;  // (decided inside the visit that just ended)
-                    }
+                    if (__builtin_expect(!guard_hit, 1)) return;  // (decided inside the visit that just ended)
                     float l_q[QT];
 #pragma unroll
                     for (int qt = 0; qt < QT; ++qt) l_q[qt] = vadd(rs[qt][0], rs[qt][1]);
@@ -1310,7 +1072,7 @@ fa_fwd_kernel64(const KernelArgs args) {
             FA_TLP(1);  // Q, K(1), V(0) requested
             // S(0) of the wave's first 32 rows needs only K(0) and Q tile 0, which land ~1.5 k cycles before Q tile 1
             // (the requests return in issue order at the CU's start-up rate): start on them, take tile 1 when it is in
-            if (!(ABL & 8)) {  // K(0), Q tile 0 landed: [Q tile 1,] K(1), V(0) fly on
+            if (!(TUNE & 8)) {  // K(0), Q tile 0 landed: [Q tile 1,] K(1), V(0) fly on
                 if constexpr (QT == 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             }
@@ -1327,7 +1089,7 @@ fa_fwd_kernel64(const KernelArgs args) {
                 for (int step = 0; step < 16; ++step) a_all[step] = k_frag(kt, step);
                 static_for<0, 16>([&](auto step_tag) { qk_mfma(Sa, decltype(step_tag)::value, 0, a_all[decltype(step_tag)::value]); });
                 if constexpr (QT == 2) {
-                    if (!(ABL & 8)) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // Q tile 1 landed: K(1), V(0) fly on
+                    if (!(TUNE & 8)) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // Q tile 1 landed: K(1), V(0) fly on
                     read_q(Qr[QT - 1], smem_base + (wave < 2 ? 3 * TILE : V_BASE + 3 * TILE) + (wave & 1) * 8192);
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     static_for<0, 16>([&](auto step_tag) { qk_mfma(Sa, decltype(step_tag)::value, QT - 1, a_all[decltype(step_tag)::value]); });
@@ -1338,15 +1100,11 @@ fa_fwd_kernel64(const KernelArgs args) {
                 dma_k(tile_g(Kc, Kn, 2), 2);
                 dma_v(tile_g(Vc, Vn, 1), 1);
                 barrier();  // every wave has read its Q tile 1 out of stages 3, which K(3) now overwrites
-                // (ABL & 524288, tools/tune64.hip, TIMING ONLY -- results are wrong: the upper bound of what deferring these
-                // 64 KB + 32 KB out of the prologue could buy: they are simply not requested)
-                if (!(ABL & 524288)) {
-                    dma_k(tile_g(Kc, Kn, 3), 3);
-                    dma_v(tile_g(Vc, Vn, 2), 2);
-                }
+                dma_k(tile_g(Kc, Kn, 3), 3);
+                dma_v(tile_g(Vc, Vn, 2), 2);
                 kq = tile_g(Kc, Kn, 4);
                 vq = tile_g(Vc, Vn, 3);
-                if (has_next && !(ABL & 524288)) request_next_q(0);
+                if (has_next) request_next_q(0);
                 FA_TLP(4);  // S(0) MFMAs and the remaining requests issued
                 asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // MFMA D -> VALU read
 #pragma unroll
@@ -1366,7 +1124,7 @@ fa_fwd_kernel64(const KernelArgs args) {
                 }
                 set_cinit(Sa);
                 head_units(Sa);
-                if (!(ABL & 8)) {  // K(1) landed (under S(0)); younger: V(0), K(2), V(1) [, K(3), V(2) [, the next Q tile 0]]
+                if (!(TUNE & 8)) {  // K(1) landed (under S(0)); younger: V(0), K(2), V(1) [, K(3), V(2) [, the next Q tile 0]]
                     if (has_next) asm volatile("s_waitcnt vmcnt(28)" ::: "memory");
                     else asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
                 }
@@ -1427,8 +1185,7 @@ fa_fwd_kernel64(const KernelArgs args) {
                             w[1] = E::pack2(hi2[0], hi2[1]);
                             *(u32x2 *)(wp + (((4 * t + rq) ^ swz_of(r31)) << 4)) = w;
                         }
-                        // one d tile at a time: S(0) of the next item is live (ABL & 131072, experiment: two at a time)
-                        if (!(ABL & 131072) || (t & 1)) __builtin_amdgcn_sched_barrier(0);
+                        __builtin_amdgcn_sched_barrier(0);   // one d tile at a time: S(0) of the next item is live
                     }
                     if (qt == QT - 1 && zero_behind) zero_o();
                     // rows RPP i + rsub of the tile: one scalar base for the 32 rows, a 32-bit lane offset per store;
@@ -1455,18 +1212,9 @@ fa_fwd_kernel64(const KernelArgs args) {
                         // s_nop 1: a store of more than 64 bits reads its data registers for two more cycles, and hipcc --
                         // which does not see the instruction inside the asm -- may reuse v[i] for the very next vector
                         // instruction (it did, for the next store's address: tools/isa_lint64.py, finding STDATA)
-                        // cache policy of the O stores (ABL bits 29..30, tools/tune64.hip: 0 = nt as shipped, 1 = sc1, 2 = sc0 sc1
-                        // write-through, 3 = default): what is still dirty in the L2s when the launch ends is written back at the
-                        // kernel boundary (MI355X_MICROARCH.md, price list row `boundary`)
-                        constexpr int STP = (ABL >> 29) & 3;
-                        if constexpr (STP == 0)
-                            asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" ::"v"(lane_off + (unsigned)(RPP * i) * (unsigned)ss * 2u), "v"(v[i]), "s"(rows0));
-                        else if constexpr (STP == 1)
-                            asm volatile("global_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 1" ::"v"(lane_off + (unsigned)(RPP * i) * (unsigned)ss * 2u), "v"(v[i]), "s"(rows0));
-                        else if constexpr (STP == 2)
-                            asm volatile("global_store_dwordx4 %0, %1, %2 sc0 sc1\n\ts_nop 1" ::"v"(lane_off + (unsigned)(RPP * i) * (unsigned)ss * 2u), "v"(v[i]), "s"(rows0));
-                        else
-                            asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(lane_off + (unsigned)(RPP * i) * (unsigned)ss * 2u), "v"(v[i]), "s"(rows0));
+                        // nt: O is written once and not read again (sc1 / sc0 sc1 write-through and the default policy measured
+                        // 0 / 0 / -0.1 ... -3 %: profiles/r04/tune64_store_policy.txt)
+                        asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" ::"v"(lane_off + (unsigned)(RPP * i) * (unsigned)ss * 2u), "v"(v[i]), "s"(rows0));
                     }
                 }
             };
@@ -1475,8 +1223,8 @@ fa_fwd_kernel64(const KernelArgs args) {
             // GENERAL visits (whatever an item's ends need, decided at run time), the groups in between the HOT ones (see
             // visit()).  Straight-line by construction -- [first group] [hot loop] [loop over the last two groups] [epilogue
             // + seam] -- because alternative visit bodies that join behind a branch (or a loop both reach) made hipcc
-            // shuffle the accumulator tiles between them and spill.  ABL & 128 (tools/tune64.hip): no hot region, as round 4 ran.
-            constexpr bool HOT_LOOP = !(ABL & 128);
+            // shuffle the accumulator tiles between them and spill.  TUNE & 128 (tools/tune64.hip): no hot region, as round 4 ran.
+            constexpr bool HOT_LOOP = !(TUNE & 128);
             for (;;) {
                 int it = 0;
                 if constexpr (HOT_LOOP) {
@@ -1518,7 +1266,7 @@ fa_fwd_kernel64(const KernelArgs args) {
                 guard(Sa, true);
                 const int qb_st = qb_c;  // the item being stored
                 (void)qb_st;
-                store_item(Oc, qb_c, ord, has_next && !(ABL & 128));
+                store_item(Oc, qb_c, ord, has_next && !(TUNE & 128));
 #if defined(FA_TRACE) && FA_TRACE >= 4
                 if (tl_seam) tl_at(51);  // epilogue issued
 #endif
@@ -1576,7 +1324,7 @@ fa_fwd_kernel64(const KernelArgs args) {
 #if defined(FA_TRACE) && FA_TRACE >= 4
                 if (tl_seam) tl_at(55);  // row max of S(0), softmax state reset
 #endif
-                if constexpr ((ABL & 128) != 0) zero_o();  // (otherwise cleared inside store_item)
+                if constexpr ((TUNE & 128) != 0) zero_o();  // (otherwise cleared inside store_item)
 #if defined(FA_TRACE) && FA_TRACE >= 4
                 if (tl_seam) tl_at(52);  // O = 0 issued
 #endif

@@ -345,3 +345,32 @@ def test_visit_histogram_matches_the_committed_digest():
     assert got["hipcc"] == want["hipcc"], ("the compiler changed: every hand-placed schedule needs re-verification on the GPU "
                                            "(pytest -m gpu, tools/soak.py, bench.py) before the digest is regenerated", got["hipcc"])
     assert got["kernels"] == want["kernels"], "the visit's instruction histogram moved: see the docstring"
+
+
+def test_product_translation_units_cannot_instantiate_timing_only_variants(tmp_path):
+    """VERDICT r05 task 8: the persistent kernel's experiment bits (template argument ABL: most of them compute WRONG
+    results on purpose, for timing) exist only in tools built with -DFA_TUNE.  The product's slices are compiled without it
+    -- checked on the PREPROCESSED source of a product slice: the constant the kernel body reads is 0 there and a
+    static_assert refuses any other ABL -- and the Makefile gives -DFA_TUNE to the tools alone.  A translation unit without
+    the macro that asks for ABL = 2 (no softmax vector work at all) does not compile."""
+    import subprocess
+    csrc = os.path.join(ROOT, "flash_attention_from_scratch_amd", "csrc")
+    hipcc = "/opt/rocm/bin/hipcc"
+    pre = subprocess.run([hipcc, "-E", "-std=c++17", "--offload-arch=gfx950", "--cuda-device-only", "-DFA_INST_DT=15", "-DFA_INST_QT=2",
+                          os.path.join(csrc, "fa_inst.hip")], capture_output=True, text=True, timeout=600)
+    assert pre.returncode == 0, pre.stderr[-2000:]
+    text = pre.stdout
+    assert "constexpr int TUNE = 0;" in text and "constexpr int TUNE = ABL;" not in text
+    assert 'static_assert(ABL == 0' in text
+    mk = open(os.path.join(csrc, "Makefile")).read()
+    flags = {ln.split(":=")[0].split("?=")[0].strip(): ln for ln in mk.splitlines() if ":=" in ln or "?=" in ln}
+    assert "-DFA_TUNE" in flags["TOOLFLAGS"] and "-DFA_TUNE" not in flags["HIPFLAGS"] and "-DFA_TUNE" not in flags["QT2FLAGS"]
+    src = tmp_path / "wrong.hip"
+    src.write_text('#include "%s/fa_fwd_kernel64.hpp"\n'
+                   'template __global__ void fa::fa_fwd_kernel64<15, false, 2, false, true, false, 2>(const fa::KernelArgs);\n' % csrc)
+    bad = subprocess.run([hipcc, "-std=c++17", "--offload-arch=gfx950", "--cuda-device-only", "-fsyntax-only", str(src)],
+                         capture_output=True, text=True, timeout=600)
+    assert bad.returncode != 0 and "timing-only variants" in bad.stderr, bad.stderr[-1500:]
+    # (the header the review reads: the plans and the trace helpers live in their own files)
+    n_lines = len(open(os.path.join(csrc, "fa_fwd_kernel64.hpp")).read().splitlines())
+    assert n_lines <= 1400, n_lines
