@@ -316,6 +316,30 @@ static FA_DEV void glds16_sv_m0(const void *base_wave_uniform, unsigned lane_byt
 static FA_DEV void glds16_issue(const void *base_wave_uniform, unsigned lane_byte_off) {
     asm volatile("global_load_lds_dwordx4 %0, %1" : : "v"(lane_byte_off), "s"(base_wave_uniform) : "memory");
 }
+// The same three with an IMMEDIATE offset (round 6).  The instruction adds it to the global address AND to the LDS
+// destination (measured: M0 = base + 2048, offset:1024 lands at base + 3072 what lies 1024 bytes behind the lane's
+// address), so the pieces of one tile that a wave requests can share ONE M0 value when they are neighbours in the LDS
+// image: destination = M0 + 1024 j, the lane offsets carry -1024 j to compensate (fa_fwd_kernel64.hpp).
+template <int OFF> static FA_DEV void glds16_sv_off(const void *base_wave_uniform, unsigned lane_byte_off, unsigned lds_dst_wave_uniform) {
+    static_assert(OFF >= 0 && OFF < 4096, "13-bit signed immediate");
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, %2 offset:%4\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(lane_byte_off), "s"(base_wave_uniform), "s"(lds_dst_wave_uniform), "n"(OFF)
+                 : "memory");
+}
+template <int OFF> static FA_DEV void glds16_sv_m0_off(const void *base_wave_uniform, unsigned lane_byte_off, unsigned lds_dst_wave_uniform) {
+    static_assert(OFF >= 0 && OFF < 4096, "13-bit signed immediate");
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 3\n\tglobal_load_lds_dwordx4 %0, %1 offset:%3"
+                 :
+                 : "v"(lane_byte_off), "s"(base_wave_uniform), "s"(lds_dst_wave_uniform), "n"(OFF)
+                 : "memory");
+}
+template <int OFF> static FA_DEV void glds16_issue_off(const void *base_wave_uniform, unsigned lane_byte_off) {
+    static_assert(OFF >= 0 && OFF < 4096, "13-bit signed immediate");
+    asm volatile("global_load_lds_dwordx4 %0, %1 offset:%2" : : "v"(lane_byte_off), "s"(base_wave_uniform), "n"(OFF) : "memory");
+}
 static FA_DEV void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 // workgroup barrier that the compiler may not move LDS traffic across and that does
 // not drain VMEM (in-flight DMA survives it)

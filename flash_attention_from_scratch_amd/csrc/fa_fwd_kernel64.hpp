@@ -197,9 +197,6 @@ fa_fwd_kernel64(const KernelArgs args) {
     //   V: chunk p -> subtile p>>5 = (key>>3)*4 + (d>>5); inside: key&7 = (p&31)>>2,
     //      d&31 = (p&3)*8
     const int k_row_in_piece = lane / CPR;                                 // 0..RPP-1
-    // swizzle of tile row RPP*i + k_row_in_piece; i = wave + NWAVES*j and RPP*NWAVES % 16 == 0
-    const int k_swz = SWZ ? swz_of(RPP * wave + k_row_in_piece) : 0;
-    const int64_t k_lane_off = (int64_t)k_row_in_piece * ss + (((lane & (CPR - 1)) ^ k_swz) << 3);
     const int v_sub_in_piece = lane >> 5;                                  // 0..1
     const int v_w = lane & 31;
     const int64_t v_lane_row = (v_w >> 2);                                 // key & 7
@@ -208,13 +205,21 @@ fa_fwd_kernel64(const KernelArgs args) {
     const unsigned smem_base = __builtin_amdgcn_readfirstlane(lds_addr(smem));
     // DMA addressing: SGPR base = head base + tile offset (scalar ALU), VGPR = 32-bit
     // per-lane byte offset of this wave's piece inside a tile (invariant over tiles).
+    // Round 6: a wave's pieces are NEIGHBOURS in the LDS image (piece i = 4 wave + j), and piece j is issued with the
+    // immediate offset 1024 j, which the instruction adds to the LDS destination as well as to the global address
+    // (fa_fwd_kernel.hpp, glds16_issue_off): ONE M0 per tile and wave (= stage + 4096 wave) instead of one per piece --
+    // six scalar instructions fewer per visit.  The lane offsets carry the -1024 j; so that they stay unsigned, the K / V
+    // head pointers of this kernel sit DMA_BIAS bytes in front of the tensors' and the offsets DMA_BIAS behind.
+    constexpr unsigned DMA_BIAS = (DMA_PER_WAVE - 1) * 1024;
     unsigned k_off[DMA_PER_WAVE], v_off[DMA_PER_WAVE];
 #pragma unroll
     for (int j = 0; j < DMA_PER_WAVE; ++j) {
-        const int i = wave + NWAVES * j;  // piece index, wave-uniform; keys 4i .. 4i+3
-        k_off[j] = (unsigned)(((int64_t)(RPP * i) * ss + k_lane_off) * 2);
+        const int i = DMA_PER_WAVE * wave + j;  // piece index, wave-uniform; keys 4i .. 4i+3
+        const int k_row = RPP * i + k_row_in_piece;
+        const int k_swz = SWZ ? swz_of(k_row) : 0;
+        k_off[j] = (unsigned)(((int64_t)k_row * ss + (((lane & (CPR - 1)) ^ k_swz) << 3)) * 2) + DMA_BIAS - 1024u * j;
         const int sub = 2 * i + v_sub_in_piece;  // subtiles 2i, 2i+1
-        v_off[j] = (unsigned)(((8 * (sub / DSUB) + v_lane_row) * ss + (sub % DSUB) * 32 + v_lane_d) * 2);
+        v_off[j] = (unsigned)(((8 * (sub / DSUB) + v_lane_row) * ss + (sub % DSUB) * 32 + v_lane_d) * 2) + DMA_BIAS - 1024u * j;
     }
     const int64_t tile_stride = (int64_t)BC * ss;  // elements between consecutive KV blocks
     auto tile_at = [&](const uint16_t *head, int t) {  // first row of tile t of a head's K or V
@@ -231,22 +236,25 @@ fa_fwd_kernel64(const KernelArgs args) {
     const float c = (float)((double)(1.0f / __builtin_sqrtf((float)D)) * 1.4426950408889634074);
     const float cs = PSQ ? 1.0f : c;  // what turns an S element into a base-2 exponent (PSQ: the scale already sits in Q)
 
-    // per-lane LDS read offsets
-    //   K A-operand: row 32*nt + r31, chunk (2*ks + hi) ^ (r31 & 15)
-    const int ka_swz = SWZ ? swz_of(r31) : 0;
-    const int ka_base = r31 * ROWB;
-    //   V^T A-operand (transpose read): see header comment
-    const int li = lane & 15, lg = lane >> 4;
-    const int va_base = (4 * (lg >> 1) + (li >> 2)) * 64 + (lg & 1) * 32 + (li & 3) * 8;
-
     // a row whose keys were all masked so far has m = -inf: exponentiate against 0 instead
     auto finite_or_zero = [&](float mval) { return (MASK && mval == -__builtin_inff()) ? 0.0f : mval; };
 
     // ---- one walk over this workgroup's items: ordinals o (item = blockIdx.x + o gridDim.x) whose bit
     // min(o, 63) is set in `todo`.  FAST: the speculative schedule (see SPEC above); returns the ordinals
     // (same encoding) of the items whose check failed in any row of this wave.
-    auto walk = [&](auto fast_tag, const unsigned long long todo) -> unsigned long long {
+    // qt_tag: 32-row Q tiles per wave IN THIS WALK.  = QTP, except for the second pass of the 64-row speculative plain form
+    // (round 6, HALF below): a failed item is redone as its failed 128-row HALVES, one 32-row tile per wave -- the
+    // machinery of the QTP = 1 kernel inside this one.  A walk over half items takes half the time of a walk over whole
+    // ones, and a failure is a few rows as a rule: the launch's tail behind a failed item halves.  Per 32-row tile the
+    // one-tile walk performs exactly the arithmetic of the 64-row lazy walk (tools/check_qt1.hip: bit for bit), so a
+    // redone row is what it was when whole items were redone: the lazy variant's.  Half h of ordinal o is this walk's
+    // ordinal 2 o + h; `todo` holds the ordinals whose half 0 failed (waves 0, 1 of the first pass), `todo_hi` half 1.
+    auto walk = [&](auto fast_tag, auto qt_tag, const unsigned long long todo, const unsigned long long todo_hi) -> unsigned long long {
         constexpr bool FAST = decltype(fast_tag)::value;
+        constexpr int QT = decltype(qt_tag)::value;   // (shadows the kernel's: everything below is this walk's geometry)
+        using TR = RingTraits<QT>;
+        constexpr bool HALF = QT != QTP;
+        static_assert(!HALF || (QTP == 2 && QT == 1 && SPEC && !FAST && !MASK && !PSQ), "half items: the second pass of the 64-row speculative plain form");
         // FWD (round 6): the speculative first pass of the plain forms visits an item's K / V tiles FIRST-TO-LAST.  Its
         // reference is the row max of the first tile it visits, and attention-sink keys sit at the START of a sequence: walked
         // last-to-first (forward_kernel.cuh:142) they arrived last, ~17 binades above a reference taken at the other end --
@@ -256,32 +264,40 @@ fa_fwd_kernel64(const KernelArgs args) {
         constexpr bool FWD = FAST && !MASK;
         unsigned long long failed = 0;  // FAST: the ordinals whose check failed; the second pass: the number of items it computed
         const int n_items = args.n_bh * nq;
+        auto parent = [&](int o) { return HALF ? (o >> 1) : o; };   // the workgroup's ordinal of the (whole) item
         auto next_ord = [&](int o) {  // next ordinal of this pass behind o, or -1 (scalar; item seams only)
             for (;;) {
                 ++o;
-                if ((long long)blockIdx.x + (long long)o * (long long)gridDim.x >= (long long)n_items) return -1;
-                if (!SPEC || ((todo >> (o < 63 ? o : 63)) & 1ull)) return o;
+                const int op = parent(o);
+                if ((long long)blockIdx.x + (long long)op * (long long)gridDim.x >= (long long)n_items) return -1;
+                const unsigned long long mask = (HALF && (o & 1)) ? todo_hi : todo;
+                if (!SPEC || ((mask >> (op < 63 ? op : 63)) & 1ull)) return o;
             }
+        };
+        auto coords_of = [&](int o, int &bh_out, int &qb_out) {  // (batch * head, Q block in this walk's units) of ordinal o
+            item_coords((int)blockIdx.x + parent(o) * (int)gridDim.x, bh_out, qb_out);
+            if constexpr (HALF) qb_out = 2 * qb_out + (o & 1);
         };
         int ord = next_ord(-1);
         if (ord < 0) return failed;  // (second pass only: nothing of this workgroup's failed)
         int bh, qb;
-        item_coords((int)blockIdx.x + ord * (int)gridDim.x, bh, qb);
+        coords_of(ord, bh, qb);
         if (MASK && args.causal) qb = walk_qb((int)blockIdx.x + ord * (int)gridDim.x, qb);
         const int b = bh / args.n_heads, h = bh % args.n_heads;
         const int64_t head_off = (int64_t)b * args.batch_stride + (int64_t)h * args.head_stride;
         const uint16_t *Qg = (const uint16_t *)args.q + head_off;
-        const uint16_t *Kg = (const uint16_t *)args.k + head_off;
-        const uint16_t *Vg = (const uint16_t *)args.v + head_off;
+        const uint16_t *Kg = (const uint16_t *)args.k + head_off - DMA_BIAS / 2;   // (see DMA_BIAS: only ever a DMA base)
+        const uint16_t *Vg = (const uint16_t *)args.v + head_off - DMA_BIAS / 2;
         uint16_t *Og = (uint16_t *)args.o + head_off;
         // KV blocks are visited last-to-first (forward_kernel.cuh:142,175-184): visit index `it` is
         // sequence block n_kv-1-it.  Causal: only the 4 (qb + 1) tiles up to the item's diagonal.
         const int n_kv = (MASK && args.causal) ? 4 * (qb + 1) : args.n_kv_blocks;
         // ---- first requests of the walk: K(0), then Q (all S(0) needs); the rest follows in the prologue
         if (!(TUNE & 16)) {
-#pragma unroll
-            for (int j = 0; j < DMA_PER_WAVE; ++j)
-                glds16_sv(tile_at(Kg, FWD ? 0 : n_kv - 1), k_off[j], smem_base + (wave + NWAVES * j) * 1024);
+            static_for<0, DMA_PER_WAVE>([&](auto j_) {
+                constexpr int j = decltype(j_)::value;
+                glds16_sv_off<1024 * j>(tile_at(Kg, FWD ? 0 : n_kv - 1), k_off[j], smem_base + wave * (DMA_PER_WAVE * 1024));
+            });
         }
 
         vec8 Qr[QT][KS];  // Q of the current item (AGPRs), filled through LDS (request_q / read_q below)
@@ -352,9 +368,24 @@ fa_fwd_kernel64(const KernelArgs args) {
             float rs[QT][2] = {};
             float m_pend[QT];        // candidate reference max found during the previous visit
             unsigned resc_any = 0;   // bit qt: Q tile qt moves its reference max at the next visit's top
+            // per-lane LDS read offsets, from a volatile lane id PER WALK: derived from threadIdx at kernel entry, the ones only
+            // a walk's prologue needs stayed live across the whole first walk for the second one (round 6: one of them was
+            // the pre-scaled-Q build's 257th register)
+            //   K A-operand: row 32*nt + r31, chunk (2*ks + hi) ^ (r31 & 15)
+            //   V^T A-operand (transpose read): see fa_fwd_kernel.hpp's header comment
+            int ka_swz, ka_base, ka_hi, va_base;
+            {
+                int l_;
+                asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l_));
+                const int r31_ = l_ & 31, li = l_ & 15, lg = l_ >> 4;
+                ka_swz = SWZ ? swz_of(r31_) : 0;
+                ka_base = r31_ * ROWB;
+                ka_hi = l_ >> 5;
+                va_base = (4 * (lg >> 1) + (li >> 2)) * 64 + (lg & 1) * 32 + (li & 3) * 8;
+            }
             auto k_frag = [&](const char *kt, int step) -> vec8 {  // step = 2*ks + nt
                 const int ks = step >> 1, nt = step & 1;
-                return *(const vec8 *)(kt + nt * 32 * ROWB + ka_base + (((2 * ks + hi) ^ ka_swz) << 4));
+                return *(const vec8 *)(kt + nt * 32 * ROWB + ka_base + (((2 * ks + ka_hi) ^ ka_swz) << 4));
             };
             auto v_frag = [&](const char *vt, int step) -> vec8 {  // step = 4*s16 + t
                 const int s16 = step >> 2, t = step & 3;
@@ -414,7 +445,7 @@ fa_fwd_kernel64(const KernelArgs args) {
             // S(0) with the next item's Q (brought into the spare Q set during the item's first visits), and a
             // seam costs the O epilogue and the reset of the item state only.  After the last item the "next" item is the item itself:
             // the re-fetched tiles land in stages nobody reads.
-            int item = (int)blockIdx.x + ord * (int)gridDim.x;
+            int item = (int)blockIdx.x + parent(ord) * (int)gridDim.x;   // (the whole item's id: traces, the causal walk)
             int ord_n = -1;  // ordinal of the next item of this pass, or -1
             const uint16_t *Kc = Kg, *Vc = Vg;   // current item
             uint16_t *Oc = Og;
@@ -488,18 +519,18 @@ fa_fwd_kernel64(const KernelArgs args) {
                 }
             };
             auto dma_k = [&](const uint16_t *src, int stage) {
-#pragma unroll
-                for (int j = 0; j < DMA_PER_WAVE; ++j) {
+                static_for<0, DMA_PER_WAVE>([&](auto j_) {
+                    constexpr int j = decltype(j_)::value;
                     FA_JIT(false);
-                    glds16_sv_m0(src, k_off[j], smem_base + stage * TILE + (wave + NWAVES * j) * 1024);
-                }
+                    glds16_sv_m0_off<1024 * j>(src, k_off[j], smem_base + stage * TILE + wave * (DMA_PER_WAVE * 1024));
+                });
             };
             auto dma_v = [&](const uint16_t *src, int stage) {
-#pragma unroll
-                for (int j = 0; j < DMA_PER_WAVE; ++j) {
+                static_for<0, DMA_PER_WAVE>([&](auto j_) {
+                    constexpr int j = decltype(j_)::value;
                     FA_JIT(false);
-                    glds16_sv_m0(src, v_off[j], smem_base + V_BASE + stage * TILE + (wave + NWAVES * j) * 1024);
-                }
+                    glds16_sv_m0_off<1024 * j>(src, v_off[j], smem_base + V_BASE + stage * TILE + wave * (DMA_PER_WAVE * 1024));
+                });
             };
             const uint16_t *kq = nullptr, *vq = nullptr;  // next K / V tile to request (set per item below)
             // operand ring: slot u % RS holds operand u; the loads of operands step + LA, step + LA + 1 are issued
@@ -733,8 +764,8 @@ fa_fwd_kernel64(const KernelArgs args) {
                         zero_cinit();  // this visit forms the NEXT item's S(0): no reference yet
                     }
                 }
-                const unsigned kdst = smem_base + R * TILE + wave * 1024;                        // K(it+4) -> stage of K(it)
-                const unsigned vdst = smem_base + V_BASE + ((R + 3) & 3) * TILE + wave * 1024;   // V(it+3) -> stage of V(it-1)
+                const unsigned kdst = smem_base + R * TILE + wave * (DMA_PER_WAVE * 1024);                        // K(it+4) -> stage of K(it)
+                const unsigned vdst = smem_base + V_BASE + ((R + 3) & 3) * TILE + wave * (DMA_PER_WAVE * 1024);   // V(it+3) -> stage of V(it-1)
                 if (!FAST && resc_any) {  // wave-uniform, rare: move the reference max of one or both Q tiles
                     asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");  // MFMA D (O) -> VALU read
 #pragma unroll
@@ -893,22 +924,20 @@ fa_fwd_kernel64(const KernelArgs args) {
                             mask_tile(S_nxt, nkn - 1, qb_n, g - 34);
                         }
                     }
-                    if constexpr (g < GAPS - 1 && plan.dma[g + 1] >= 0 && !(TUNE & 16)) {
-                        // M0 (LDS destination) of the DMA piece of the NEXT gap: the write needs one instruction
-                        // between it and the DMA, and that gap's MFMA is one (hipcc itself never touches M0 here)
-                        constexpr int j = plan.dma[g + 1] >> 1;
-                        asm volatile("s_mov_b32 m0, %0" ::"s"((plan.dma[g + 1] & 1) == 0 ? kdst + NWAVES * j * 1024
-                                                                                          : vdst + NWAVES * j * 1024));
+                    if constexpr (g < GAPS - 1 && plan.dma[g + 1] >= 0 && (plan.dma[g + 1] % DMA_PER_WAVE) == 0 && !(TUNE & 16)) {
+                        // M0 (LDS destination) of the tile whose first piece rides in the NEXT gap (pieces 0..3: K, 4..7: V;
+                        // the immediate offset of a piece moves its destination on): the write needs one instruction between
+                        // it and the DMA, and that gap's MFMA is one (hipcc itself never touches M0 here)
+                        asm volatile("s_mov_b32 m0, %0" ::"s"(plan.dma[g + 1] == 0 ? kdst : vdst));
                     }
-                    if constexpr (plan.dma[g] >= 0 && !(TUNE & 16)) {  // one 1-KiB DMA piece (its M0 was set one gap ago)
-                        constexpr int j = plan.dma[g] >> 1;
-                        static_assert(g > 0 && plan.dma[g - 1] < 0, "a DMA piece needs the gap before it for its M0");
-                        // per-piece lane offsets: 6 more VGPRs than one offset + a scalar piece stride (piece j
-                        // of a wave starts 16 rows below piece j-1), but 16 fewer SALU instructions per
-                        // visit (+0.5 %)
+                    if constexpr (plan.dma[g] >= 0 && !(TUNE & 16)) {  // one 1-KiB DMA piece (its tile's M0 was set a gap or more ago)
+                        constexpr int j = plan.dma[g] % DMA_PER_WAVE;
+                        static_assert(g > 0 && plan.dma[g - 1] < 0, "a tile's first DMA piece needs the gap before it for its M0");
+                        // per-piece lane offsets: 6 more VGPRs than one offset + a scalar piece stride, but 16 fewer SALU
+                        // instructions per visit (+0.5 %, round 1)
                         FA_JIT(false);
-                        if constexpr ((plan.dma[g] & 1) == 0) glds16_issue(kq, k_off[j]);
-                        else glds16_issue(vq, v_off[j]);
+                        if constexpr (plan.dma[g] < DMA_PER_WAVE) glds16_issue_off<1024 * j>(kq, k_off[j]);
+                        else glds16_issue_off<1024 * j>(vq, v_off[j]);
                     }
                     static_for<0, plan.exp_n[g]>([&](auto i) { exp_unit_on(S_cur, plan.exp_first[g] + decltype(i)::value, IntTag<SUM_RS>{}); });
                     if constexpr (ROT_K > 0) {
@@ -1042,9 +1071,9 @@ fa_fwd_kernel64(const KernelArgs args) {
             auto set_next = [&]() {  // coordinates of the item after `item` (or `item` again)
                 ord_n = next_ord(ord);
                 has_next = ord_n >= 0;
-                const int nitem = (int)blockIdx.x + ord_n * (int)gridDim.x;
+                const int nitem = (int)blockIdx.x + parent(ord_n) * (int)gridDim.x;
                 int bh_n;
-                item_coords(has_next ? nitem : item, bh_n, qb_n);
+                coords_of(has_next ? ord_n : ord, bh_n, qb_n);
                 if (causal) {
                     qb_n = walk_qb(has_next ? nitem : item, qb_n);
                     nkn = 4 * (qb_n + 1);
@@ -1052,8 +1081,8 @@ fa_fwd_kernel64(const KernelArgs args) {
                 const int b_n = bh_n / args.n_heads, h_n = bh_n % args.n_heads;
                 const int64_t off_n = (int64_t)b_n * args.batch_stride + (int64_t)h_n * args.head_stride;
                 Qn = (const uint16_t *)args.q + off_n;
-                Kn = (const uint16_t *)args.k + off_n;
-                Vn = (const uint16_t *)args.v + off_n;
+                Kn = (const uint16_t *)args.k + off_n - DMA_BIAS / 2;
+                Vn = (const uint16_t *)args.v + off_n - DMA_BIAS / 2;
                 On = (uint16_t *)args.o + off_n;
             };
             set_next();
@@ -1165,7 +1194,9 @@ fa_fwd_kernel64(const KernelArgs args) {
                         if (__ballot(!(l_row < kLimit)) != 0 || item_bad) failed |= 1ull << (ord < 63 ? ord : 63);
                     }
                     if constexpr (SPEC && !FAST) {
-                        if (qt == 0) ++failed;  // (scalar: one more item of the second pass, for fa_fwd_stats)
+                        // (scalar: one more item of the second pass, for fa_fwd_stats -- a whole item whose two halves are
+                        // both redone counts once, with its first half)
+                        if (qt == 0 && (!HALF || !(ord & 1) || !((todo >> (parent(ord) < 63 ? parent(ord) : 63)) & 1ull))) ++failed;
                     }
                     const float inv = 1.0f / l_row;
                     char *wp = stage_o + r31 * ROWB + hi * 8;
@@ -1277,7 +1308,7 @@ fa_fwd_kernel64(const KernelArgs args) {
                 // ---- seam: the last visit left the next item's S(0) in Sa and its row max in mraw; its
                 // first tiles are landed or in flight, its first operands sit in the ring
                 ord = ord_n;
-                item = (int)blockIdx.x + ord * (int)gridDim.x;
+                item = (int)blockIdx.x + parent(ord) * (int)gridDim.x;
                 Kc = Kn; Vc = Vn; Oc = On; qb_c = qb_n;
                 nkc = nkn;
                 set_next();
@@ -1350,23 +1381,35 @@ fa_fwd_kernel64(const KernelArgs args) {
     };  // walk
 
     if constexpr (SPEC) {
-        unsigned long long failed = walk(BoolTag<true>{}, ~0ull);
-        // every wave's failures -> one workgroup-uniform mask.  Each wave leaves its mask in its OWN O staging
+        unsigned long long failed = walk(BoolTag<true>{}, IntTag<QTP>{}, ~0ull, 0ull);
+        // every wave's failures -> workgroup-uniform masks.  Each wave leaves its mask in its OWN O staging
         // area (beside the rings: no K / V piece ever lands there, and its own epilogue reads have retired),
         // so one barrier publishes all four.
         char *slot = smem + 2 * TR::kStages * TILE;
         if (lane == 0) *(unsigned long long *)(slot + wave * 8192) = failed;
         barrier();
-        unsigned long long all = 0;
+        auto uniform64 = [&](unsigned long long x) {
+            const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)x);
+            const unsigned hi32 = __builtin_amdgcn_readfirstlane((unsigned)(x >> 32));
+            return ((unsigned long long)hi32 << 32) | lo;
+        };
+        // the 64-row speculative plain form redoes a failed item as its failed HALVES (see walk): waves 0 and 1 own an item's
+        // rows 0 .. 127, waves 2 and 3 its rows 128 .. 255
+        constexpr bool HALVES = QTP == 2 && !MASK && !PSQ;
+        unsigned long long lo_half = 0, hi_half = 0;
 #pragma unroll
-        for (int w = 0; w < NWAVES; ++w) all |= *(const unsigned long long *)(slot + w * 8192);
-        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)all);
-        const unsigned hi32 = __builtin_amdgcn_readfirstlane((unsigned)(all >> 32));
-        all = ((unsigned long long)hi32 << 32) | lo;
+        for (int w = 0; w < NWAVES; ++w) {
+            const unsigned long long f_w = *(const unsigned long long *)(slot + w * 8192);
+            if (HALVES && w >= NWAVES / 2) hi_half |= f_w;
+            else lo_half |= f_w;
+        }
+        lo_half = uniform64(lo_half);
+        hi_half = uniform64(hi_half);
         unsigned redone = 0;
-        if (all) {
+        if (lo_half | hi_half) {
             barrier();  // (all four slots read before the second pass requests its first Q tile into one of them)
-            redone = (unsigned)walk(BoolTag<false>{}, all);
+            if constexpr (HALVES) redone = (unsigned)walk(BoolTag<false>{}, IntTag<1>{}, lo_half, hi_half);
+            else redone = (unsigned)walk(BoolTag<false>{}, IntTag<QTP>{}, lo_half, 0ull);
         }
         if (redone && threadIdx.x == 0) report_redo(args);
         if (args.stats && threadIdx.x == 0) {  // fa_fwd_stats: this workgroup's items, and how many of them ran twice
@@ -1375,7 +1418,7 @@ fa_fwd_kernel64(const KernelArgs args) {
             if (redone) atomicAdd(args.stats + 1, redone);
         }
     } else {
-        walk(BoolTag<false>{}, ~0ull);
+        walk(BoolTag<false>{}, IntTag<QTP>{}, ~0ull, 0ull);
         if (args.stats && threadIdx.x == 0) {
             const long long n_items = (long long)args.n_bh * args.n_q_blocks;
             atomicAdd(args.stats, (unsigned)((n_items - (long long)blockIdx.x + (long long)gridDim.x - 1) / (long long)gridDim.x));

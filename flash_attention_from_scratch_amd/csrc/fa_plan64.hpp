@@ -14,7 +14,7 @@ namespace fa {
 struct Plan64 {
     signed char exp_first[64], exp_n[64];  // softmax units (2 elements each), 32 per visit, in P.V order
     signed char max_first[64], max_n[64];  // row-max units over S(it+1), 32 per visit
-    signed char dma[64];                   // DMA piece 0..7 (even = K, odd = V) or -1
+    signed char dma[64];                   // DMA piece 0..7 (0..3: the wave's four pieces of the K tile, 4..7: of the V tile) or -1
     signed char tail[64];                  // end-of-visit chain step 1.. or 0
     signed char barrier[64];               // 1: the visit's counted DMA wait + workgroup barrier
     signed char early_first[64], early_n[64];  // rotated plan: softmax units of the NEXT tile (S(it+1)), first rot_k of its 32

@@ -224,28 +224,30 @@ def lint(path, window=3, raw=2, only=None):
         # The one-Q-tile-per-wave form (template argument QTP = 1, round 5) has visits of 16 + 16.
         mf = [i for i, l in enumerate(code) if l.startswith("v_mfma")]
         kinds = "".join("a" if code[i].split()[1].startswith("a[") else "v" for i in mf)
-        half = 16 if re.search(r"fa_fwd_kernel64I.*ELi1EEEvNS_10KernelArgsE", names[kidx]) else 32
-        pos = 0
-        while True:
-            j = kinds.find("v" * half + "a" * half, pos)
-            if j < 0:
-                break
-            # (a copy that touches none of the visit's own matrix registers -- O, the accumulators, and Q, the B operands --
-            # is not one of those: the pre-scaled Q of the NEXT item is written into the spare Q set on the slow path of an
-            # item's first visits, through VGPRs, while the MFMAs work on the current set)
-            used = set()
-            for i in mf[j:j + 2 * half]:
-                for tok in code[i].split()[1:]:
-                    used |= {r for r in regs2(tok) if r[0] == "a"}
-            for i in range(mf[j + 2], mf[j + 2 * half - 1] + 1):
-                if code[i].startswith("v_accvgpr_"):
-                    touched = set()
-                    for tok in code[i].split()[1:]:
-                        touched |= {r for r in regs2(tok) if r[0] == "a"}
-                    if touched & used:
-                        findings.append(("AGPR", kidx, i, code[mf[j + 2 * half - 1]], code[i]))
-                        break
-            pos = j + 2 * half
+        # (round 6: the 64-row speculative plain form redoes failed items as half items with one-tile visits: both shapes
+        # are looked for in every kernel; a 16 + 16 window inside a 32 + 32 visit checks a part of it again, harmlessly)
+        for half in (32, 16):
+          pos = 0
+          while True:
+              j = kinds.find("v" * half + "a" * half, pos)
+              if j < 0:
+                  break
+              # (a copy that touches none of the visit's own matrix registers -- O, the accumulators, and Q, the B operands --
+              # is not one of those: the pre-scaled Q of the NEXT item is written into the spare Q set on the slow path of an
+              # item's first visits, through VGPRs, while the MFMAs work on the current set)
+              used = set()
+              for i in mf[j:j + 2 * half]:
+                  for tok in code[i].split()[1:]:
+                      used |= {r for r in regs2(tok) if r[0] == "a"}
+              for i in range(mf[j + 2], mf[j + 2 * half - 1] + 1):
+                  if code[i].startswith("v_accvgpr_"):
+                      touched = set()
+                      for tok in code[i].split()[1:]:
+                          touched |= {r for r in regs2(tok) if r[0] == "a"}
+                      if touched & used:
+                          findings.append(("AGPR", kidx, i, code[mf[j + 2 * half - 1]], code[i]))
+                          break
+              pos = j + 2 * half
     return findings
 
 

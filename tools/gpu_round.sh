@@ -5,7 +5,8 @@
 #            bench      the driver's command (full line) + rocprofv3 --kernel-trace --stats of the same command (same lease),
 #                       2000 steps (sustained), no preconditioning (cold), lazy build, pre-scaled Q, fp16 + fp16 lazy
 #            data       non-Gaussian data (sink / heavy) x {always speculative, adaptive, lazy} x {bf16, fp16}
-#            workloads  c3, c4 (one GPU's shard), c3 lazy, the c2 sweep, --gpus 2 self-launched (plumbing)
+#            workloads  c3, c4 (one GPU's shard), c3 lazy, the c2 sweep, --gpus 2 and the eight-launchers-one-host rehearsal, self-launched;
+#                       where an S = 512 launch goes (tools/s512_floor.py)
 #            wideners   causal / ragged timings, the masked build with nothing masked (tools/masked_probe.py)
 #            tune       tune64: this tree's variants and the PREVIOUS round's kernel in one process; item / seam traces
 #            sweeps     pt_bench over the native configs and the reference's 80 (KERNELS=tune)
@@ -13,14 +14,14 @@
 #            soak       60 s of random launches of every variant, the same under the jitter build, jitter_check
 # Everything runs on ONE lease: bench_c1.json and rocprof_kernel_stats.csv are the same box.  (The one-off scripts of rounds
 # 1-4 are in the git history: `git log --diff-filter=D --name-only -- tools/`.)
-TAG=${1:-r05}; shift
+TAG=${1:-r06}; shift
 SECTIONS="${*:-tests bench data workloads wideners tune sweeps pmc soak}"
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
 L=flash_attention_from_scratch_amd/lib
 SPEC="(BF16, 128, 256, 64, 4): async+eager+swizzled+load_0_0_0_tiles+buffer+spec_softmax"
-ADAPT="$SPEC+adaptive"   # what best_config() returns since round 4 (both dtypes)
+ADAPT="$SPEC+adaptive"   # opt-in since round 6 (best_config() = $SPEC: stateless)
 LAZY="(BF16, 128, 256, 64, 4): async+eager+swizzled+load_0_0_0_tiles+buffer"
 QUICK="--no-cpu-baseline --no-traffic --hermetic-reps 0 --no-mfma-roof"
 has() { [[ " $SECTIONS " == *" $1 "* ]]; }
@@ -56,6 +57,8 @@ for W in c3 c4; do echo "== bench $W"; timeout 900 python bench.py --workload $W
 echo "== bench c3 with the lazy rescale"; timeout 900 python bench.py --workload c3 --steps 10 --warmup 3 $QUICK --kernel "${LAZY/BF16/FP16}" > $OUT/bench_c3_lazy.json 2>/dev/null; cut -c1-200 $OUT/bench_c3_lazy.json
 echo "== bench c2 (seq sweep, harmonic mean; per-seq_len rooflines)"; timeout 900 python bench.py --workload c2 --steps 20 --warmup 5 > $OUT/bench_c2.json 2>/dev/null; cut -c1-200 $OUT/bench_c2.json
 echo "== bench --gpus 2, self-launched (gloo; both ranks on this box's one GPU: plumbing only -- NUMA pinning, affinities in the line)"; timeout 600 python bench.py --gpus 2 --warmup 2 > $OUT/bench_n2_selflaunch.json 2> $OUT/bench_n2.err; cut -c1-200 $OUT/bench_n2_selflaunch.json
+echo "== bench --gpus 8 --workload c4 --batch-per-rank 1, self-launched: eight launchers on ONE host against this box's one GPU (host us per launch, affinity, barrier latency per rank)"; timeout 900 python bench.py --gpus 8 --workload c4 --batch-per-rank 1 --steps 10 --warmup 3 --no-cpu-baseline --no-traffic --hermetic-reps 0 --no-mfma-roof --no-variants > $OUT/bench_n8_selflaunch.json 2> $OUT/bench_n8.err; cut -c1-300 $OUT/bench_n8_selflaunch.json; tail -2 $OUT/bench_n8.err
+echo "== where an S = 512 launch goes: kernel duration and gap to the next dispatch (rocprofv3 --kernel-trace), event-timed interval, workgroup walk"; timeout 900 python tools/s512_floor.py > $OUT/s512_launch_breakdown.txt 2>&1; cat $OUT/s512_launch_breakdown.txt | cut -c1-300; timeout 900 python tools/s512_floor.py --seq 1024 > $OUT/s1024_launch_breakdown.txt 2>&1; grep "dispatch records\|event-timed" $OUT/s1024_launch_breakdown.txt | cut -c1-300
 fi
 if has wideners; then
 echo "== wideners"; timeout 600 python flash_attention_from_scratch_amd/tools/bench_wideners.py > $OUT/wideners.txt 2>/dev/null; cat $OUT/wideners.txt
