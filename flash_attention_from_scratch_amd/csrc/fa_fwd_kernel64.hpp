@@ -115,46 +115,7 @@ fa_fwd_kernel64(const KernelArgs args) {
     const int r31 = lane & 31;
     const int hi = lane >> 5;
 #ifdef FA_JITTER
-    // Timing-perturbed build (csrc/Makefile target `jitter` -> lib/libfa_hip_jitter.so; the counterpart of the reference's
-    // compute-sanitizer racecheck + FA_DEBUG build, tools/debug/check_race.sh:3-4, setup.py:15,37-38 -- SURVEY.md 5).
-    // The ring protocol of this kernel rests on counted waits, a barrier two MFMAs into a visit and DMA pieces issued a
-    // fixed number of visits ahead; on an idle box the four waves run in near lockstep and a missing wait can hide.  Here
-    // every wave draws from its own LCG and sleeps 0 .. 7 x 64 cycles in front of every DMA piece, every sync point and
-    // (one time in eight) every operand wait, so the waves of a workgroup drift apart by up to a visit's length and meet
-    // each protocol step in a different order from launch to launch.  The plan, the waits and the arithmetic are the
-    // product's: outputs must be bit-identical to the product library's (tests/test_gpu_parity.py, tools/soak.py).
-    unsigned jit_state;
-    {
-        unsigned long long t_;
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_));
-        const unsigned seed_ = __builtin_amdgcn_readfirstlane((unsigned)t_ * 2654435761u + (unsigned)wave * 40503u + blockIdx.x * 9176u);
-        asm volatile("v_mov_b32 %0, %1" : "=v"(jit_state) : "s"(seed_));
-    }
-    auto jitter = [&](auto rare_tag) {
-        constexpr bool RARE = decltype(rare_tag)::value;   // true: sleep one time in eight only (the 16 operand waits of a visit)
-        unsigned n_, r_;
-        // the generator's state lives in a VECTOR register between draws (every lane the same value): as one more scalar
-        // carried through twelve visit bodies hipcc ran out of ways to keep it (it copied it into a vector register and
-        // back, which is not an instruction: "illegal VGPR to SGPR copy")
-        unsigned js_ = __builtin_amdgcn_readfirstlane(jit_state);
-        asm volatile("s_mul_i32 %0, %0, 0x19660d\n\t"
-                     "s_add_u32 %0, %0, 0x3c6ef35f\n\t"
-                     "s_lshr_b32 %1, %0, 29\n\t"        // 0 .. 7 sleeps of 64 cycles
-                     "s_bfe_u32 %2, %0, 0x30014\n\t"    // bits 20 .. 22: the one-in-eight draw
-                     "s_cmp_lg_u32 %2, 0\n\t"
-                     "s_cselect_b32 %2, %3, 0\n\t"      // RARE and the draw is not 0: no sleep
-                     "s_cmp_lg_u32 %2, 0\n\t"
-                     "s_cselect_b32 %1, 0, %1\n"
-                     ".Ljit%=:\n\t"
-                     "s_cmp_eq_u32 %1, 0\n\t"
-                     "s_cbranch_scc1 .Ljit_done%=\n\t"
-                     "s_sleep 1\n\t"
-                     "s_sub_u32 %1, %1, 1\n\t"
-                     "s_branch .Ljit%=\n"
-                     ".Ljit_done%=:"
-                     : "+s"(js_), "=&s"(n_), "=&s"(r_) : "s"(RARE ? 1u : 0u) : "scc");
-        asm volatile("v_mov_b32 %0, %1" : "=v"(jit_state) : "s"(js_));
-    };
+#include "fa_jitter64.inc"   // jit_state + jitter(): every wave sleeps 0 .. 7 x 64 cycles in front of each protocol step
 #endif
 #define FA_TRACE64_HELPERS
 #include "fa_trace64.inc"

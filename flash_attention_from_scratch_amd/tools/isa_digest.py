@@ -36,8 +36,10 @@ def hipcc_version():
     return " | ".join(keep)
 
 
-def visits_of(text, kernel_regex):
-    """-> [(block label, {op class: count}, n instructions)] for the visit blocks of the kernel matching `kernel_regex`."""
+def visits_of(text, kernel_regex, lo=56, hi=1 << 30):
+    """-> [{op class: count, "instructions": n}] for the visit blocks of the kernel matching `kernel_regex`: the basic blocks
+    with lo <= MFMAs <= hi (the 64-row visits by default; lo, hi = 28, 32 gives the half-item visits of the round-6 second
+    pass, one 32-row Q tile per wave = 16 + 16 MFMAs)."""
     m = re.search(r"^(_ZN2fa15fa_fwd_kernel64" + kernel_regex + r"EEvNS_10KernelArgsE):.*?\n(.*?)\n\s+s_endpgm", text, flags=re.S | re.M)
     if not m:
         return None
@@ -61,7 +63,7 @@ def visits_of(text, kernel_regex):
                 if (cls == "mfma" and op.startswith("v_mfma")) or (cls != "mfma" and op.startswith(cls)):
                     c[cls] += 1
                     break
-        if c["mfma"] >= 56:
+        if lo <= c["mfma"] <= hi:
             out.append({"instructions": len(ops), **{k: c[k] for k in OPS}})
     return out
 
@@ -78,7 +80,7 @@ KERNELS = {
 
 
 def digest():
-    out = {"hipcc": hipcc_version(), "kernels": {}}
+    out = {"hipcc": hipcc_version(), "kernels": {}, "second_pass_half_visits": {}}
     cache = {}
     for name, (slice_dir, regex) in KERNELS.items():
         path = os.path.join(BUILD, slice_dir, "fa_inst-hip-amdgcn-amd-amdhsa-gfx950.s")
@@ -87,6 +89,9 @@ def digest():
                 return None
             cache[path] = open(path).read()
         out["kernels"][name] = visits_of(cache[path], regex)
+        half = [v for v in (visits_of(cache[path], regex, 28, 32) or []) if v["v_max3_f32"] > 0]
+        if half:
+            out["second_pass_half_visits"][name] = half
     return out
 
 

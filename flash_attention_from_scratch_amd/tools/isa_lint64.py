@@ -225,13 +225,19 @@ def lint(path, window=3, raw=2, only=None):
         mf = [i for i, l in enumerate(code) if l.startswith("v_mfma")]
         kinds = "".join("a" if code[i].split()[1].startswith("a[") else "v" for i in mf)
         # (round 6: the 64-row speculative plain form redoes failed items as half items with one-tile visits: both shapes
-        # are looked for in every kernel; a 16 + 16 window inside a 32 + 32 visit checks a part of it again, harmlessly)
+        # are looked for in every kernel; a 16 + 16 window that lies inside a 32 + 32 visit is that visit's, not one more)
+        covered = []
         for half in (32, 16):
           pos = 0
           while True:
               j = kinds.find("v" * half + "a" * half, pos)
               if j < 0:
                   break
+              if half == 32:
+                  covered.append((j, j + 64))
+              elif any(lo <= j and j + 32 <= hi for lo, hi in covered):
+                  pos = j + 1
+                  continue
               # (a copy that touches none of the visit's own matrix registers -- O, the accumulators, and Q, the B operands --
               # is not one of those: the pre-scaled Q of the NEXT item is written into the spare Q set on the slow path of an
               # item's first visits, through VGPRs, while the MFMAs work on the current set)
