@@ -808,6 +808,7 @@ def robustness(cfg, shape, dtype, device, args, flop, sync):
     cases = [("heavy", dtype), ("sink", dtype)]
     if dtype == torch.bfloat16:
         cases.append(("sink", torch.float16))   # fp16's 16-bit P leaves ~10 nats: the case that kept round 3's fp16 default lazy
+        cases.append(("heavy", torch.float16))  # ... and the one the stateless default does NOT cover: most items run twice
     for data, dt in cases:
         gen = torch.Generator(device=device).manual_seed(4242)
         q, k, v = make_inputs(data, shape, dt, device, gen)
@@ -1137,6 +1138,9 @@ def main():
                 "global_batch": batch * world,
                 "kernel": cfg.short_form(),
                 "softmax_mode": kc.softmax_mode(cfg),
+                # (round 6: > 0 = the launcher takes the form whose every second round of a long head walks K / V
+                # [tile 0, then last-to-second]; the value is the workgroups per XCD -- Q block qb walks that way when (qb // G) is odd)
+                "kv_walk_alternates": kc.kv_walk_alternates(cfg, (hi - lo) * heads, seq, num_cus=props.multi_processor_count),
                 "parallelism": f"batch-shard x{world}, no collective",
                 "device": getattr(props, "gcnArchName", props.name),
                 "compute_units": props.multi_processor_count,

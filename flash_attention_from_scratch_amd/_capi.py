@@ -59,7 +59,7 @@ class FaKernelInfo(ctypes.Structure):
         # ABI 5: the ring form of a 32-rows-per-wave configuration (include/fa_hip.h)
         ("ring_form", ctypes.c_int32), ("ring_softmax_mode", ctypes.c_int32),
         ("ring_num_regs", ctypes.c_int32), ("ring_scratch_bytes", ctypes.c_int32),
-        ("ring_lds_bytes", ctypes.c_int32), ("persistent", ctypes.c_int32),
+        ("ring_lds_bytes", ctypes.c_int32), ("persistent", ctypes.c_int32), ("alt_form", ctypes.c_int32),
     ]
 
 

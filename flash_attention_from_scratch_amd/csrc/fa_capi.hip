@@ -220,7 +220,8 @@ void do_init_body(int dev, DeviceState *st) {
     for (const auto &e : registry()) {
         // (each function by ITS OWN LDS size: the ring form's 160 KB does not depend on what the compiler-scheduled body of
         // the same entry uses -- ADVICE r05)
-        const struct { fa::kernel_fn fn; int bytes; } fns[] = {{e.fn, e.lds_bytes}, {e.fn_ragged, e.lds_bytes}, {e.fn_ring, e.ring_lds_bytes}};
+        const struct { fa::kernel_fn fn; int bytes; } fns[] = {{e.fn, e.lds_bytes}, {e.fn_ragged, e.lds_bytes}, {e.fn_ring, e.ring_lds_bytes},
+                                                                 {e.fn_alt, e.lds_bytes}};
         for (const auto &f : fns) {
             if (!f.fn || f.bytes <= 48 * 1024) continue;
             const hipError_t rc = hipFuncSetAttribute((const void *)f.fn, hipFuncAttributeMaxDynamicSharedMemorySize, f.bytes);
@@ -362,6 +363,10 @@ int launch(const fa_fwd_args *a, const fa::KernelEntry *e, const DeviceState *de
         const unsigned cap = (unsigned)(dev->num_cus & ~7) ? (unsigned)(dev->num_cus & ~7) : 8u;
         if (n_wg > cap) n_wg = cap;
     }
+    // a long head (its Q blocks fill an even number of rounds of an XCD's n_wg / 8 workgroups): the form that walks every second
+    // round [tile 0, then last-to-second] (KernelEntry::fn_alt) -- a function of the sequence length and the CU count alone
+    if (persistent && fn == e->fn && e->fn_alt && (ka.n_bh & 7) == 0 && n_wg >= 16 && ka.n_q_blocks % (2 * (int)(n_wg >> 3)) == 0)
+        fn = e->fn_alt;
     const dim3 grid(n_wg);
     const dim3 block((unsigned)e->threads);
     void *params[] = {&ka};
@@ -738,6 +743,7 @@ static void fill_info(const fa::KernelEntry &e, fa_kernel_info *out) {
     out->ring_form = e.fn_ring ? 1 : 0;
     out->ring_lds_bytes = e.fn_ring ? e.ring_lds_bytes : 0;
     out->persistent = e.persistent;
+    out->alt_form = e.fn_alt ? 1 : 0;
     out->ring_softmax_mode = e.fn_ring ? (e.softmax_mode == FA_SOFTMAX_SPECULATIVE ? FA_SOFTMAX_SPECULATIVE : FA_SOFTMAX_LAZY) : 0;
     out->ring_num_regs = out->ring_scratch_bytes = e.fn_ring ? -1 : 0;
     if (e.fn_ring) {

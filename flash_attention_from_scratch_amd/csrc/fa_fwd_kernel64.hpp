@@ -70,13 +70,22 @@ template <int QT> struct RingTraits {
 // schedule's order; the guard's checkpoint rides in gaps 27 / 29 of every fourth visit; an item given up on is redone
 // by the lazy schedule like everywhere).  Needs seq_len % 256 == 0 like the 64-row form (four ring stages = four tiles
 // to a group); the compiler-scheduled 32-rows-per-wave body of fa_fwd_kernel.hpp serves the other multiples of 128.
-template <int DT, bool MASK = false, int ABL = 0, bool RAG = false, bool SPEC = false, bool PSQ = false, int QTP = 2>
+// ALT (round 6; the 64-row speculative plain form, chosen by the launcher for long sequences): when a head's Q blocks
+// take an even number (>= 2) of rounds of an XCD's workgroups -- n_q_blocks % (2 gridDim.x / 8) == 0, seq_len >= 16384 on
+// 256 CUs -- every second round walks the head's K / V as [tile 0, then last-to-second]: the tail of the 2 x 8 MiB stream
+// the round before left in the XCD's 4 MiB L2 is read again first instead of being evicted by a walk that starts over
+// (C3: 1.50 x the algorithmic HBM bytes without).  Tile 0 stays first -- the first pass's reference, and where attention
+// sinks sit (FWD below).  Which way an item walks is a function of its own Q block and the device's CU count, never of
+// the batch it sits in: (qb / (gridDim.x / 8)) & 1.  Same tiles, same arithmetic per tile; the fp32 sums add up in
+// the other order.  Everything else (the second pass, the other forms) keeps its order.
+template <int DT, bool MASK = false, int ABL = 0, bool RAG = false, bool SPEC = false, bool PSQ = false, int QTP = 2, bool ALT = false>
 __global__ void
 __launch_bounds__(256, 1)
 fa_fwd_kernel64(const KernelArgs args) {
     static_assert(!RAG || MASK, "the ragged form is a masked variant");
     static_assert(!PSQ || !MASK, "the pre-scaled Q is built for the plain form");
     static_assert(QTP == 2 || (QTP == 1 && !MASK && !RAG && !PSQ), "one Q tile per wave: the plain forms (lazy / speculative)");
+    static_assert(!ALT || (SPEC && !MASK && !PSQ && QTP == 2), "alternating K / V direction: the 64-row speculative plain form");
 #ifdef FA_TUNE
     constexpr int TUNE = ABL;
 #else
@@ -223,6 +232,10 @@ fa_fwd_kernel64(const KernelArgs args) {
         // fp32 sums add up in the other order).  The second pass (running max) and the masked forms (a causal item's diagonal
         // tiles are its first) keep the reference's order.
         constexpr bool FWD = FAST && !MASK;
+        constexpr bool ALTW = ALT && FWD;   // this walk alternates its K / V direction by rounds (see ALT above)
+        auto rev_of = [&](int qb_) { return ALTW && (((qb_ / ((int)gridDim.x >> 3)) & 1) != 0); };
+        // tile visited j-th by an item of nk tiles: j, or for a reversed item 0, nk - 1, nk - 2, ..., 1
+        auto tord = [&](bool rev, int nk, int j) { return (ALTW && rev) ? (j == 0 ? 0 : nk - j) : j; };
         unsigned long long failed = 0;  // FAST: the ordinals whose check failed; the second pass: the number of items it computed
         const int n_items = args.n_bh * nq;
         auto parent = [&](int o) { return HALF ? (o >> 1) : o; };   // the workgroup's ordinal of the (whole) item
@@ -419,8 +432,11 @@ fa_fwd_kernel64(const KernelArgs args) {
             // -- still a multiple of the ring depth, so the stage arithmetic along the walk holds
             const bool causal = MASK && args.causal;
             int nkc = n_kv, nkn = n_kv;  // tiles of the current / next item
+            bool rev_c = rev_of(qb), rev_n = rev_c;          // ALT: the current / next item walks [0, last .. 1]
+            int64_t dstr = rev_c ? -tile_stride : tile_stride;  // ... and its request pointers' step in the hot visits
+            (void)rev_n; (void)dstr;
             auto tile_g = [&](const uint16_t *cur, const uint16_t *nxt, int j) {
-                if constexpr (FWD) return j < nkc ? tile_at(cur, j) : tile_at(nxt, j - nkc);
+                if constexpr (FWD) return j < nkc ? tile_at(cur, tord(rev_c, nkc, j)) : tile_at(nxt, tord(rev_n, nkn, j - nkc));
                 return j < nkc ? tile_at(cur, nkc - 1 - j) : tile_at(nxt, nkn - 1 - (j - nkc));
             };
             auto lane_now = [&]() {  // volatile: anything derived from threadIdx would be kept live across the walk
@@ -428,57 +444,7 @@ fa_fwd_kernel64(const KernelArgs args) {
                 asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l_));
                 return l_;
             };
-            // MASK: logits above the causal diagonal become -inf.  `tile` counts from the start of the
-            // sequence, `qb_rows` is the Q block whose rows the S tile belongs to.  A wave's 64 rows meet
-            // the diagonal in exactly one 64-key tile; tiles beyond it are masked whole.
-            // only_nt: -1, or the one 32-key half of the tile to mask (a visit masks the halves in two consecutive gaps: each
-            // half's sixteen-register tuples are rebuilt while the old ones are still live, and all four at once cost the
-            // masked speculative build its last registers)
-            auto mask_tile = [&](auto &S, int tile, int qb_rows, int only_nt = -1) {
-                // (lane indices from a volatile v_mbcnt, as in the seam code: derived from threadIdx at kernel entry, the
-                // per-register compare constants of all four S tiles were kept in registers across the whole walk)
-                const int l_ = lane_now();
-                const int r31 = l_ & 31, hi = l_ >> 5;
-                if constexpr (RAG) {
-                    const int r0 = 64 * tile < args.seq_len - 64 ? 64 * tile : args.seq_len - 64;  // first key of the window
-                    const int delta = 64 * tile - r0;  // keys of the window in front of the tile's own first key
-                    if (delta > 0) {  // wave-uniform: the last tiles of a sequence only
-                        const int lim = delta - 4 * hi;
-#pragma unroll
-                        for (int qt = 0; qt < QT; ++qt)
-#pragma unroll
-                            for (int nt = (only_nt < 0 ? 0 : only_nt); nt < (only_nt < 0 ? NT : only_nt + 1); ++nt)
-#pragma unroll
-                                for (int r = 0; r < 16; ++r)
-                                    S[qt][nt][r] = (32 * nt + (r & 3) + 8 * (r >> 2) < lim) ? -__builtin_inff() : S[qt][nt][r];
-                    }
-                    const int row_min = 256 * qb_rows + 64 * wave;  // this wave's first row
-                    if (causal && r0 + 63 > row_min) {  // wave-uniform: some key of the window lies above some row's diagonal
-#pragma unroll
-                        for (int qt = 0; qt < QT; ++qt) {
-                            const int lim = row_min + 32 * qt + r31 - r0 - 4 * hi;  // key-in-window > lim: above the diagonal
-#pragma unroll
-                            for (int nt = (only_nt < 0 ? 0 : only_nt); nt < (only_nt < 0 ? NT : only_nt + 1); ++nt)
-#pragma unroll
-                                for (int r = 0; r < 16; ++r)
-                                    S[qt][nt][r] = (32 * nt + (r & 3) + 8 * (r >> 2) > lim) ? -__builtin_inff() : S[qt][nt][r];
-                        }
-                    }
-                } else if constexpr (MASK) {
-                    const int d = tile - (4 * qb_rows + wave);
-                    if (causal && d >= 0) {  // wave-uniform
-#pragma unroll
-                        for (int qt = 0; qt < QT; ++qt)
-#pragma unroll
-                            for (int nt = (only_nt < 0 ? 0 : only_nt); nt < (only_nt < 0 ? NT : only_nt + 1); ++nt)
-#pragma unroll
-                                for (int r = 0; r < 16; ++r) {
-                                    const int key = 32 * nt + (r & 3) + 8 * (r >> 2) + 4 * hi, row = 32 * qt + r31;
-                                    S[qt][nt][r] = (d > 0 || key > row) ? -__builtin_inff() : S[qt][nt][r];
-                                }
-                    }
-                }
-            };
+#include "fa_mask64.inc"   // mask_tile(S, tile, qb_rows, only_nt): logits above the causal diagonal / beyond a ragged end become -inf
             auto dma_k = [&](const uint16_t *src, int stage) {
                 static_for<0, DMA_PER_WAVE>([&](auto j_) {
                     constexpr int j = decltype(j_)::value;
@@ -803,8 +769,11 @@ fa_fwd_kernel64(const KernelArgs args) {
                             kq = tile_g(Kc, Kn, it + 5);
                             vq = tile_g(Vc, Vn, it + 4);
                         } else if constexpr (HOT) {  // (it + 5 < n_kv: the next requests are this item's next tiles down -- FWD: up)
-                            kq += FWD ? tile_stride : -tile_stride;
-                            vq += FWD ? tile_stride : -tile_stride;
+                            kq += ALTW ? dstr : (FWD ? tile_stride : -tile_stride);
+                            vq += ALTW ? dstr : (FWD ? tile_stride : -tile_stride);
+                        } else if constexpr (ALTW) {  // (an item's ends: by tile index -- either item may walk either way)
+                            kq = tile_g(Kc, Kn, it + 5);
+                            vq = tile_g(Vc, Vn, it + 4);
                         } else if constexpr (FWD) {
                             kq = (it + 5 == nkc) ? Kn : kq + tile_stride;
                             vq = (it + 4 == nkc) ? Vn : vq + tile_stride;
@@ -983,7 +952,10 @@ fa_fwd_kernel64(const KernelArgs args) {
                     // ---- rare ----  (per ROW: a row that does not need it keeps its scale -- dragged along by its neighbours'
                     // rescues it would sink towards l = 0 -- and a row that does is brought to l in [1, 2) in one step)
                     asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");  // the last P.V MFMAs -> VALU reads of O
-                    float nonfinite = 0.0f;  // sum of (o - o): 0 while every element of O is finite, NaN otherwise
+                    // NaN-propagating maximum of |o| over the wave's O (v_maximum3_f32: IEEE 754-2019 maximum -- a NaN operand gives
+                    // NaN): finite while every element of O is.  (Round 6: 64 instructions per Q tile where "sum of o - o" took 256,
+                    // and the multiply in pairs -- heavy-tailed keys send every item of a head through here a few times.)
+                    float o_max = 0.0f;
 #pragma unroll
                     for (int qt = 0; qt < QT; ++qt) {
                         const float lq = pair_max(l_q[qt]);           // the two lanes of a row decide together
@@ -1000,9 +972,12 @@ fa_fwd_kernel64(const KernelArgs args) {
                         for (int t = 0; t < DTILES; ++t) {
                             asm volatile("" : "+a"(O[qt][t]));  // (the copies start behind the pads above and end behind the multiply)
 #pragma unroll
-                            for (int r = 0; r < 16; ++r) {
-                                O[qt][t][r] *= sc;
-                                nonfinite += O[qt][t][r] - O[qt][t][r];
+                            for (int r = 0; r < 16; r += 2) {
+                                typedef float f32x2 __attribute__((ext_vector_type(2)));
+                                const f32x2 p2 = f32x2{O[qt][t][r], O[qt][t][r + 1]} * sc;  // v_pk_mul_f32
+                                O[qt][t][r] = p2[0];
+                                O[qt][t][r + 1] = p2[1];
+                                asm volatile("v_maximum3_f32 %0, |%1|, |%2|, %0" : "+v"(o_max) : "v"(p2[0]), "v"(p2[1]));
                             }
                             asm volatile("" : "+a"(O[qt][t]));
                         }
@@ -1024,7 +999,7 @@ fa_fwd_kernel64(const KernelArgs args) {
                     if constexpr (ROT_K > 0) {
                         if (!behind_last_visit) static_for<0, ROT_K>([&](auto i) { exp_unit_on(S_cur, decltype(i)::value, IntTag<SUM_NONE>{}); });
                     }
-                    if (__ballot(!(nonfinite == 0.0f)) != 0) item_bad = true;  // inf or NaN somewhere in O
+                    if (__ballot(!(o_max < __builtin_inff())) != 0) item_bad = true;  // inf or NaN somewhere in O
                     asm volatile("s_nop 3" ::: "memory");  // accvgpr write -> MFMA accumulator
                 }
             };
@@ -1035,6 +1010,7 @@ fa_fwd_kernel64(const KernelArgs args) {
                 const int nitem = (int)blockIdx.x + parent(ord_n) * (int)gridDim.x;
                 int bh_n;
                 coords_of(has_next ? ord_n : ord, bh_n, qb_n);
+                rev_n = rev_of(qb_n);
                 if (causal) {
                     qb_n = walk_qb(has_next ? nitem : item, qb_n);
                     nkn = 4 * (qb_n + 1);
@@ -1057,8 +1033,12 @@ fa_fwd_kernel64(const KernelArgs args) {
             FA_TLP(0);  // K(0) requested, next item known
             request_q(Qg, qb, 0, q_stage);
             if constexpr (QT == 2) request_q(Qg, qb, 1, smem_base + (wave < 2 ? 3 * TILE : V_BASE + 3 * TILE) + (wave & 1) * 8192);
+            // (TUNE & 256, tools/tune64.hip: every second workgroup of an XCD asks for V(0) before K(1) -- does the launch's first
+            // burst, 256 CUs asking for the same kind of tile at once, go faster out of step?  profiles/r06/s512_floor.txt)
+            const bool v_first = (TUNE & 256) != 0 && (((int)blockIdx.x >> 3) & 1) != 0;
+            if (v_first) dma_v(tile_g(Vc, Vn, 0), 0);
             dma_k(tile_g(Kc, Kn, 1), 1);
-            dma_v(tile_g(Vc, Vn, 0), 0);
+            if (!v_first) dma_v(tile_g(Vc, Vn, 0), 0);
             FA_TLP(1);  // Q, K(1), V(0) requested
             // S(0) of the wave's first 32 rows needs only K(0) and Q tile 0, which land ~1.5 k cycles before Q tile 1
             // (the requests return in issue order at the CU's start-up rate): start on them, take tile 1 when it is in
@@ -1115,7 +1095,10 @@ fa_fwd_kernel64(const KernelArgs args) {
                 set_cinit(Sa);
                 head_units(Sa);
                 if (!(TUNE & 8)) {  // K(1) landed (under S(0)); younger: V(0), K(2), V(1) [, K(3), V(2) [, the next Q tile 0]]
-                    if (has_next) asm volatile("s_waitcnt vmcnt(28)" ::: "memory");
+                    if (v_first) {  // (V(0) is older than K(1) here)
+                        if (has_next) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+                        else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                    } else if (has_next) asm volatile("s_waitcnt vmcnt(28)" ::: "memory");
                     else asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
                 }
                 FA_TLP(5);  // row max done, K(1) landed
@@ -1144,6 +1127,42 @@ fa_fwd_kernel64(const KernelArgs args) {
                 asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
                 const int r31 = lane & 31, hi = lane >> 5;
                 const int rsub = lane / CPR, chunk = lane & (CPR - 1);
+                // rows RPP i + rsub of a tile: one scalar base for the 32 rows, a 32-bit lane offset per store; all reads first
+                // (the waits then count down), and the read address is one XOR per row group: row = RPP i + rsub, so
+                // chunk ^ swz_of(row) = (chunk ^ rsub) ^ (RPP i & 15)
+                static_assert(D == 128 && RPP == 4, "epilogue address split");
+                const unsigned lane_off = (unsigned)rsub * (unsigned)ss * 2u + (unsigned)chunk * 16u;
+                const unsigned rd0 = (unsigned)rsub * ROWB + ((unsigned)(chunk ^ rsub) << 4);
+                s16x8 v[32 / RPP];
+                auto read_rows = [&]() {
+#pragma unroll
+                    for (int i = 0; i < 32 / RPP; ++i)
+                        v[i] = *(const s16x8 *)(stage_o + RPP * i * ROWB + (rd0 ^ (((RPP * i) & 15u) << 4)));
+                };
+                auto store_rows = [&](int qt) {
+                    const uint16_t *rows0 = Oc + ((int64_t)qb_c * TR::kBr + wave * TR::kRowsPerWave + qt * 32) * ss;
+#pragma unroll
+                    for (int i = 0; i < 32 / RPP; ++i) {
+                        // non-temporal: O is written once and not read again by this kernel (+1.3...2.8 % at
+                        // seq_len <= 1024, where the store-issue-bound epilogue is a visible share).
+                        // asm: scalar row base + 32-bit lane offset (hipcc builds a 64-bit address per lane and store)
+                        if constexpr (RAG) {  // rows beyond the sequence are not stored
+                            if (qb_c * TR::kBr + wave * TR::kRowsPerWave + qt * 32 + RPP * i + rsub >= args.seq_len) continue;
+                        }
+                        // (the row group's offset goes into the lane offset, one v_add per store: eight scalar row bases
+                        // instead cost 16 SGPRs that hipcc kept live -- spilled to VGPR lanes -- across the whole item)
+                        // s_nop 1: a store of more than 64 bits reads its data registers for two more cycles, and hipcc --
+                        // which does not see the instruction inside the asm -- may reuse v[i] for the very next vector
+                        // instruction (it did, for the next store's address: tools/isa_lint64.py, finding STDATA)
+                        // nt: O is written once and not read again (sc1 / sc0 sc1 write-through and the default policy measured
+                        // 0 / 0 / -0.1 ... -3 %: profiles/r04/tune64_store_policy.txt)
+                        asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" ::"v"(lane_off + (unsigned)(RPP * i) * (unsigned)ss * 2u), "v"(v[i]), "s"(rows0));
+                    }
+                };
+                // TUNE & 512 (tools/tune64.hip; profiles/r06/s512_floor.txt): the second tile is converted into REGISTERS under
+                // the first tile's LDS round trip and row stores, and goes through the staging area behind them
+                constexpr bool OVL = (TUNE & 512) != 0 && QT == 2;
+                u32x2 w_def[OVL ? DTILES : 1][4];
 #pragma unroll
                 for (int qt = 0; qt < QT; ++qt) {
                     const float l_row = pair_sum(rs[qt][0] + rs[qt][1]);
@@ -1175,39 +1194,21 @@ fa_fwd_kernel64(const KernelArgs args) {
                             u32x2 w;
                             w[0] = E::pack2(lo2[0], lo2[1]);
                             w[1] = E::pack2(hi2[0], hi2[1]);
-                            *(u32x2 *)(wp + (((4 * t + rq) ^ swz_of(r31)) << 4)) = w;
+                            if (OVL && qt == 1) w_def[OVL ? t : 0][rq] = w;
+                            else *(u32x2 *)(wp + (((4 * t + rq) ^ swz_of(r31)) << 4)) = w;
                         }
                         __builtin_amdgcn_sched_barrier(0);   // one d tile at a time: S(0) of the next item is live
                     }
-                    if (qt == QT - 1 && zero_behind) zero_o();
-                    // rows RPP i + rsub of the tile: one scalar base for the 32 rows, a 32-bit lane offset per store;
-                    // all reads first (the waits then count down), and the read address is one XOR per row
-                    // group: row = RPP i + rsub, so chunk ^ swz_of(row) = (chunk ^ rsub) ^ (RPP i & 15)
-                    static_assert(D == 128 && RPP == 4, "epilogue address split");
-                    const uint16_t *rows0 = Oc + ((int64_t)qb_c * TR::kBr + wave * TR::kRowsPerWave + qt * 32) * ss;
-                    const unsigned lane_off = (unsigned)rsub * (unsigned)ss * 2u + (unsigned)chunk * 16u;
-                    const unsigned rd0 = (unsigned)rsub * ROWB + ((unsigned)(chunk ^ rsub) << 4);
-                    s16x8 v[32 / RPP];
+                    if (OVL && qt == 1) {
+                        store_rows(0);
 #pragma unroll
-                    for (int i = 0; i < 32 / RPP; ++i)
-                        v[i] = *(const s16x8 *)(stage_o + RPP * i * ROWB + (rd0 ^ (((RPP * i) & 15u) << 4)));
+                        for (int t = 0; t < DTILES; ++t)
 #pragma unroll
-                    for (int i = 0; i < 32 / RPP; ++i) {
-                        // non-temporal: O is written once and not read again by this kernel (+1.3...2.8 % at
-                        // seq_len <= 1024, where the store-issue-bound epilogue is a visible share).
-                        // asm: scalar row base + 32-bit lane offset (hipcc builds a 64-bit address per lane and store)
-                        if constexpr (RAG) {  // rows beyond the sequence are not stored
-                            if (qb_c * TR::kBr + wave * TR::kRowsPerWave + qt * 32 + RPP * i + rsub >= args.seq_len) continue;
-                        }
-                        // (the row group's offset goes into the lane offset, one v_add per store: eight scalar row bases
-                        // instead cost 16 SGPRs that hipcc kept live -- spilled to VGPR lanes -- across the whole item)
-                        // s_nop 1: a store of more than 64 bits reads its data registers for two more cycles, and hipcc --
-                        // which does not see the instruction inside the asm -- may reuse v[i] for the very next vector
-                        // instruction (it did, for the next store's address: tools/isa_lint64.py, finding STDATA)
-                        // nt: O is written once and not read again (sc1 / sc0 sc1 write-through and the default policy measured
-                        // 0 / 0 / -0.1 ... -3 %: profiles/r04/tune64_store_policy.txt)
-                        asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" ::"v"(lane_off + (unsigned)(RPP * i) * (unsigned)ss * 2u), "v"(v[i]), "s"(rows0));
+                            for (int rq = 0; rq < 4; ++rq) *(u32x2 *)(wp + (((4 * t + rq) ^ swz_of(r31)) << 4)) = w_def[OVL ? t : 0][rq];
                     }
+                    if (qt == QT - 1 && zero_behind) zero_o();
+                    read_rows();
+                    if (!(OVL && qt == 0)) store_rows(qt);
                 }
             };
             // seq_len is a multiple of B_r = 256, so n_kv = seq_len / 64 is a multiple of 4 = ring depth.
@@ -1272,6 +1273,8 @@ fa_fwd_kernel64(const KernelArgs args) {
                 item = (int)blockIdx.x + parent(ord) * (int)gridDim.x;
                 Kc = Kn; Vc = Vn; Oc = On; qb_c = qb_n;
                 nkc = nkn;
+                rev_c = rev_n;
+                dstr = rev_c ? -tile_stride : tile_stride;
                 set_next();
 #if defined(FA_TRACE) && FA_TRACE >= 4
                 if (tl_seam) tl_at(53);  // coordinates of the item after
@@ -1334,6 +1337,7 @@ fa_fwd_kernel64(const KernelArgs args) {
 #if defined(FA_TRACE) && FA_TRACE >= 4
             if constexpr (FAST || !SPEC) {
                 tl_at(63);
+                tl_real(47);
                 ((unsigned *)args.trace)[(wave * 256 + (int)blockIdx.x) * 64 + lane] = tlv;
             }
 #endif

@@ -37,6 +37,10 @@ struct KernelEntry {
     // plain variant, the speculative schedule (softmax_mode 3) for the speculative one.
     kernel_fn fn_ring = nullptr;
     int ring_lds_bytes = 0;
+    // Round 6: the 64-row speculative plain form whose first pass walks every second round of a long head's Q blocks
+    // [tile 0, then last-to-second] (fa_fwd_kernel64<..., ALT = true>): the launcher takes it when a head's Q blocks fill an
+    // even number of rounds of an XCD's workgroups, so that the K / V tail a round leaves in L2 is read again first.
+    kernel_fn fn_alt = nullptr;
 };
 
 // What the OPT template flag selects in each kernel body (the device-side predicates are SPEC in
@@ -64,7 +68,8 @@ constexpr KernelEntry make_entry() {
         else
             return KernelEntry{DT, 64, 4, 64, 1, 1, OPT, 1, 1, 0, 128, TR::kThreads, TR::kLdsBytes, 1,
                                (kernel_fn)&fa_fwd_kernel64<DT, false, 0, false, OPT>, nullptr,  // OPT: speculative softmax
-                               softmax_mode_of(true, OPT, true, true, false), 0};
+                               softmax_mode_of(true, OPT, true, true, false), 0, nullptr, 0,
+                               OPT ? (kernel_fn)&fa_fwd_kernel64<DT, false, 0, false, OPT, false, 2, OPT> : nullptr};
     } else if constexpr (QT == 1 && NWAVES == 4 && BC == 64 && SWZ && EAGER && PIPE && DMA && !MASK && D == 128) {
         // the reference's winning tile shape, (B_r 128, B_c 64, 4 warps) + buffer (kernel_sass/16_A100.asm:5): the
         // compiler-scheduled body, and the hand-placed ring form for seq_len % 256 == 0.  OPT = true is the speculative

@@ -618,6 +618,21 @@ def walks_kv_forward(cfg, masked=False, seq_len=None) -> bool:
     return seq_len is not None and seq_len % 256 == 0 and has_ring_form(cfg, masked)
 
 
+def kv_walk_alternates(cfg, n_bh, seq_len, masked=False, num_cus=256) -> int:
+    """Round 6, long sequences: the 64-rows-per-wave speculative plain kernel has a form whose first pass walks every second
+    round of a head's Q blocks as [tile 0, then last-to-second] (fa_fwd_kernel64<..., ALT>, KernelEntry::fn_alt; DESIGN.md
+    3.5), so that the K / V tail the round before left in the XCD's L2 is read again first.  The launcher takes it when
+    batch * heads is a multiple of 8 and a head's Q blocks fill an even number of rounds of an XCD's workgroups.
+    -> G, the workgroups per XCD (Q block qb walks that way when (qb // G) is odd), or 0 when every item walks first-to-last.
+    A function of seq_len and the device's CU count alone: an item's bits never depend on the batch it sits in."""
+    if masked or getattr(cfg, "prescaled_q", False) or not is_persistent_shape(cfg) or not walks_kv_forward(cfg, masked, seq_len):
+        return 0
+    n_q = seq_len // 256
+    n_wg = min(n_bh * n_q, (num_cus & ~7) or 8)
+    g = n_wg >> 3
+    return g if (n_bh % 8 == 0 and n_wg >= 16 and seq_len % 256 == 0 and n_q % (2 * g) == 0) else 0
+
+
 def uses_speculative_softmax(cfg, masked=False) -> bool:
     """True where the config runs the speculative softmax: an item is first run against
     the row max of its first K/V tile only (no per-tile row max, no rescale), its row sums are checked

@@ -8,8 +8,9 @@ A100's 40 MB L2, :36,98-99), an idle spin, and the in-extension event time of
 flash_attention.forward_timed (preferred over outer events, :169-172).  Output is
 the same CSV table (mean/median/min/max/stddev ms, % of the comparator, attention
 TFLOP/s by calc_self_attn_flop) plus the roofline figure 4*B*H*S^2*d.  Clock
-pinning (nvidia-smi -lgc, :111-134) has no unprivileged ROCm equivalent on the GPU
-box; `--perf-determinism` tries `rocm-smi --setperfdeterminism` and carries on.
+pinning (nvidia-smi -lgc, :111-134) is not done: the GPU pool runs every job at the
+machine's default settings and refuses any command that would change them, so clocks
+are READ (bench.py puts the hwmon sclk / power beside every number), never set.
 
 Kernels are selected with the KERNELS env var exactly as in the reference
 (kernel_configs.get_kernel_configs): all | tune | prog[all] | "B_r,B_c" | native | best.
@@ -17,7 +18,6 @@ Kernels are selected with the KERNELS env var exactly as in the reference
 import argparse
 import csv
 import statistics
-import subprocess
 import sys
 
 import torch
@@ -105,12 +105,8 @@ def main(argv=None):
     ap.add_argument("--batch", type=int, default=0, help="override BATCH_SIZE_FOR_SEQ_LEN")
     ap.add_argument("--heads", type=int, default=BENCHMARK_N_HEADS)
     ap.add_argument("--no-ref", action="store_true", help="skip the torch SDPA comparator")
-    ap.add_argument("--perf-determinism", action="store_true")
     args = ap.parse_args(argv)
 
-    if args.perf_determinism:
-        subprocess.run("rocm-smi --setperfdeterminism 1900", shell=True,
-                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     device = torch.device("cuda:0")
     writer = csv.writer(sys.stdout)
     writer.writerow(["Kernel Name", "d_head", "seq_len", "batch", "Mean (ms)", "Median (ms)", "Min (ms)",

@@ -51,7 +51,7 @@ def symbol_to_config(symbol):
         return None
     vals = [{"true": 1, "false": 0}.get(t.strip(), t.strip()) for t in m.group(2).split(",")]
     vals = [int(v) for v in vals]
-    if m.group(1) == "64":  # fa_fwd_kernel64<DT, MASK, ABL, RAG, SPEC, PSQ, QTP>: the persistent (256, 64, 4) + buffer kernel,
+    if m.group(1) == "64":  # fa_fwd_kernel64<DT, MASK, ABL, RAG, SPEC, PSQ, QTP, ALT>: the persistent (256, 64, 4) + buffer kernel,
         # or (QTP = 1) the ring form of (128, 64, 4) + buffer
         spec = bool(vals[4]) if len(vals) > 4 else False
         qtp = vals[6] if len(vals) > 6 else 2

@@ -25,6 +25,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <vector>
+#include <algorithm>
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(e_), __LINE__); exit(2); } } while (0)
 
 #if FA_TRACE >= 4
@@ -79,6 +80,24 @@ int main(int argc, char **argv) {
             pro += r[1] - r[0]; run += r[63] - r[0]; ent += r[0] - first; ext += last - r[63];
             for (int i = 0; i + 1 < per_wg; ++i) item[i] += r[2 + i] - r[1 + i];
             fin += r[63] - r[per_wg];
+        }
+        {   // the chip-wide 100-MHz counter at every workgroup's entry (slot 46) and exit (slot 47): the clock of the walk, and where
+            // the walks lie inside the launch (VERDICT r05 task 2: what a launch spends outside its workgroups)
+            unsigned r_first = ~0u, r_last = 0; double clk = 0, in_us = 0, out_us = 0, walk_us = 0;
+            for (int w = 0; w < grid; ++w) { const unsigned *r = t.data() + w * 64; if (r[46] < r_first) r_first = r[46]; }
+            for (int w = 0; w < grid; ++w) { const unsigned *r = t.data() + w * 64; if (r[47] - r_first > r_last - r_first) r_last = r[47]; }
+            std::vector<double> ent_us(grid), ext_us(grid);
+            for (int w = 0; w < grid; ++w) {
+                const unsigned *r = t.data() + w * 64;
+                clk += (double)(r[63] - r[0]) / ((double)(r[47] - r[46]) * 0.01);   // cycles per us = MHz
+                ent_us[w] = (r[46] - r_first) * 0.01; ext_us[w] = (r_last - r[47]) * 0.01;
+                in_us += ent_us[w]; out_us += ext_us[w]; walk_us += (r[47] - r[46]) * 0.01;
+            }
+            std::sort(ent_us.begin(), ent_us.end()); std::sort(ext_us.begin(), ext_us.end());
+            printf("realtime: first entry -> last exit %.2f us of the %.2f us event bracket | walk clock %.0f MHz | a workgroup's walk %.2f us (mean) |"
+                   " entry behind the first: mean %.2f us, median %.2f, max %.2f | exit before the last: mean %.2f us, median %.2f, max %.2f\n",
+                   (r_last - r_first) * 0.01, ms * 1000, clk / grid, walk_us / grid, in_us / grid, ent_us[grid / 2], ent_us[grid - 1],
+                   out_us / grid, ext_us[grid / 2], ext_us[grid - 1]);
         }
         printf("mean over workgroups: entry +%.0f | prologue (entry -> first visit) %.0f |", ent / grid, pro / grid);
         for (int i = 0; i + 1 < per_wg; ++i) printf(" item %d (%d visits + seam) %.0f |", i, nkv, item[i] / grid);

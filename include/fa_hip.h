@@ -150,6 +150,12 @@ typedef struct fa_kernel_info {
     int32_t ring_lds_bytes;      /* dynamic LDS per workgroup of the ring form (160 KiB: one workgroup per CU); 0 without one */
     int32_t persistent;          /* 1: the variant (`fn`; a ring form always) is launched as one workgroup per CU that walks the
                                     (batch*head, Q block) items itself -- the grid is min(items, CUs rounded down to 8) */
+    int32_t alt_form;            /* 1: long sequences run a second device form of this variant, whose speculative first pass
+                                    walks every second round of a head's Q blocks [K / V tile 0, then last-to-second] so that
+                                    the tail a round left in the XCD's L2 is read again first (taken when batch * heads is a
+                                    multiple of 8 and seq_len / B_r is a multiple of 2 * grid / 8: seq_len 16384, 32768, ... on
+                                    256 CUs).  Same tiles and arithmetic per tile; which way an item walks depends on its Q
+                                    block and the CU count only, never on the batch */
 } fa_kernel_info;
 
 /* Device-side statistics (optional, fa_fwd_opts.stats): a DEVICE pointer to two 32-bit counters the
@@ -285,7 +291,7 @@ int fa_get_kernel_sized(int index, fa_kernel_info *out, uint32_t out_size);
 int fa_fwd_query_sized(const fa_fwd_config *cfg, const fa_fwd_opts *opts, fa_kernel_info *out, uint32_t out_size);
 
 /* Increases whenever a struct of this header grows or an entry point changes meaning (6 = this header: fa_kernel_info grew
- * by ring_lds_bytes and persistent; the speculative first pass of the persistent kernel walks K / V first-to-last; 5: the
+ * by ring_lds_bytes, persistent and alt_form; the speculative first pass of the persistent kernel walks K / V first-to-last; 5: the
  * adaptive record per device variant, fa_adaptive_state_for, the four ring_* fields). */
 #define FA_ABI_VERSION 6
 int fa_abi_version(void);

@@ -101,7 +101,9 @@ typedef struct {
     int prescale_q;     /* NOT the reference's arithmetic: logits from a 16-bit Q * c (the device's pre-scaled-Q option) */
     int kv_forward;     /* NOT the reference's order (forward_kernel.cuh:142 walks last-to-first): KV blocks first-to-last, as
                          * the device's speculative first pass walks them since round 6 (its reference is the row max of the
-                         * first block it visits, and attention sinks sit at the first keys) */
+                         * first block it visits, and attention sinks sit at the first keys).  A value G >= 2: first-to-last
+                         * for the Q blocks with (qb / G) even, [block 0, then last-to-second] for the others -- the device's
+                         * alternating form for long sequences (fa_fwd_kernel64<..., ALT>; G = its workgroups per XCD) */
 } tensors_t;
 
 /*
@@ -135,7 +137,8 @@ static void q_block_forward(const tensors_t *t, int64_t b, int64_t h, int64_t qb
     memset(O, 0, sizeof(float) * B_r * d);
 
     for (int64_t step = 0; step < n_kv; ++step) { /* forward_kernel.cuh:142,179-184: last to first (kv_forward: first to last) */
-        const int64_t blk = t->kv_forward ? step : n_kv - 1 - step;
+        int64_t blk = t->kv_forward ? step : n_kv - 1 - step;
+        if (t->kv_forward >= 2 && ((qb / t->kv_forward) & 1)) blk = step == 0 ? 0 : n_kv - step;
         const int is_first = (step == 0);
         /* S = Q K^T, fp32 accumulate (gemm.cuh:45-87, mma f32 accum) */
         for (int r = 0; r < rows; ++r) {
@@ -337,7 +340,7 @@ int fa_oracle_forward_blockwise_lazy_psq(const uint16_t *q, const uint16_t *k, c
 
 /* The speculative first pass of the persistent device kernel (plain forms, round 6): the reference of a row is the row max
  * of the FIRST block visited and never moves (tau = infinity), the blocks are visited first-to-last (kv_forward = 1; 0 gives
- * the masked forms' and rounds 2-5's order). */
+ * the masked forms' and rounds 2-5's order; G >= 2 the alternating order of tensors_t.kv_forward). */
 int fa_oracle_forward_blockwise_spec(const uint16_t *q, const uint16_t *k, const uint16_t *v,
                                      uint16_t *o, int dtype, int64_t batch, int64_t seq,
                                      int64_t heads, int64_t d_head, int64_t batch_stride,

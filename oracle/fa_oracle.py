@@ -147,23 +147,26 @@ def blockwise_forward_lazy(q, k, v, B_r, B_c, tau=8.0, n_threads=0, prescaled_q=
 SPEC_TAU = 1e30  # "never move the reference max": the speculative schedule's first pass
 
 
-def blockwise_forward_spec(q, k, v, B_r, B_c, kv_forward=True, n_threads=0, prescaled_q=False):
+def blockwise_forward_spec(q, k, v, B_r, B_c, kv_forward=True, n_threads=0, prescaled_q=False, alt_group=0):
     """The speculative first pass (NOT the reference's arithmetic): a row's reference is the row max of
     the first K / V block visited and never moves.  kv_forward: blocks first-to-last, as the persistent kernel's plain
-    forms walk them since round 6 (False: last-to-first = blockwise_forward_lazy with tau = SPEC_TAU)."""
+    forms walk them since round 6 (False: last-to-first = blockwise_forward_lazy with tau = SPEC_TAU).  alt_group = G >= 2:
+    the Q blocks with (qb // G) odd visit [block 0, then last-to-second] -- the device's alternating form for long
+    sequences (kernel_configs.kv_walk_alternates gives G for a launch)."""
     _check(q, k, v)
     B, S, H, D = q.shape
     o = torch.empty_like(q)
     rc = lib().fa_oracle_forward_blockwise_spec(
         q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), _code(q.dtype),
-        B, S, H, D, q.stride(0), q.stride(1), q.stride(2), B_r, B_c, int(bool(kv_forward)), int(bool(prescaled_q)), n_threads,
+        B, S, H, D, q.stride(0), q.stride(1), q.stride(2), B_r, B_c,
+        int(alt_group) if (kv_forward and alt_group >= 2) else int(bool(kv_forward)), int(bool(prescaled_q)), n_threads,
     )
     if rc != 0:
         raise RuntimeError(f"fa_oracle_forward_blockwise_spec failed: {rc}")
     return o
 
 
-def blockwise_for_config(cfg, q, k, v, n_threads=0, masked=False):
+def blockwise_for_config(cfg, q, k, v, n_threads=0, masked=False, num_cus=256):
     """The CPU restatement of the arithmetic the device variant behind `cfg` performs on inputs that
     do not trip the speculative schedule's overflow check (those rows are redone with tau = 8).
     `masked`: the config's causal / ragged form (only the persistent kernel's is speculative)."""
@@ -173,7 +176,8 @@ def blockwise_for_config(cfg, q, k, v, n_threads=0, masked=False):
     if kc.uses_speculative_softmax(cfg, masked):
         return blockwise_forward_spec(q, k, v, min(cfg.B_r, q.shape[1]), cfg.B_c,
                                       kv_forward=kc.walks_kv_forward(cfg, masked, q.shape[1]), n_threads=n_threads,
-                                      prescaled_q=psq)
+                                      prescaled_q=psq,
+                                      alt_group=kc.kv_walk_alternates(cfg, q.shape[0] * q.shape[2], q.shape[1], masked, num_cus))
     if kc.uses_lazy_rescale(cfg, q.shape[1]):
         return blockwise_forward_lazy(q, k, v, cfg.B_r, cfg.B_c, n_threads=n_threads, prescaled_q=psq)
     return blockwise_forward(q, k, v, cfg.B_r, cfg.B_c, optimized_softmax=cfg.optimized_softmax,

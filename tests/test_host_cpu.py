@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layout_matches_header():
     assert ctypes.sizeof(_capi.FaFwdConfig) == 13 * 4
     assert ctypes.sizeof(_capi.FaFwdArgs) == 4 * 8 + 7 * 8 + 13 * 4 + 4  # tail padding to 8
-    assert ctypes.sizeof(_capi.FaKernelInfo) == 13 * 4 + 8 * 4 + 4 * 4 + 2 * 4   # (+ the four ring_* fields of ABI 5, + ring_lds_bytes, persistent of ABI 6)
+    assert ctypes.sizeof(_capi.FaKernelInfo) == 13 * 4 + 8 * 4 + 4 * 4 + 3 * 4   # (+ the four ring_* fields of ABI 5, + ring_lds_bytes, persistent, alt_form of ABI 6)
     assert ctypes.sizeof(_capi.FaFwdStats) == 8
     assert ctypes.sizeof(_capi.FaFwdOpts) == 5 * 4 + 4 + 2 * 8   # five 32-bit fields, padding, two pointers
     # the header's own view, compiled: sizes and offsets of the structs ctypes mirrors

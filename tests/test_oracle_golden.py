@@ -93,6 +93,40 @@ def test_c_speculative_restatement_rising_logits_bf16():
     assert ((exact - ref).abs() <= tol).all()
 
 
+def test_c_speculative_restatement_alternating_direction_keeps_block_0_first():
+    """Round 6: the device's long-sequence form walks the Q blocks with (qb // G) odd as [block 0, then last-to-second]
+    (fa_fwd_kernel64<..., ALT>; kernel_configs.kv_walk_alternates).  The restatement with alt_group = G: the even groups'
+    rows are the first-to-last restatement's bits; the odd groups' rows differ from them in the last bits at most (same
+    terms, other order) and stay inside the bars; an fp16 attention sink at the first keys overflows nothing in either
+    direction (the reference is block 0's row max both ways: P <= 1 for the sink keys)."""
+    from flash_helpers import kernel_configs as kc
+
+    torch.manual_seed(11)
+    q, k, v = (torch.randn(1, 1024, 2, 128).to(torch.float16) for _ in range(3))
+    fwd = fo.blockwise_forward_spec(q, k, v, 256, 64, kv_forward=True)
+    alt = fo.blockwise_forward_spec(q, k, v, 256, 64, kv_forward=True, alt_group=2)   # Q blocks 2, 3 walk [0, 15 .. 1]
+    assert torch.equal(alt[:, :512], fwd[:, :512])
+    assert not torch.equal(alt[:, 512:], fwd[:, 512:])
+    ref = fo.eager_attention(q, k, v, upcast=True).float()
+    assert (alt.float() - ref).abs().max().item() <= 2 * ULP["fp16"]
+    a = (12.0 * 128 ** 0.5) ** 0.5
+    q[..., 0] = a
+    k[..., 0] = 0
+    k[:, :4, :, 0] = a
+    ref = fo.eager_attention(q, k, v, upcast=True).float()
+    alt = fo.blockwise_forward_spec(q, k, v, 256, 64, kv_forward=True, alt_group=2)
+    # (the four sink keys carry the row: outputs of magnitude 2 .. 4, where one fp16 ulp is 2^-9)
+    assert torch.isfinite(alt.float()).all() and ((alt.float() - ref).abs() <= 2.0 ** -10 * (1 + ref.abs())).all()
+    # which launches alternate: batch * heads a multiple of 8, a head's Q blocks an even number of rounds of 32 workgroups
+    cfg = kc.best_config(kc.DType.FP16, 16384)
+    assert kc.kv_walk_alternates(cfg, 64, 16384) == 32 and kc.kv_walk_alternates(cfg, 64, 32768) == 32
+    assert kc.kv_walk_alternates(cfg, 64, 8192) == 0 and kc.kv_walk_alternates(cfg, 64, 4096) == 0
+    assert kc.kv_walk_alternates(cfg, 12, 16384) == 0 and kc.kv_walk_alternates(cfg, 64, 16384, masked=True) == 0
+    assert kc.kv_walk_alternates(cfg, 64, 16384, num_cus=304) == 0   # (38 workgroups per XCD: 64 Q blocks are not whole rounds)
+    from dataclasses import replace
+    assert kc.kv_walk_alternates(replace(cfg, speculative_softmax=False), 64, 16384) == 0
+
+
 def test_c_lazy_rescale_staircase_logits():
     """Row maxima that keep rising along the visit order (keys near the start of the sequence are
     larger and are visited last) cross the threshold several times, in fp16 too (P <= 2^8)."""

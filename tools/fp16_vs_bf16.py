@@ -26,7 +26,7 @@ def parse_summary(path):
 
 
 def label(sym):
-    m = re.search(r"fa_fwd_kernel64<(\d+), (\w+), \d+, (\w+), (\w+), (\w+)(?:, \d+)?>", sym)
+    m = re.search(r"fa_fwd_kernel64<(\d+), (\w+), \d+, (\w+), (\w+), (\w+)(?:, \d+)?(?:, \w+)?>", sym)
     if not m:
         return sym[:40]
     dt, _mask, _rag, spec, psq = m.groups()

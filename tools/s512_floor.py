@@ -101,7 +101,7 @@ def main():
     if os.path.exists(t64):
         out = subprocess.run([t64, str(a.seq), str(a.batch), "16"], capture_output=True, text=True, timeout=300).stdout
         for ln in out.splitlines():
-            if ln.startswith("==") or ln.startswith("mean over"):
+            if ln.startswith("==") or ln.startswith("mean over") or ln.startswith("realtime:"):
                 print("trace64_items: " + ln[:400])
     return 0
 
