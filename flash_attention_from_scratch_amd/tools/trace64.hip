@@ -85,6 +85,7 @@ int main(int argc, char **argv) {
             // the walks lie inside the launch (VERDICT r05 task 2: what a launch spends outside its workgroups)
             unsigned r_first = ~0u, r_last = 0; double clk = 0, in_us = 0, out_us = 0, walk_us = 0;
             for (int w = 0; w < grid; ++w) { const unsigned *r = t.data() + w * 64; if (r[46] < r_first) r_first = r[46]; }
+            r_last = r_first;
             for (int w = 0; w < grid; ++w) { const unsigned *r = t.data() + w * 64; if (r[47] - r_first > r_last - r_first) r_last = r[47]; }
             std::vector<double> ent_us(grid), ext_us(grid);
             for (int w = 0; w < grid; ++w) {

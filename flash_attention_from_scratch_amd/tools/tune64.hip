@@ -49,6 +49,14 @@ template <bool SPEC> static void launch_qt1(const fa::KernelArgs &a) {
     b.n_q_blocks = a.seq_len / 128;
     hipLaunchKernelGGL(kern, dim3(b.n_bh * b.n_q_blocks < 256 ? b.n_bh * b.n_q_blocks : 256), dim3(256), 163840, 0, b);
 }
+// -7: the long-sequence form of the shipped speculative kernel (ALT: every second round of a head's Q blocks walks K / V
+// [tile 0, then last-to-second]); differs from the shipped one only where the launcher would take it (S = 16384 here)
+static void launch_alt(const fa::KernelArgs &a) {
+    auto kern = fa::fa_fwd_kernel64<15, false, 0, false, true, false, 2, true>;
+    static bool init = false;
+    if (!init) { CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 163840)); init = true; }
+    hipLaunchKernelGGL(kern, dim3(a.n_bh * a.n_q_blocks < 256 ? a.n_bh * a.n_q_blocks : 256), dim3(256), 163840, 0, a);
+}
 template <bool SPEC> static void launch_32row(const fa::KernelArgs &a) {
     using TR = fa::FwdTraits<15, 1, 4, 64, true, true, SPEC, true, true, false, 128>;
     auto kern = fa::fa_fwd_kernel<15, 1, 4, 64, true, true, SPEC, true, true, false, 128>;
@@ -62,6 +70,8 @@ template <int ABL> void add(const char *name) {
     if (!only_list.empty() && std::find(only_list.begin(), only_list.end(), ABL) == only_list.end()) return;
     if constexpr (ABL == -3 || ABL == -5) {
         variants.push_back({name, ABL, launch_qt1<ABL == -5>, 0.0, 0, 1e9f});
+    } else if constexpr (ABL == -7) {
+        variants.push_back({name, ABL, launch_alt, 0.0, 0, 1e9f});
     } else if constexpr (ABL == -4 || ABL == -6) {
         variants.push_back({name, ABL, launch_32row<ABL == -6>, 0.0, 0, 1e9f});
     } else if constexpr (ABL < 0) {

