@@ -830,7 +830,7 @@ def test_jitter_build_matches_the_product_bit_for_bit():
     pseudo-random 0 .. 7 x 64 cycles in front of every DMA piece, sync point and (one time in eight) operand wait, so the
     four waves of a workgroup drift apart by up to a visit and meet every step of the ring protocol (counted vmcnt waits,
     the barrier two MFMAs into a visit, tiles requested three visits ahead) in another order at every launch.  A missing
-    wait or a stage overwritten too early shows as different bits.  tools/jitter_check.py: ten seeded cases (item seams, the
+    wait or a stage overwritten too early shows as different bits.  tools/jitter_check.py: twelve seeded cases (item seams, the
     speculative second pass, lazy rescales, causal, ragged, both dtypes), three launches each; the jitter build's hashes
     must equal the product library's and repeat.  Then the soak (random shapes against fp32 attention) under it."""
     import subprocess
@@ -845,7 +845,7 @@ def test_jitter_build_matches_the_product_bit_for_bit():
                            text=True, timeout=900, env={**env, **extra})
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
         got = [ln for ln in r.stdout.splitlines() if ln.startswith("case ")]
-        assert len(got) == 10 and all(" finite=1 repeat=1 " in ln for ln in got), r.stdout[-3000:]
+        assert len(got) == 12 and all(" finite=1 repeat=1 " in ln for ln in got), r.stdout[-3000:]
         return got, r.stdout.splitlines()[0]
     product, which_p = lines({})
     jittered, which_j = lines({"FA_HIP_LIB": jit})

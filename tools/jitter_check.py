@@ -32,6 +32,8 @@ CASES = [
     ("fp16", 5, 1000, 7, True, True, True, True),        # ragged + causal + a spike
     ("bf16", 16, 512, 16, True, False, False, False),    # 2 items of 8 visits per workgroup
     ("bf16", 1, 8192, 8, True, False, False, False),     # 128 visits per item
+    ("fp16", 1, 16384, 8, True, False, False, False),    # round 6: the long-sequence form (every second round walks K / V [0, last .. 1])
+    ("bf16", 1, 16384, 8, True, False, False, True),     # ... and a second pass behind it (the spiked row's item walks that way: Q block 32)
 ]
 
 
