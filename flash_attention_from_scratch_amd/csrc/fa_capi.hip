@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <atomic>
@@ -365,7 +366,10 @@ int launch(const fa_fwd_args *a, const fa::KernelEntry *e, const DeviceState *de
     }
     // a long head (its Q blocks fill an even number of rounds of an XCD's n_wg / 8 workgroups): the form that walks every second
     // round [tile 0, then last-to-second] (KernelEntry::fn_alt) -- a function of the sequence length and the CU count alone
-    if (persistent && fn == e->fn && e->fn_alt && (ka.n_bh & 7) == 0 && n_wg >= 16 && ka.n_q_blocks % (2 * (int)(n_wg >> 3)) == 0)
+    // (FA_HIP_NO_ALT in the environment, read once per process: a MEASUREMENT switch -- the same launch through the plain form,
+    // for the A/B of profiles/r06/c3_alt_ab.txt; nothing in the product sets it)
+    static const bool no_alt = getenv("FA_HIP_NO_ALT") != nullptr;
+    if (!no_alt && persistent && fn == e->fn && e->fn_alt && (ka.n_bh & 7) == 0 && n_wg >= 16 && ka.n_q_blocks % (2 * (int)(n_wg >> 3)) == 0)
         fn = e->fn_alt;
     const dim3 grid(n_wg);
     const dim3 block((unsigned)e->threads);
