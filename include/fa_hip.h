@@ -155,7 +155,9 @@ typedef struct fa_kernel_info {
                                     the tail a round left in the XCD's L2 is read again first (taken when batch * heads is a
                                     multiple of 8 and seq_len / B_r is a multiple of 2 * grid / 8: seq_len 16384, 32768, ... on
                                     256 CUs).  Same tiles and arithmetic per tile; which way an item walks depends on its Q
-                                    block and the CU count only, never on the batch */
+                                    block and the CU count only, never on the batch.  (FA_HIP_NO_ALT in the environment, read
+                                    once per process, sends such launches through the plain form: a MEASUREMENT switch for
+                                    A/B runs -- profiles/r06/c3_alt_ab.txt, tools/l2_stride_probe.py -- that nothing sets) */
 } fa_kernel_info;
 
 /* Device-side statistics (optional, fa_fwd_opts.stats): a DEVICE pointer to two 32-bit counters the
