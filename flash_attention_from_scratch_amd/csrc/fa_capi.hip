@@ -354,10 +354,13 @@ int launch(const fa_fwd_args *a, const fa::KernelEntry *e, const DeviceState *de
     // the ring form of a 32-rows-per-wave configuration (KernelEntry::fn_ring): seq_len a multiple of 256
     bool persistent = e->persistent != 0;
     int lds_bytes = e->lds_bytes;
+    unsigned threads = (unsigned)e->threads;
     if (e->fn_ring && a->seq_len % 256 == 0 && !causal) {
         fn = e->fn_ring;
         lds_bytes = e->ring_lds_bytes;
         persistent = true;
+        if (e->ring_threads) threads = (unsigned)e->ring_threads;
+        if (e->ring_rows) ka.n_q_blocks = (int32_t)(a->seq_len / e->ring_rows);   // (the ring form's own items: 256 rows)
     }
     unsigned n_wg = (unsigned)(ka.n_bh * ka.n_q_blocks);
     if (persistent) {
@@ -372,7 +375,7 @@ int launch(const fa_fwd_args *a, const fa::KernelEntry *e, const DeviceState *de
     if (!no_alt && persistent && fn == e->fn && e->fn_alt && (ka.n_bh & 7) == 0 && n_wg >= 16 && ka.n_q_blocks % (2 * (int)(n_wg >> 3)) == 0)
         fn = e->fn_alt;
     const dim3 grid(n_wg);
-    const dim3 block((unsigned)e->threads);
+    const dim3 block(threads);
     void *params[] = {&ka};
     hipError_t rc = hipLaunchKernel((const void *)fn, grid, block, params, (size_t)lds_bytes, stream);
     if (rc != hipSuccess) return fail(FA_ERR_LAUNCH, "hipLaunchKernel: %s", hipGetErrorString(rc));

@@ -21,13 +21,16 @@ namespace fa {
 
 // Geometry of the persistent ring kernel (its own traits: FwdTraits describes fa_fwd_kernel.hpp's kernels, whose QT = 1
 // forms have two LDS stages): 4 waves, 64-key tiles, d_head 128, four K and four V stages + 8 KB of staging per wave.
-template <int QT> struct RingTraits {
+// NW = 8 (round 6, experimental: tools/check_nw8.hip): EIGHT waves of one 32-row Q tile each share the same rings -- two waves
+// per SIMD; 4 KB of staging per wave, so a wave's Q / O tile passes through it in two 16-row halves.
+template <int QT, int NW = 4> struct RingTraits {
     static constexpr int kRowsPerWave = 32 * QT;
-    static constexpr int kBr = kRowsPerWave * 4;
+    static constexpr int kBr = kRowsPerWave * NW;
     static constexpr int kTileBytes = 64 * 2 * 128;
     static constexpr int kStages = 4;
-    static constexpr int kThreads = 256;
-    static constexpr int kLdsBytes = 2 * kStages * kTileBytes + 4 * 32 * 2 * 128;
+    static constexpr int kThreads = 64 * NW;
+    static constexpr int kStageBytes = NW == 8 ? 4096 : 8192;   // O / Q staging per wave
+    static constexpr int kLdsBytes = 2 * kStages * kTileBytes + NW * kStageBytes;
 };
 
 // (the reference's meaning of optimized_softmax -- the first tile skips the rescale -- holds here by
@@ -70,6 +73,11 @@ template <int QT> struct RingTraits {
 // schedule's order; the guard's checkpoint rides in gaps 27 / 29 of every fourth visit; an item given up on is redone
 // by the lazy schedule like everywhere).  Needs seq_len % 256 == 0 like the 64-row form (four ring stages = four tiles
 // to a group); the compiler-scheduled 32-rows-per-wave body of fa_fwd_kernel.hpp serves the other multiples of 128.
+// NW (round 6): waves per workgroup.  4 everywhere but in the product's ring form of (128, 64, 4) + buffer, which runs QTP = 1 with
+// NW = 8: eight waves of one 32-row Q tile each share the four-stage rings (256-row items: two of the configuration's Q blocks;
+// two waves per SIMD, <= 256 registers per lane) -- a tile's sixteen DMA pieces are dealt two per wave, and a wave's staging area
+// is 4 KiB, so its Q and O tiles pass through in two 16-row halves (HSUB).  Per 32-row tile the four-wave form's arithmetic, bit
+// for bit (tools/check_nw8.hip).
 // ALT (round 6; the 64-row speculative plain form, chosen by the launcher for long sequences): when a head's Q blocks
 // take an even number (>= 2) of rounds of an XCD's workgroups -- n_q_blocks % (2 gridDim.x / 8) == 0, seq_len >= 16384 on
 // 256 CUs -- every second round walks the head's K / V as [tile 0, then last-to-second]: the tail of the 2 x 8 MiB stream
@@ -78,10 +86,11 @@ template <int QT> struct RingTraits {
 // sinks sit (FWD below).  Which way an item walks is a function of its own Q block and the device's CU count, never of
 // the batch it sits in: (qb / (gridDim.x / 8)) & 1.  Same tiles, same arithmetic per tile; the fp32 sums add up in
 // the other order.  Everything else (the second pass, the other forms) keeps its order.
-template <int DT, bool MASK = false, int ABL = 0, bool RAG = false, bool SPEC = false, bool PSQ = false, int QTP = 2, bool ALT = false>
+template <int DT, bool MASK = false, int ABL = 0, bool RAG = false, bool SPEC = false, bool PSQ = false, int QTP = 2, bool ALT = false, int NW = 4>
 __global__ void
-__launch_bounds__(256, 1)
+__launch_bounds__(64 * NW, 1)
 fa_fwd_kernel64(const KernelArgs args) {
+    static_assert(NW == 4 || (NW == 8 && QTP == 1 && !MASK && !PSQ && !ALT && ABL == 0), "eight waves: the one-Q-tile-per-wave plain forms");
     static_assert(!RAG || MASK, "the ragged form is a masked variant");
     static_assert(!PSQ || !MASK, "the pre-scaled Q is built for the plain form");
     static_assert(QTP == 2 || (QTP == 1 && !MASK && !RAG && !PSQ), "one Q tile per wave: the plain forms (lazy / speculative)");
@@ -92,12 +101,13 @@ fa_fwd_kernel64(const KernelArgs args) {
     static_assert(ABL == 0, "experiment / timing-only variants exist in tools built with -DFA_TUNE only");
     constexpr int TUNE = 0;
 #endif
-    constexpr int QT = QTP, NWAVES = 4, BC = 64, D = 128;
+    constexpr int QT = QTP, NWAVES = NW, BC = 64, D = 128;
+    constexpr bool HSUB = NW == 8;   // Q / O tiles pass through a wave's staging area in two 16-row halves
     constexpr bool SWZ = true, EAGER = true, PIPE = true, DMA = true;
 
     using E = Elem<DT>;
     using vec8 = typename E::vec8;
-    using TR = RingTraits<QT>;
+    using TR = RingTraits<QT, NW>;
 #define FA_TRACE64_MACROS
 #include "fa_trace64.inc"
 #undef FA_TRACE64_MACROS
@@ -222,7 +232,7 @@ fa_fwd_kernel64(const KernelArgs args) {
     auto walk = [&](auto fast_tag, auto qt_tag, const unsigned long long todo, const unsigned long long todo_hi) -> unsigned long long {
         constexpr bool FAST = decltype(fast_tag)::value;
         constexpr int QT = decltype(qt_tag)::value;   // (shadows the kernel's: everything below is this walk's geometry)
-        using TR = RingTraits<QT>;
+        using TR = RingTraits<QT, NW>;
         constexpr bool HALF = QT != QTP;
         static_assert(!HALF || (QTP == 2 && QT == 1 && SPEC && !FAST && !MASK && !PSQ), "half items: the second pass of the 64-row speculative plain form");
         // FWD (round 6): the speculative first pass of the plain forms visits an item's K / V tiles FIRST-TO-LAST.  Its
@@ -324,13 +334,13 @@ fa_fwd_kernel64(const KernelArgs args) {
             // reference's eager rescale (softmax.cuh:36-49); only the rounding point of P differs,
             // with the same relative error.  With O in the accumulator file a rescale costs ~200
             // issue slots per Q tile, and for random data some row of 32 finds a new max in most tiles.
-            static_assert(DMA && D == 128 && BC == 64 && NT == 2 && NWAVES == 4, "pinned schedule");
+            static_assert(DMA && D == 128 && BC == 64 && NT == 2 && (NWAVES == 4 || NWAVES == 8), "pinned schedule");
             static_assert(TR::kStages == 4, "ring depth");
             constexpr float TAU = 8.0f;
             // rotated units (fa_plan64.hpp): the speculative plain form of the 64-row kernel carries the next tile's first units
             constexpr int ROT_K = (FAST && !MASK && QT == 2) ? FA_ROT_DEFAULT : 0;
-            constexpr Plan64 plan = QT == 1 ? make_plan32(FAST) : make_plan64(MASK, FAST, 22 - ROT_K, ROT_K);
-            static_assert(QT == 1 ? plan32_ok(plan, FAST) : plan64_ok(plan, ROT_K), "filler plan violates a wait-state distance");
+            constexpr Plan64 plan = QT == 1 ? make_plan32(FAST, 2 * DMA_PER_WAVE) : make_plan64(MASK, FAST, 22 - ROT_K, ROT_K);
+            static_assert(QT == 1 ? plan32_ok(plan, FAST, 2 * DMA_PER_WAVE) : plan64_ok(plan, ROT_K), "filler plan violates a wait-state distance");
             constexpr int GAPS = 32 * QT, PH2 = 16 * QT;   // MFMAs of a visit; the first one of phase 2 (O += V P)
             static_assert(plan_barrier_gap(plan, GAPS) >= 0, "the sync point rides inside the stream");
             f32x16 Sa[QT][NT], Sb[QT][NT];
@@ -489,8 +499,9 @@ fa_fwd_kernel64(const KernelArgs args) {
             // the end of the prologue), read behind the barrier of visit 1, where tile 1 is requested,
             // which is read behind the barrier of visit 2 -- all on the slow path that the sync point of
             // an item's first three visits takes anyway, so the steady state carries none of it.
-            const unsigned q_stage = smem_base + 2 * TR::kStages * TILE + wave * 8192;
-            auto request_q = [&](const uint16_t *Qh, int qblk, int qt, unsigned stage) {  // rows 32 qt .. 32 qt + 31 of this wave's rows
+            const unsigned q_stage = smem_base + 2 * TR::kStages * TILE + wave * TR::kStageBytes;
+            // half (eight waves: 4 KB of staging): -1 = the whole tile (pieces 0 .. 7), 0 / 1 = its rows 0 .. 15 / 16 .. 31 (four pieces)
+            auto request_q = [&](const uint16_t *Qh, int qblk, int qt, unsigned stage, int half = -1) {  // rows 32 qt .. 32 qt + 31 of this wave's rows
                 const int l_ = lane_now();
                 // piece i: rows 4i .. 4i+3; this lane: row 4i + l/16, chunk (l % 16) ^ (row & 15)
                 //   = ((l % 16) ^ (l / 16)) ^ 4 (i & 3): one lane offset, 64 (i & 3) XORed in per piece
@@ -511,14 +522,33 @@ fa_fwd_kernel64(const KernelArgs args) {
                     }
                 }
                 const uint16_t *rows0 = Qh + ((int64_t)qblk * TR::kBr + wave * TR::kRowsPerWave + 32 * qt) * ss;
+                if constexpr (HSUB) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        glds16_sv_m0(rows0, (off ^ (64u * (i & 3))) + (unsigned)(4 * (i + 4 * half)) * (unsigned)ss * 2u, stage + i * 1024);
+                    return;
+                }
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     FA_JIT(false);
                     glds16_sv_m0(rows0, (off ^ (64u * (i & 3))) + (unsigned)(4 * i) * (unsigned)ss * 2u, stage + i * 1024);
                 }
             };
-            auto read_q = [&](vec8 (&dst)[KS], unsigned stage) {  // this lane's chunks: row l % 32, chunk (2 ks + l/32) ^ (row & 15)
+            auto read_q = [&](vec8 (&dst)[KS], unsigned stage, int half = -1) {  // this lane's chunks: row l % 32, chunk (2 ks + l/32) ^ (row & 15)
                 const int l_ = lane_now();
+                if constexpr (HSUB) {
+                    // the lanes whose row lies in this half (rows 0 .. 15: lanes 0-15, 32-47) read it from the 4-KB image; the others
+                    // keep what they hold (EXEC narrowed inside the asm: no divergent control flow around an accumulator-file write)
+                    const unsigned base_h = stage + (l_ & 15) * 256, x_h = (unsigned)((l_ >> 5) ^ (l_ & 15));
+                    const unsigned long long mask = half ? 0xffff0000ffff0000ull : 0x0000ffff0000ffffull;
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) {
+                        unsigned long long save_;
+                        asm volatile("s_mov_b64 %1, exec\n\ts_and_b64 exec, exec, %3\n\tds_read_b128 %0, %2\n\ts_mov_b64 exec, %1"
+                                     : "+a"(dst[ks]), "=&s"(save_) : "v"(base_h + ((x_h ^ (2 * ks)) << 4)), "s"(mask) : "memory", "scc");
+                    }
+                    return;
+                }
                 const unsigned base = stage + (l_ & 31) * 256, x = (unsigned)((l_ >> 5) ^ (l_ & 15));
                 if constexpr (PSQ) {
                     // through VGPRs: Q * c in fp32, RNE to 16 bit (the one rounding this option adds), then into the
@@ -548,8 +578,9 @@ fa_fwd_kernel64(const KernelArgs args) {
                 for (int ks = 0; ks < KS; ++ks)
                     asm volatile("ds_read_b128 %0, %1" : "=a"(dst[ks]) : "v"(base + ((x ^ (2 * ks)) << 4)) : "memory");
             };
-            auto request_next_q = [&](int qt) { request_q(Qn, qb_n, qt, q_stage); };
-            auto read_next_q = [&](vec8 (&dst)[KS]) { read_q(dst, q_stage); };
+            // sub: the wave's Q tile `sub` (four waves), or half `sub` of its one tile (eight waves)
+            auto request_next_q = [&](int sub) { if constexpr (HSUB) request_q(Qn, qb_n, 0, q_stage, sub); else request_q(Qn, qb_n, sub, q_stage); };
+            auto read_next_q = [&](vec8 (&dst)[KS], int half = -1) { read_q(dst, q_stage, half); };
             // one softmax unit = two elements of a tile's P: u = 8*s16 + 2*j + qt, in the order P.V consumes P.  Where its two
             // values go: SUM_RS the running row sums; SUM_EARLY the side sums rs_e of the rotated plan's early units (SET_EARLY:
             // the first unit of a Q tile starts them: no add), folded into rs by the next visit; SUM_NONE nowhere (the guard's
@@ -653,6 +684,25 @@ fa_fwd_kernel64(const KernelArgs args) {
                     // order: [pieces(last visit of the previous item) | 16 epilogue stores] [Q tile 0: 8]
                     // pieces(0) [Q tile 1: 8] pieces(1) pieces(2) -- and the next item's Q tiles are moved
                     // into the spare Q set here (see request_next_q).
+                    if constexpr (HSUB) {   // eight waves: four pieces per visit and wave, Q in halves of four pieces
+                        int allow = 4;
+                        if (!HOTB && it < 3) allow = (it < 2) ? 4 + seam_st + (has_next ? 4 : 0) : 4 + (has_next ? 4 : 0);
+                        if (allow == 4) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+                        else if (allow == 8) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+                        else if (allow == 12) asm volatile("s_waitcnt vmcnt(12)\n\ts_barrier" ::: "memory");
+                        else asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
+                        if constexpr (!HOTB && (R == 1 || R == 2)) {
+                            if (it == R && has_next) {   // half R - 1 of the next item's Q landed (only this visit's pieces are younger)
+                                asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                                read_next_q(Qr2[0], R - 1);
+                                if constexpr (R == 1) {
+                                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                                    request_next_q(1);
+                                }
+                            }
+                        }
+                        return;
+                    }
                     if (HOTB || it >= 3) {
                         asm volatile("s_waitcnt vmcnt(" FA_VM8 ")\n\ts_barrier" ::: "memory");
                         return;
@@ -1031,8 +1081,16 @@ fa_fwd_kernel64(const KernelArgs args) {
             // are idle until K(3) / V(2) are requested behind the barrier below.  Then K(1), V(0) here and
             // K(2), V(1) | K(3), V(2) under S(0), in the order the counted waits assume.
             FA_TLP(0);  // K(0) requested, next item known
-            request_q(Qg, qb, 0, q_stage);
-            if constexpr (QT == 2) request_q(Qg, qb, 1, smem_base + (wave < 2 ? 3 * TILE : V_BASE + 3 * TILE) + (wave & 1) * 8192);
+            // (eight waves: the tile's second half through this wave's eighth of K stage 3 / V stage 3, like the second tile of the 64-row form)
+            const unsigned q_alt = HSUB ? smem_base + (wave < 4 ? 3 * TILE : V_BASE + 3 * TILE) + (wave & 3) * 4096
+                                        : smem_base + (wave < 2 ? 3 * TILE : V_BASE + 3 * TILE) + (wave & 1) * 8192;
+            if constexpr (HSUB) {
+                request_q(Qg, qb, 0, q_stage, 0);
+                request_q(Qg, qb, 0, q_alt, 1);
+            } else {
+                request_q(Qg, qb, 0, q_stage);
+            }
+            if constexpr (QT == 2) request_q(Qg, qb, 1, q_alt);
             // (TUNE & 256, tools/tune64.hip: every second workgroup of an XCD asks for V(0) before K(1) -- does the launch's first
             // burst, 256 CUs asking for the same kind of tile at once, go faster out of step?  profiles/r06/s512_floor.txt)
             const bool v_first = (TUNE & 256) != 0 && (((int)blockIdx.x >> 3) & 1) != 0;
@@ -1044,10 +1102,16 @@ fa_fwd_kernel64(const KernelArgs args) {
             // (the requests return in issue order at the CU's start-up rate): start on them, take tile 1 when it is in
             if (!(TUNE & 8)) {  // K(0), Q tile 0 landed: [Q tile 1,] K(1), V(0) fly on
                 if constexpr (QT == 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                else if constexpr (HSUB) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // (both halves: K(1), V(0) = 2 + 2 pieces fly on)
                 else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             }
             FA_TLP(2);  // K(0), Q tile 0 landed
-            read_q(Qr[0], q_stage);
+            if constexpr (HSUB) {
+                read_q(Qr[0], q_stage, 0);
+                read_q(Qr[0], q_alt, 1);
+            } else {
+                read_q(Qr[0], q_stage);
+            }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             barrier();  // K(0) is visible
             FA_TLP(3);  // Q tile 0 read, barrier passed
@@ -1060,7 +1124,7 @@ fa_fwd_kernel64(const KernelArgs args) {
                 static_for<0, 16>([&](auto step_tag) { qk_mfma(Sa, decltype(step_tag)::value, 0, a_all[decltype(step_tag)::value]); });
                 if constexpr (QT == 2) {
                     if (!(TUNE & 8)) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // Q tile 1 landed: K(1), V(0) fly on
-                    read_q(Qr[QT - 1], smem_base + (wave < 2 ? 3 * TILE : V_BASE + 3 * TILE) + (wave & 1) * 8192);
+                    read_q(Qr[QT - 1], q_alt);
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     static_for<0, 16>([&](auto step_tag) { qk_mfma(Sa, decltype(step_tag)::value, QT - 1, a_all[decltype(step_tag)::value]); });
                 }
@@ -1098,6 +1162,9 @@ fa_fwd_kernel64(const KernelArgs args) {
                     if (v_first) {  // (V(0) is older than K(1) here)
                         if (has_next) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
                         else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                    } else if constexpr (HSUB) {   // (ten pieces of five tiles [, the next Q's first half: four])
+                        if (has_next) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+                        else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
                     } else if (has_next) asm volatile("s_waitcnt vmcnt(28)" ::: "memory");
                     else asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
                 }
@@ -1109,108 +1176,7 @@ fa_fwd_kernel64(const KernelArgs args) {
 #pragma unroll
                 for (int u = 0; u < LA; ++u) ring[u] = k_frag(smem + TILE, u);  // first operands of visit 0: K(1)
             }
-            // O of one item: finish l, normalise, RNE to 16 bit (final_softmax_normalization
-            // softmax.cuh:107-128; forward_kernel.cuh:186-203), through this wave's 8-KB LDS staging
-            // area one 32-row Q tile at a time so that the global stores are whole 256-B rows (16 B per
-            // lane, 4 rows per wave-instruction).  Wave-private: no barrier.  The 16-B chunk index is
-            // XORed with (row & 15) so the 8-B writes and the 16-B reads are bank-conflict free.
-            // zero_behind: O is cleared for the next item as soon as its last register has been read (eight MFMAs on a zero
-            // operand, which then run under the second tile's LDS round trip and row stores instead of behind the seam's
-            // row max: -0.3 k cycles per item)
-            auto store_item = [&](uint16_t *Oc, const int qb_c, const int ord, const bool zero_behind) {
-                FA_JIT(false);
-                asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // last P.V -> VALU reads of O
-                char *stage_o = smem + 2 * TR::kStages * TILE + wave * (32 * ROWB);
-                // lane-derived indices recomputed here from a volatile v_mbcnt: values derived from
-                // threadIdx at kernel entry would stay live (and get spilled) across the whole item loop
-                int lane;
-                asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
-                const int r31 = lane & 31, hi = lane >> 5;
-                const int rsub = lane / CPR, chunk = lane & (CPR - 1);
-                // rows RPP i + rsub of a tile: one scalar base for the 32 rows, a 32-bit lane offset per store; all reads first
-                // (the waits then count down), and the read address is one XOR per row group: row = RPP i + rsub, so
-                // chunk ^ swz_of(row) = (chunk ^ rsub) ^ (RPP i & 15)
-                static_assert(D == 128 && RPP == 4, "epilogue address split");
-                const unsigned lane_off = (unsigned)rsub * (unsigned)ss * 2u + (unsigned)chunk * 16u;
-                const unsigned rd0 = (unsigned)rsub * ROWB + ((unsigned)(chunk ^ rsub) << 4);
-                s16x8 v[32 / RPP];
-                auto read_rows = [&]() {
-#pragma unroll
-                    for (int i = 0; i < 32 / RPP; ++i)
-                        v[i] = *(const s16x8 *)(stage_o + RPP * i * ROWB + (rd0 ^ (((RPP * i) & 15u) << 4)));
-                };
-                auto store_rows = [&](int qt) {
-                    const uint16_t *rows0 = Oc + ((int64_t)qb_c * TR::kBr + wave * TR::kRowsPerWave + qt * 32) * ss;
-#pragma unroll
-                    for (int i = 0; i < 32 / RPP; ++i) {
-                        // non-temporal: O is written once and not read again by this kernel (+1.3...2.8 % at
-                        // seq_len <= 1024, where the store-issue-bound epilogue is a visible share).
-                        // asm: scalar row base + 32-bit lane offset (hipcc builds a 64-bit address per lane and store)
-                        if constexpr (RAG) {  // rows beyond the sequence are not stored
-                            if (qb_c * TR::kBr + wave * TR::kRowsPerWave + qt * 32 + RPP * i + rsub >= args.seq_len) continue;
-                        }
-                        // (the row group's offset goes into the lane offset, one v_add per store: eight scalar row bases
-                        // instead cost 16 SGPRs that hipcc kept live -- spilled to VGPR lanes -- across the whole item)
-                        // s_nop 1: a store of more than 64 bits reads its data registers for two more cycles, and hipcc --
-                        // which does not see the instruction inside the asm -- may reuse v[i] for the very next vector
-                        // instruction (it did, for the next store's address: tools/isa_lint64.py, finding STDATA)
-                        // nt: O is written once and not read again (sc1 / sc0 sc1 write-through and the default policy measured
-                        // 0 / 0 / -0.1 ... -3 %: profiles/r04/tune64_store_policy.txt)
-                        asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" ::"v"(lane_off + (unsigned)(RPP * i) * (unsigned)ss * 2u), "v"(v[i]), "s"(rows0));
-                    }
-                };
-                // TUNE & 512 (tools/tune64.hip; profiles/r06/s512_floor.txt): the second tile is converted into REGISTERS under
-                // the first tile's LDS round trip and row stores, and goes through the staging area behind them
-                constexpr bool OVL = (TUNE & 512) != 0 && QT == 2;
-                u32x2 w_def[OVL ? DTILES : 1][4];
-#pragma unroll
-                for (int qt = 0; qt < QT; ++qt) {
-                    const float l_row = pair_sum(rs[qt][0] + rs[qt][1]);
-                    if constexpr (FAST) {
-                        // every P of the row is <= l: below the limit nothing overflowed on the way (fp32 exp2, the
-                        // 16-bit P, fp32 O); NaN fails the compare too.  A failed item is stored all the same (its
-                        // rows are rewritten by the second pass).
-                        constexpr float kLimit = spec_limit64<DT>();
-                        if (__ballot(!(l_row < kLimit)) != 0 || item_bad) failed |= 1ull << (ord < 63 ? ord : 63);
-                    }
-                    if constexpr (SPEC && !FAST) {
-                        // (scalar: one more item of the second pass, for fa_fwd_stats -- a whole item whose two halves are
-                        // both redone counts once, with its first half)
-                        if (qt == 0 && (!HALF || !(ord & 1) || !((todo >> (parent(ord) < 63 ? parent(ord) : 63)) & 1ull))) ++failed;
-                    }
-                    const float inv = 1.0f / l_row;
-                    char *wp = stage_o + r31 * ROWB + hi * 8;
-#pragma unroll
-                    for (int t = 0; t < DTILES; ++t) {
-                        // (the tile's accumulator copies start here: hipcc otherwise reads all 128 up front and spills)
-                        asm volatile("" : "+a"(O[qt][t]));
-                        // regs 4rq..4rq+3 : d = 32t + 8rq + 4hi + 0..3  -> chunk 4t + rq, half hi.  Converted in
-                        // pairs (one v_cvt_pk per two values; a per-element convert costs three instructions per pair)
-#pragma unroll
-                        for (int rq = 0; rq < 4; ++rq) {
-                            typedef float f32x2 __attribute__((ext_vector_type(2)));
-                            const f32x2 lo2 = f32x2{O[qt][t][4 * rq], O[qt][t][4 * rq + 1]} * inv;  // v_pk_mul_f32
-                            const f32x2 hi2 = f32x2{O[qt][t][4 * rq + 2], O[qt][t][4 * rq + 3]} * inv;
-                            u32x2 w;
-                            w[0] = E::pack2(lo2[0], lo2[1]);
-                            w[1] = E::pack2(hi2[0], hi2[1]);
-                            if (OVL && qt == 1) w_def[OVL ? t : 0][rq] = w;
-                            else *(u32x2 *)(wp + (((4 * t + rq) ^ swz_of(r31)) << 4)) = w;
-                        }
-                        __builtin_amdgcn_sched_barrier(0);   // one d tile at a time: S(0) of the next item is live
-                    }
-                    if (OVL && qt == 1) {
-                        store_rows(0);
-#pragma unroll
-                        for (int t = 0; t < DTILES; ++t)
-#pragma unroll
-                            for (int rq = 0; rq < 4; ++rq) *(u32x2 *)(wp + (((4 * t + rq) ^ swz_of(r31)) << 4)) = w_def[OVL ? t : 0][rq];
-                    }
-                    if (qt == QT - 1 && zero_behind) zero_o();
-                    read_rows();
-                    if (!(OVL && qt == 0)) store_rows(qt);
-                }
-            };
+#include "fa_epilogue64.inc"   // store_item(Oc, qb_c, ord, zero_behind): the item's O through the staging area to global memory
             // seq_len is a multiple of B_r = 256, so n_kv = seq_len / 64 is a multiple of 4 = ring depth.
             // The item loop, in groups of four visits (one per ring stage): an item's first group and its last two run the
             // GENERAL visits (whatever an item's ends need, decided at run time), the groups in between the HOT ones (see
@@ -1351,7 +1317,7 @@ fa_fwd_kernel64(const KernelArgs args) {
         // area (beside the rings: no K / V piece ever lands there, and its own epilogue reads have retired),
         // so one barrier publishes all four.
         char *slot = smem + 2 * TR::kStages * TILE;
-        if (lane == 0) *(unsigned long long *)(slot + wave * 8192) = failed;
+        if (lane == 0) *(unsigned long long *)(slot + wave * TR::kStageBytes) = failed;
         barrier();
         auto uniform64 = [&](unsigned long long x) {
             const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)x);
@@ -1364,7 +1330,7 @@ fa_fwd_kernel64(const KernelArgs args) {
         unsigned long long lo_half = 0, hi_half = 0;
 #pragma unroll
         for (int w = 0; w < NWAVES; ++w) {
-            const unsigned long long f_w = *(const unsigned long long *)(slot + w * 8192);
+            const unsigned long long f_w = *(const unsigned long long *)(slot + w * TR::kStageBytes);
             if (HALVES && w >= NWAVES / 2) hi_half |= f_w;
             else lo_half |= f_w;
         }
@@ -1377,16 +1343,18 @@ fa_fwd_kernel64(const KernelArgs args) {
             else redone = (unsigned)walk(BoolTag<false>{}, IntTag<QTP>{}, lo_half, 0ull);
         }
         if (redone && threadIdx.x == 0) report_redo(args);
+        // (eight waves: a 256-row item is TWO Q blocks of the (128, 64, 4) configuration it serves -- counted as such)
+        constexpr unsigned PER_ITEM = NW == 8 ? 2 : 1;
         if (args.stats && threadIdx.x == 0) {  // fa_fwd_stats: this workgroup's items, and how many of them ran twice
             const long long n_items = (long long)args.n_bh * args.n_q_blocks;
-            atomicAdd(args.stats, (unsigned)((n_items - (long long)blockIdx.x + (long long)gridDim.x - 1) / (long long)gridDim.x));
-            if (redone) atomicAdd(args.stats + 1, redone);
+            atomicAdd(args.stats, PER_ITEM * (unsigned)((n_items - (long long)blockIdx.x + (long long)gridDim.x - 1) / (long long)gridDim.x));
+            if (redone) atomicAdd(args.stats + 1, PER_ITEM * redone);
         }
     } else {
         walk(BoolTag<false>{}, IntTag<QTP>{}, ~0ull, 0ull);
         if (args.stats && threadIdx.x == 0) {
             const long long n_items = (long long)args.n_bh * args.n_q_blocks;
-            atomicAdd(args.stats, (unsigned)((n_items - (long long)blockIdx.x + (long long)gridDim.x - 1) / (long long)gridDim.x));
+            atomicAdd(args.stats, (NW == 8 ? 2u : 1u) * (unsigned)((n_items - (long long)blockIdx.x + (long long)gridDim.x - 1) / (long long)gridDim.x));
         }
     }
 }

@@ -103,13 +103,13 @@ constexpr bool plan64_ok(const Plan64 &p, int rot_k = 0) {
 // 16 row-max units over S(it+1) (complete behind gap 15), the merged end-of-visit chain (steps 10..14), the 8 DMA
 // pieces at the even gaps 2..16 (each needs the gap before it for its M0), the barrier in gap 1; the operand wait and
 // the two reads of the next pair sit in the even gaps.  Unit u's P slice s16 = u / 4 is consumed from gap 16 + 4 s16.
-constexpr Plan64 make_plan32(bool nomax = false) {
+constexpr Plan64 make_plan32(bool nomax = false, int n_pieces = 8) {   // n_pieces: 8 (four waves), 4 (eight waves share a tile's 16 pieces)
     Plan64 p{};
     int e = 0, m = 0, d = 0;
     for (int g = 0; g < 32; ++g) {
         const int h = g - 16;
         int ne = 0, nm = 0, dm = -1, tl = 0;
-        if ((g & 1) == 0 && g >= 2 && g <= 16) dm = d++;
+        if ((g & 1) == 0 && g >= 2 && g <= 16 && d < n_pieces) dm = d++;
         if (g < 16) {
             // 11 units: the odd gaps 3..15, and the even gaps 4, 8, 12, 14 (the lighter ones: no DMA issue cost twice)
             if (g >= 3 && ((g & 1) || g == 4 || g == 8 || g == 12 || g == 14)) ne = 1;
@@ -133,7 +133,7 @@ constexpr int plan_barrier_gap(const Plan64 &p, int n_gaps) {
         if (p.barrier[g]) return g;
     return -1;
 }
-constexpr bool plan32_ok(const Plan64 &p, bool nomax = false) {
+constexpr bool plan32_ok(const Plan64 &p, bool nomax = false, int n_pieces = 8) {
     int e = 0, m = 0, d = 0, bar = -1;
     for (int g = 0; g < 32; ++g) {
         for (int u = p.exp_first[g]; u < p.exp_first[g] + p.exp_n[g]; ++u)
@@ -148,7 +148,7 @@ constexpr bool plan32_ok(const Plan64 &p, bool nomax = false) {
         if (p.barrier[g] && g >= 28) return false;                   // K(it+2) is first read at gap 30
         e += p.exp_n[g]; m += p.max_n[g]; d += p.dma[g] >= 0;
     }
-    return e == 16 && m == (nomax ? 0 : 16) && d == 8 && bar >= 0;
+    return e == 16 && m == (nomax ? 0 : 16) && d == n_pieces && bar >= 0;
 }
 
 }  // namespace fa

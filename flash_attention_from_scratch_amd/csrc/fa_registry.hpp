@@ -41,6 +41,10 @@ struct KernelEntry {
     // [tile 0, then last-to-second] (fa_fwd_kernel64<..., ALT = true>): the launcher takes it when a head's Q blocks fill an
     // even number of rounds of an XCD's workgroups, so that the K / V tail a round leaves in L2 is read again first.
     kernel_fn fn_alt = nullptr;
+    // ... the ring form's own launch geometry (round 6: eight waves of one Q tile each -- two of the shape's 128-row workgroups
+    // fused into one that shares the K / V rings: 512 threads, 256-row items); 0 = the entry's own threads / B_r
+    int ring_threads = 0;
+    int ring_rows = 0;
 };
 
 // What the OPT template flag selects in each kernel body (the device-side predicates are SPEC in
@@ -74,10 +78,15 @@ constexpr KernelEntry make_entry() {
         // the reference's winning tile shape, (B_r 128, B_c 64, 4 warps) + buffer (kernel_sass/16_A100.asm:5): the
         // compiler-scheduled body, and the hand-placed ring form for seq_len % 256 == 0.  OPT = true is the speculative
         // softmax (asked for through fa_fwd_opts only) in both.
+        // Round 6: the ring form is the EIGHT-wave one (fa_fwd_kernel64<..., QTP = 1, ALT = false, NW = 8>): 32 rows per wave as
+        // the config asks, two waves per SIMD, 256-row items -- two of the shape's 128-row workgroups fused into one that
+        // shares one set of K / V rings; per 32-row tile the arithmetic of the four-wave ring form of round 5 and of the 64-row
+        // lazy kernel, bit for bit (tools/check_nw8.hip, tools/check_qt1.hip).
         return KernelEntry{DT, 32, 4, 64, 1, 1, OPT, 1, 1, 0, 128, TR::kThreads, TR::kLdsBytes, 0,
                            (kernel_fn)&fa_fwd_kernel<DT, QT, NWAVES, BC, SWZ, EAGER, OPT, PIPE, DMA, MASK, D>, nullptr,
                            softmax_mode_of(false, OPT, EAGER, DMA, MASK), 0,
-                           (kernel_fn)&fa_fwd_kernel64<DT, false, 0, false, OPT, false, 1>, RingTraits<1>::kLdsBytes};
+                           (kernel_fn)&fa_fwd_kernel64<DT, false, 0, false, OPT, false, 1, false, 8>, RingTraits<1, 8>::kLdsBytes,
+                           nullptr, RingTraits<1, 8>::kThreads, RingTraits<1, 8>::kBr};
     } else {
         return KernelEntry{DT, 32 * QT, NWAVES, BC, SWZ, EAGER, OPT, PIPE, DMA, MASK ? 1 : 0, D, TR::kThreads,
                            TR::kLdsBytes, 0,

@@ -580,7 +580,9 @@ def has_ring_form(cfg, masked=False) -> bool:
     kernel_sass/16_A100.asm:5): launches with ``seq_len % 256 == 0`` run the hand-placed persistent kernel with one 32-row
     Q tile per wave (``fa_kernel_info.ring_form``), the other multiples of 128 the compiler-scheduled body.
     The plain configuration runs that kernel's lazy rescale, the speculative one its speculative schedule
-    (``fa_kernel_info.ring_softmax_mode``).  Not the masked forms."""
+    (``fa_kernel_info.ring_softmax_mode``).  Not the masked forms.  Round 6: the ring form runs EIGHT waves -- two of the
+    shape's 128-row Q blocks fused into one 256-row item whose waves share one set of K / V rings (two waves per SIMD); the
+    bits are the four-wave form's, and ``fa_fwd_stats`` still counts 128-row Q blocks (a redone item counts as two)."""
     return (not masked and cfg.d_head == 128 and (cfg.B_r, cfg.B_c, cfg.n_warps) == (128, 64, 4) and bool(cfg.async_copy)
             and bool(cfg.eager_load_blocks) and bool(cfg.swizzled) and bool(cfg.mma_double_buffer_loads))
 

@@ -17,7 +17,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_ISA = os.path.join(HERE, "..", "csrc", "build", "qt2_dt15", "fa_inst-hip-amdgcn-amd-amdhsa-gfx950.s")
-DEFAULT_KERNEL = r"_ZN2fa15fa_fwd_kernel64ILi15ELb0ELi0ELb0ELb1ELb0ELi2ELb0EEE"   # bf16, plain, speculative, 64 rows per wave
+DEFAULT_KERNEL = r"_ZN2fa15fa_fwd_kernel64ILi15ELb0ELi0ELb0ELb1ELb0ELi2ELb0ELi4EEE"   # bf16, plain, speculative, 64 rows per wave
 
 
 def blocks_of(text, kernel_regex):

@@ -68,16 +68,16 @@ def visits_of(text, kernel_regex, lo=56, hi=1 << 30):
     return out
 
 
-# (template arguments DT, MASK, ABL, RAG, SPEC, PSQ, QTP, ALT as hipcc mangles them)
+# (template arguments DT, MASK, ABL, RAG, SPEC, PSQ, QTP, ALT, NW as hipcc mangles them)
 KERNELS = {
-    "bf16 speculative (default)": ("qt2_dt15", "ILi15ELb0ELi0ELb0ELb1ELb0ELi2ELb0E"),
-    "bf16 lazy": ("qt2_dt15", "ILi15ELb0ELi0ELb0ELb0ELb0ELi2ELb0E"),
-    "fp16 speculative": ("qt2_dt5", "ILi5ELb0ELi0ELb0ELb1ELb0ELi2ELb0E"),
-    "fp16 lazy (default)": ("qt2_dt5", "ILi5ELb0ELi0ELb0ELb0ELb0ELi2ELb0E"),
-    "bf16 speculative, prescaled Q": ("qt2_dt15", "ILi15ELb0ELi0ELb0ELb1ELb1ELi2ELb0E"),
-    "bf16 lazy, prescaled Q": ("qt2_dt15", "ILi15ELb0ELi0ELb0ELb0ELb1ELi2ELb0E"),
-    "bf16 speculative, alternating K / V direction (long sequences)": ("qt2_dt15", "ILi15ELb0ELi0ELb0ELb1ELb0ELi2ELb1E"),
-    "fp16 speculative, alternating K / V direction (long sequences)": ("qt2_dt5", "ILi5ELb0ELi0ELb0ELb1ELb0ELi2ELb1E"),
+    "bf16 speculative (default)": ("qt2_dt15", "ILi15ELb0ELi0ELb0ELb1ELb0ELi2ELb0ELi4E"),
+    "bf16 lazy": ("qt2_dt15", "ILi15ELb0ELi0ELb0ELb0ELb0ELi2ELb0ELi4E"),
+    "fp16 speculative": ("qt2_dt5", "ILi5ELb0ELi0ELb0ELb1ELb0ELi2ELb0ELi4E"),
+    "fp16 lazy (default)": ("qt2_dt5", "ILi5ELb0ELi0ELb0ELb0ELb0ELi2ELb0ELi4E"),
+    "bf16 speculative, prescaled Q": ("qt2_dt15", "ILi15ELb0ELi0ELb0ELb1ELb1ELi2ELb0ELi4E"),
+    "bf16 lazy, prescaled Q": ("qt2_dt15", "ILi15ELb0ELi0ELb0ELb0ELb1ELi2ELb0ELi4E"),
+    "bf16 speculative, alternating K / V direction (long sequences)": ("qt2_dt15", "ILi15ELb0ELi0ELb0ELb1ELb0ELi2ELb1ELi4E"),
+    "fp16 speculative, alternating K / V direction (long sequences)": ("qt2_dt5", "ILi5ELb0ELi0ELb0ELb1ELb0ELi2ELb1ELi4E"),
 }
 
 

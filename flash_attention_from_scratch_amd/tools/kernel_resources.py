@@ -27,7 +27,8 @@ def demangle_variant(name):
         rag = int(nums[3]) if len(nums) >= 4 else 0  # masked: 2 = causal form, 3 = ragged form of the same entry
         spec = int(nums[4]) if len(nums) >= 5 else 0  # the speculative softmax = optimized_softmax
         qtp = int(nums[6]) if len(nums) >= 7 else 2   # 1: the ring form of (B_r 128, B_c 64, 4 waves) + buffer
-        return dict(dtype=dt, rows_per_wave=32 * qtp, n_waves=4, B_c=64, swizzled=1, eager=1, opt_softmax=spec,
+        nw = int(nums[8]) if len(nums) >= 9 else 4    # <..., QTP, ALT, NW>: 8 = the eight-wave ring form (round 6)
+        return dict(dtype=dt, rows_per_wave=32 * qtp, n_waves=nw, B_c=64, swizzled=1, eager=1, opt_softmax=spec,
                     pipelined=1, dma=1, masked=2 * masked + rag, d_head=128, ring_kernel=1)
     if "fa_fwd_kernel16" in name and len(nums) >= 6:
         dt, nw, bc, swz, eager, opt = map(int, nums[:6])

@@ -142,7 +142,9 @@ typedef struct fa_kernel_info {
      * 32-row Q tile per wave (the machinery of the (256, 64, 4) kernel: its lazy rescale for the plain variant,
      * bit-identical to that kernel's non-speculative form, and its speculative schedule for the speculative variant,
      * whose failed items are redone by the lazy one), the other multiples of B_r by the variant described above. */
-    int32_t ring_form;           /* 1: such a form exists for this variant */
+    int32_t ring_form;           /* 1: such a form exists for this variant.  Round 6: it runs EIGHT waves of one Q tile each (512
+                                    threads; two of the configuration's 128-row Q blocks make one 256-row item, counted as two in
+                                    fa_fwd_stats) sharing one set of K / V rings -- same bits as the four-wave form of ABI 5 */
     int32_t ring_softmax_mode;   /* its fa_softmax_mode (FA_SOFTMAX_LAZY or FA_SOFTMAX_SPECULATIVE) */
     int32_t ring_num_regs;       /* VGPR+AGPR per lane of the ring form */
     int32_t ring_scratch_bytes;  /* 0 = no spills */

@@ -138,16 +138,17 @@ def test_seam_golden_with_spikes_and_the_redo_counter(tag):
         return n
 
     # (seq_len % 256 == 0 here: the (128, 64, 4)+buffer configurations run their ring form, the persistent kernel with
-    # one Q tile per wave -- its limit, per 128-row item)
-    expect = {256: predicted_redone(256), 128: predicted_redone(128)}
+    # one Q tile per wave -- its limit; since round 6 EIGHT waves: two of the shape's 128-row Q blocks make one 256-row item, and
+    # an item that fails is counted as the two Q blocks that ran twice)
+    expect = {256: predicted_redone(256), 128: 2 * predicted_redone(256)}
     # (the spike at key 3 sits in the tile the forward walk visits FIRST: it is the reference there and fails nothing; rounds
     # 2-5, walking last-to-first, counted 7 / 8 (bf16) and 9 / 17 (fp16) -- predicted_redone(.., fwd=False) still does)
-    assert expect[256] == (4 if tag == "bf16" else 5) and expect[128] == (4 if tag == "bf16" else 9), expect
+    assert expect[256] == (4 if tag == "bf16" else 5) and expect[128] == (8 if tag == "bf16" else 10), expect
     assert predicted_redone(256, fwd=False) == (7 if tag == "bf16" else 9)
     assert predicted_redone(128, ring=False, fwd=False) == (16 if tag == "bf16" else 17)   # (the compiler-scheduled body's limit and order)
     if tag == "fp16":
         # the mild spike: 20 binades at once fail fp16 -- unless the guard has moved that row's reference up by then
-        expect[256], expect[128] = (4, 5), (8, 9)
+        expect[256], expect[128] = (4, 5), (8, 10)
     for cfg, redone in ((_persistent_cfg(name, True), expect[256]), (_persistent_cfg(name, False), 0),
                         (_native(name, 128, 64, 4, True, True), expect[128]), (_native(name, 128, 64, 4, True, False), 0),
                         (kc.FlashForwardKernelConfig(name, 128, 128, 64, 4, True, True, True, 2, 2, 0, True, True), 0)):
@@ -1954,7 +1955,8 @@ print(json.dumps(_capi.adaptive_state(0, cfg)))
 def test_ring_form_of_the_reference_winning_shape():
     """(B_r 128, B_c 64, 4 warps) + buffer -- the reference's own winning tile shape (kernel_sass/16_A100.asm:5,
     kernel_configs.py:389-423 there) -- is served, for seq_len % 256 == 0, by the hand-placed persistent kernel with ONE
-    32-row Q tile per wave (fa_fwd_kernel64<..., QTP = 1>; fa_kernel_info.ring_form), for the other
+    32-row Q tile per wave (fa_fwd_kernel64<..., QTP = 1>, since round 6 with eight waves sharing the rings: 256-row items,
+    counted as two Q blocks each in fa_fwd_stats; fa_kernel_info.ring_form), for the other
     multiples of 128 by the compiler-scheduled 32-rows-per-wave body.  The ring form runs the lazy rescale per 32-row tile
     exactly as the (256, 64, 4) kernel's non-speculative form does, so the two agree BIT FOR BIT; both forms are inside
     the reference's tolerance rule against the eager golden; every reference config of the shape reaches it (the

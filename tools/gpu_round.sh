@@ -67,6 +67,7 @@ fi
 if has tune; then
 echo "== tune64 (this tree's variants + the previous round's kernel, one process, interleaved; twice)"; timeout 600 $L/tune64 reps=8 > $OUT/tune64.txt 2>&1; timeout 600 $L/tune64 reps=8 > $OUT/tune64_again.txt 2>&1; grep -h "S= 4096\|S=  512" $OUT/tune64.txt | cut -c1-140
 echo "== check_qt1: the one-Q-tile-per-wave forms (lazy, speculative) against the 64-row lazy kernel, bit for bit"; timeout 120 $L/check_qt1 > $OUT/check_qt1.txt 2>&1; tail -3 $OUT/check_qt1.txt
+echo "== check_nw8: the eight-wave ring form (the product's ring form of (128, 64, 4)+buffer since round 6) against the 64-row lazy kernel, and timed"; timeout 300 $L/check_nw8 > $OUT/check_nw8.txt 2>&1; grep -v "^  S=" $OUT/check_nw8.txt | tail -17 | cut -c1-160
 echo "== trace64_items / seam"; for a in "512 16 16" "1024 16 16" "4096 4 16"; do timeout 120 $L/trace64_items $a 2>&1 | grep -E "^==|mean over|^realtime" | tail -3; done > $OUT/trace64_items.txt; for a in "512 16 16" "4096 4 16"; do timeout 120 $L/trace64_seam $a 2>&1 | grep -E "first seam" | tail -1 >> $OUT/trace64_items.txt; done; cut -c1-300 $OUT/trace64_items.txt
 echo "== trace64_tl: the prologue and the visits of a two-item walk (S = 512), warm and flushed"; timeout 120 $L/trace64_tl 512 16 2>&1 | grep -E "^==|^mean|^spread|^wg   0" > $OUT/trace64_timeline_s512.txt; cut -c1-260 $OUT/trace64_timeline_s512.txt
 echo "== mfma_energy"; timeout 300 $L/mfma_energy > $OUT/mfma_energy.txt 2>&1; $L/mfma_energy quick >> $OUT/mfma_energy.txt 2>&1; tail -6 $OUT/mfma_energy.txt
