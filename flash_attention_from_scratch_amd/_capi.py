@@ -60,6 +60,7 @@ class FaKernelInfo(ctypes.Structure):
         ("ring_form", ctypes.c_int32), ("ring_softmax_mode", ctypes.c_int32),
         ("ring_num_regs", ctypes.c_int32), ("ring_scratch_bytes", ctypes.c_int32),
         ("ring_lds_bytes", ctypes.c_int32), ("persistent", ctypes.c_int32), ("alt_form", ctypes.c_int32),
+        ("ring_threads", ctypes.c_int32),
     ]
 
 

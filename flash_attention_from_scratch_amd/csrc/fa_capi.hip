@@ -751,6 +751,7 @@ static void fill_info(const fa::KernelEntry &e, fa_kernel_info *out) {
     out->ring_lds_bytes = e.fn_ring ? e.ring_lds_bytes : 0;
     out->persistent = e.persistent;
     out->alt_form = e.fn_alt ? 1 : 0;
+    out->ring_threads = e.fn_ring ? (e.ring_threads ? e.ring_threads : e.threads) : 0;
     out->ring_softmax_mode = e.fn_ring ? (e.softmax_mode == FA_SOFTMAX_SPECULATIVE ? FA_SOFTMAX_SPECULATIVE : FA_SOFTMAX_LAZY) : 0;
     out->ring_num_regs = out->ring_scratch_bytes = e.fn_ring ? -1 : 0;
     if (e.fn_ring) {

@@ -160,6 +160,7 @@ typedef struct fa_kernel_info {
                                     block and the CU count only, never on the batch.  (FA_HIP_NO_ALT in the environment, read
                                     once per process, sends such launches through the plain form: a MEASUREMENT switch for
                                     A/B runs -- profiles/r06/c3_alt_ab.txt, tools/l2_stride_probe.py -- that nothing sets) */
+    int32_t ring_threads;        /* workgroup size of the ring form (512: eight waves, round 6); 0 without one */
 } fa_kernel_info;
 
 /* Device-side statistics (optional, fa_fwd_opts.stats): a DEVICE pointer to two 32-bit counters the
@@ -295,7 +296,7 @@ int fa_get_kernel_sized(int index, fa_kernel_info *out, uint32_t out_size);
 int fa_fwd_query_sized(const fa_fwd_config *cfg, const fa_fwd_opts *opts, fa_kernel_info *out, uint32_t out_size);
 
 /* Increases whenever a struct of this header grows or an entry point changes meaning (6 = this header: fa_kernel_info grew
- * by ring_lds_bytes, persistent and alt_form; the speculative first pass of the persistent kernel walks K / V first-to-last; 5: the
+ * by ring_lds_bytes, persistent, alt_form and ring_threads; the speculative first pass of the persistent kernel walks K / V first-to-last; 5: the
  * adaptive record per device variant, fa_adaptive_state_for, the four ring_* fields). */
 #define FA_ABI_VERSION 6
 int fa_abi_version(void);

@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layout_matches_header():
     assert ctypes.sizeof(_capi.FaFwdConfig) == 13 * 4
     assert ctypes.sizeof(_capi.FaFwdArgs) == 4 * 8 + 7 * 8 + 13 * 4 + 4  # tail padding to 8
-    assert ctypes.sizeof(_capi.FaKernelInfo) == 13 * 4 + 8 * 4 + 4 * 4 + 3 * 4   # (+ the four ring_* fields of ABI 5, + ring_lds_bytes, persistent, alt_form of ABI 6)
+    assert ctypes.sizeof(_capi.FaKernelInfo) == 13 * 4 + 8 * 4 + 4 * 4 + 4 * 4   # (+ the four ring_* fields of ABI 5, + ring_lds_bytes, persistent, alt_form, ring_threads of ABI 6)
     assert ctypes.sizeof(_capi.FaFwdStats) == 8
     assert ctypes.sizeof(_capi.FaFwdOpts) == 5 * 4 + 4 + 2 * 8   # five 32-bit fields, padding, two pointers
     # the header's own view, compiled: sizes and offsets of the structs ctypes mirrors
@@ -149,6 +149,7 @@ def test_one_flag_one_meaning_softmax_mode_of_every_config():
     assert len(ring) == 8 and all((c.B_r, c.B_c, c.n_warps) == (128, 64, 4) and c.mma_double_buffer_loads for c in ring)   # four per dtype
     infos = [_capi.query(c) for c in ring]
     assert all(i.ring_form == 1 and i.ring_softmax_mode == 2 and i.softmax_mode in (0, 1) for i in infos)
+    assert all(i.ring_threads == 512 and i.ring_lds_bytes == 163840 and i.threads == 256 for i in infos)   # (round 6: eight waves)
     others = [c for c in kc.get_kernels_to_build() if not kc.has_ring_form(c)]
     assert all(_capi.query(c).ring_form == 0 for c in others)
     assert kc.softmax_mode(ring[0], seq_len=1024) == "lazy" and kc.softmax_mode(ring[0], seq_len=640) != "lazy" and kc.softmax_mode(ring[0]) != "lazy"
