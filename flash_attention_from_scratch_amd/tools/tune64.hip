@@ -57,6 +57,13 @@ static void launch_alt(const fa::KernelArgs &a) {
     if (!init) { CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 163840)); init = true; }
     hipLaunchKernelGGL(kern, dim3(a.n_bh * a.n_q_blocks < 256 ? a.n_bh * a.n_q_blocks : 256), dim3(256), 163840, 0, a);
 }
+// -8 / -9: the EIGHT-wave ring form (round 6: the product's ring form of (128, 64, 4)+buffer): 256-row items, 512 threads
+template <bool SPEC> static void launch_nw8(const fa::KernelArgs &a) {
+    auto kern = fa::fa_fwd_kernel64<15, false, 0, false, SPEC, false, 1, false, 8>;
+    static bool init = false;
+    if (!init) { CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 163840)); init = true; }
+    hipLaunchKernelGGL(kern, dim3(a.n_bh * a.n_q_blocks < 256 ? a.n_bh * a.n_q_blocks : 256), dim3(512), 163840, 0, a);
+}
 template <bool SPEC> static void launch_32row(const fa::KernelArgs &a) {
     using TR = fa::FwdTraits<15, 1, 4, 64, true, true, SPEC, true, true, false, 128>;
     auto kern = fa::fa_fwd_kernel<15, 1, 4, 64, true, true, SPEC, true, true, false, 128>;
@@ -70,6 +77,8 @@ template <int ABL> void add(const char *name) {
     if (!only_list.empty() && std::find(only_list.begin(), only_list.end(), ABL) == only_list.end()) return;
     if constexpr (ABL == -3 || ABL == -5) {
         variants.push_back({name, ABL, launch_qt1<ABL == -5>, 0.0, 0, 1e9f});
+    } else if constexpr (ABL == -8 || ABL == -9) {
+        variants.push_back({name, ABL, launch_nw8<ABL == -9>, 0.0, 0, 1e9f});
     } else if constexpr (ABL == -7) {
         variants.push_back({name, ABL, launch_alt, 0.0, 0, 1e9f});
     } else if constexpr (ABL == -4 || ABL == -6) {
